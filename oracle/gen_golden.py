@@ -1,0 +1,150 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.pt by running the REAL reference
+(/root/reference, shim-imported by oracle/ref_shim.py) on CPU with seeded synthetic inputs.
+
+Run in the build container:  python oracle/gen_golden.py
+The reference cannot travel to the GPU box, the fixtures can: they hold the reference's own
+state_dict, inputs, intermediates, loss, latents, gradients and post-step VQ buffers for
+BASELINE.json configs[0] ("Tiny CTViT 64x64x32, patch 16^3, dim 128, 2 layers + 32-tok text, batch 2")
+and a second small case with 2+2 layers / ragged masks / non-square grid.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = {
+    # BASELINE.json configs[0]
+    "tiny": dict(seed=0, batch=2, frames=32, image=64, patch=16, tpatch=16, dim=128, sdepth=1, tdepth=1,
+                 heads=4, dim_head=32, codebook=512, T=32, bert_hidden=128, bert_layers=2, bert_heads=4,
+                 bert_inter=256, vocab=512, max_pos=64, dim_latent=64),
+    # deeper + odd sizes: t=3, h=w=3, ragged attention masks, dim 64, 2+2 layers
+    "small": dict(seed=1, batch=3, frames=24, image=48, patch=16, tpatch=8, dim=64, sdepth=2, tdepth=2,
+                  heads=2, dim_head=32, codebook=128, T=16, bert_hidden=64, bert_layers=2, bert_heads=2,
+                  bert_inter=128, vocab=256, max_pos=32, dim_latent=32),
+}
+
+
+def synth_inputs(c):
+    g = torch.Generator().manual_seed(1234 + c["seed"])
+    video = torch.rand(c["batch"], 1, c["frames"], c["image"], c["image"], generator=g) * 2 - 1
+    T = c["T"]
+    ids = torch.randint(3, c["vocab"], (c["batch"], T), generator=g)
+    lens = torch.randint(T // 2, T + 1, (c["batch"],), generator=g)
+    ids[:, 0] = 1  # "CLS"
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    for b in range(c["batch"]):
+        ids[b, lens[b] - 1] = 2  # "SEP"
+    ids = ids * mask
+    return video, ids, mask.long()
+
+
+def subsample(t, limit=20000):
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= limit:
+        return dict(full=True, value=t.detach().clone())
+    stride = (flat.numel() + limit - 1) // limit
+    return dict(full=False, stride=stride, value=flat[::stride].clone(), norm=flat.norm().clone())
+
+
+def build(c):
+    att, ctvit_mod, ctclip_mod = ref_shim.load_reference()
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(c["seed"])
+    image_encoder = ctvit_mod.CTViT(dim=c["dim"], codebook_size=c["codebook"], image_size=c["image"],
+                                    patch_size=c["patch"], temporal_patch_size=c["tpatch"],
+                                    spatial_depth=c["sdepth"], temporal_depth=c["tdepth"],
+                                    dim_head=c["dim_head"], heads=c["heads"])
+    bcfg = BertConfig(vocab_size=c["vocab"], hidden_size=c["bert_hidden"], num_hidden_layers=c["bert_layers"],
+                      num_attention_heads=c["bert_heads"], intermediate_size=c["bert_inter"],
+                      max_position_embeddings=c["max_pos"], hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0)
+    text_encoder = BertModel(bcfg)
+    hw = c["image"] // c["patch"]
+    t = c["frames"] // c["tpatch"]
+    clip = ctclip_mod.CTCLIP(image_encoder=image_encoder, text_encoder=text_encoder, dim_text=c["bert_hidden"],
+                             dim_image=hw * hw * c["dim"], dim_latent=c["dim_latent"],
+                             extra_latent_projection=False, use_mlm=False, downsample_image_embeds=False,
+                             use_all_token_embeds=False)
+    # make every parameter "interesting" (LayerNorm gammas=1 / biases=0 / scales=1 at init hide bugs)
+    g = torch.Generator().manual_seed(99 + c["seed"])
+    with torch.no_grad():
+        for name, p in clip.named_parameters():
+            if p.ndim <= 1 and p.numel() > 0 and name != "temperature":
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    ref_shim.seed_rel_pos(image_encoder, hw, hw)
+    return clip, t, hw
+
+
+def run_case(name, c):
+    clip, t, hw = build(c)
+    video, ids, mask = synth_inputs(c)
+    text = ref_shim.TextBatch(ids, mask)
+    sd0 = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    # parameters that never reach the hot path (*_extra, to_pixels*, first-frame embed,
+    # BERT pooler) are dropped from the fixture to keep it small; consumers load with strict=False.
+    unused = ("_extra.", "to_pixels", "to_patch_emb_first_frame", "pooler.")
+    sd_keep = {k: v for k, v in sd0.items() if not any(u in k for u in unused)}
+
+    inter = {}
+    vt = clip.visual_transformer
+
+    def hook(key):
+        def fn(_m, _i, o):
+            inter[key] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+        return fn
+
+    hs = [vt.to_patch_emb.register_forward_hook(hook("patch_emb")),
+          vt.spatial_rel_pos_bias.register_forward_hook(hook("attn_bias")),
+          vt.enc_spatial_transformer.register_forward_hook(hook("spatial_out")),
+          vt.enc_temporal_transformer.register_forward_hook(hook("temporal_out")),
+          vt.enc_spatial_transformer.layers[0][0].register_forward_hook(hook("s0_peg")),
+          vt.enc_spatial_transformer.layers[0][1].register_forward_hook(hook("s0_attn")),
+          vt.enc_spatial_transformer.layers[0][3].register_forward_hook(hook("s0_ff")),
+          vt.enc_temporal_transformer.layers[0][0].register_forward_hook(hook("t0_peg")),
+          vt.enc_temporal_transformer.layers[0][1].register_forward_hook(hook("t0_attn"))]
+    vq_out = {}
+
+    def vq_hook(_m, _i, o):
+        vq_out["indices"] = o[1].detach().clone()
+    hs.append(vt.vq.register_forward_hook(vq_hook))
+
+    # --- train-mode forward + backward (scripts/CTCLIPTrainer.py:249-257)
+    clip.train()
+    loss = clip(text, video, return_loss=True, device=torch.device("cpu"))
+    loss.backward()
+    grads = {k: subsample(p.grad) for k, p in clip.named_parameters() if p.grad is not None}
+    grad_sq = sum(float((p.grad.double() ** 2).sum()) for p in clip.parameters() if p.grad is not None)
+    sd1 = clip.state_dict()
+    vq_after = {k: sd1[k].detach().clone() for k in sd1 if "vq._codebook" in k}
+    for h in hs:
+        h.remove()
+
+    # --- latents / similarity in eval mode from the ORIGINAL buffers (zero_shot.py path, ct_clip.py:788-807)
+    clip.load_state_dict(sd0)
+    clip.eval()
+    with torch.no_grad():
+        tl, il, toks = clip(text, video, return_latents=True, device=torch.device("cpu"))
+        enc_text, enc_image = clip(text, video, return_encodings=True, device=torch.device("cpu"))
+        text2 = ref_shim.TextBatch(ids[:2], mask[:2])
+        sim = clip(text2, video[:1], device=torch.device("cpu"))
+    out = dict(config=c, state_dict=sd_keep, dropped_keys=[k for k in sd0 if k not in sd_keep], video=video, input_ids=ids, attention_mask=mask,
+               loss=loss.detach().clone(), intermediates=inter, vq_indices=vq_out["indices"],
+               grads=grads, grad_norm=torch.tensor(grad_sq).sqrt().float(), vq_after=vq_after,
+               eval_text_latents=tl, eval_image_latents=il, eval_tokens=toks, eval_enc_text_cls=enc_text[:, 0].clone(),
+               eval_enc_image=enc_image, eval_similarity_2v1=sim)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: loss={float(loss):.6f} grad_norm={float(out['grad_norm']):.6f} -> {path} "
+          f"({os.path.getsize(path) / 1e6:.1f} MB)")
+
+
+if __name__ == "__main__":
+    for name, c in CASES.items():
+        run_case(name, c)
