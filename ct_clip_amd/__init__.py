@@ -1,0 +1,19 @@
+"""ct_clip_amd -- MI355X (gfx950) native CT-CLIP training hot path.
+
+Drop-in surface (same names/signatures/state_dict keys as the reference):
+    CTViT          <- transformer_maskgit.CTViT          (transformer_maskgit/transformer_maskgit/ctvit.py)
+    CTCLIP         <- ct_clip.CTCLIP                      (CT_CLIP/ct_clip/ct_clip.py)
+    CTClipTrainer  <- CTCLIPTrainer.CTClipTrainer         (scripts/CTCLIPTrainer.py)
+    get_optimizer  <- transformer_maskgit.optimizer.get_optimizer
+All arithmetic runs in hand-written HIP kernels behind the C-ABI library libctclip_hip.so (include/ctclip_hip.h).
+"""
+from .ctvit import CTViT  # noqa: F401
+from .ctclip import CTCLIP  # noqa: F401
+from .trainer import CTClipTrainer, FusedAdam, hot_path_parameters  # noqa: F401
+
+
+def get_optimizer(params, lr=1e-4, wd=1e-4, betas=(0.9, 0.99), eps=1e-8, **kwargs):
+    """transformer_maskgit/optimizer.py:10-34 on the fused HIP Adam (params: iterable of (name, param) or params)."""
+    params = list(params)
+    named = params if params and isinstance(params[0], tuple) else [(f"p{i}", p) for i, p in enumerate(params)]
+    return FusedAdam(named, lr=lr, betas=betas, eps=eps, weight_decay=wd)

@@ -1,0 +1,387 @@
+"""Primitive ops of the CT-CLIP hot path, as thin wrappers over the C-ABI HIP library.
+
+Every function takes/returns torch tensors that already live on the GPU; PyTorch is used only for memory
+(caching allocator), streams and autograd bookkeeping.  Kernels are launched on torch's current stream.
+``get()`` returns the active backend.  The only implementation shipped is the HIP one -- importing it
+without the built library raises ImportError.  ``tests/ref_backend.py`` holds a pure-torch *checker* with
+the same interface that the CPU tests swap in (via ``use()``) to validate the host-side composition and
+the hand-derived backward formulas against the oracle; it is test infrastructure, never a fallback.
+"""
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+
+
+def dcode(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowmajor(t, what):
+    assert t.dim() == 2 and t.stride(1) == 1, f"{what}: need a 2-D row-major view, got {tuple(t.shape)} {t.stride()}"
+    return t.stride(0)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def workspace(self, device, nbytes):
+        key = (device.index, _stream())
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+        return buf
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, a, b, *, a_kc=True, b_kc=True, bias=None, residual=None, out=None, out_dtype=None,
+             accumulate=False, alpha=1.0, split_k=1, M=None, N=None, K=None):
+        """out[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n] + residual[m,n] (+ out).  A = a if a_kc else a^T, same for b."""
+        lda, ldb = _rowmajor(a, "gemm a"), _rowmajor(b, "gemm b")
+        m_, k_ = (a.shape if a_kc else (a.shape[1], a.shape[0]))
+        n_, k2 = (b.shape if b_kc else (b.shape[1], b.shape[0]))
+        M = m_ if M is None else M
+        N = n_ if N is None else N
+        K = min(k_, k2) if K is None else K
+        assert a.dtype == b.dtype
+        if out is None:
+            out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+            assert not accumulate
+        ldc = _rowmajor(out, "gemm out")
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= N
+        ldr = _rowmajor(residual, "gemm residual") if residual is not None else 0
+        rc = self.lib.ctclip_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr,
+                                  int(a_kc), int(b_kc), dcode(a.dtype), dcode(out.dtype),
+                                  dcode(residual.dtype) if residual is not None else 0, int(accumulate), int(split_k),
+                                  float(alpha), _stream())
+        _lib.check(rc, "ctclip_gemm")
+        return out
+
+    def gemm_argmax(self, a, b):
+        M, K = a.shape
+        N = b.shape[0]
+        idx = torch.empty(M, dtype=torch.int64, device=a.device)
+        val = torch.empty(M, dtype=torch.float32, device=a.device)
+        nbytes = self.lib.ctclip_gemm_argmax_workspace(M, N)
+        ws = self.workspace(a.device, nbytes)
+        rc = self.lib.ctclip_gemm_argmax(_p(a), _p(b), _p(idx), _p(val), M, N, K, _rowmajor(a, "a"), _rowmajor(b, "b"),
+                                         dcode(a.dtype), _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_gemm_argmax")
+        return idx, val
+
+    # ------------------------------------------------------------------ norms
+    def layernorm_fwd(self, x, gamma, beta, eps, want_stats=True):
+        rows, cols = x.shape
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+        rc = self.lib.ctclip_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, float(eps),
+                                           dcode(x.dtype), _stream())
+        _lib.check(rc, "ctclip_layernorm_fwd")
+        return y, mean, rstd
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None):
+        rows, cols = x.shape
+        assert x.is_contiguous() and dy.is_contiguous()
+        dx = torch.empty_like(x)
+        nbytes = self.lib.ctclip_layernorm_bwd_workspace(rows, cols)
+        ws = self.workspace(x.device, nbytes)
+        rc = self.lib.ctclip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), rows,
+                                           cols, dcode(x.dtype), _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_layernorm_bwd")
+        return dx
+
+    def patch_ln(self, video, pt, p1, p2, kpad, eps, dtype):
+        B, C, Fr, H, W = video.shape
+        assert C == 1 and video.dtype == torch.float32 and video.is_contiguous()
+        ntok = B * (Fr // pt) * (H // p1) * (W // p2)
+        out = torch.empty((ntok, kpad), dtype=dtype, device=video.device)
+        rc = self.lib.ctclip_patch_ln_fwd(_p(video), _p(out), B, Fr, H, W, pt, p1, p2, kpad, float(eps), dcode(dtype), _stream())
+        _lib.check(rc, "ctclip_patch_ln_fwd")
+        return out
+
+    def l2norm_rows(self, x, out_dtype, eps=1e-12):
+        rows, cols = x.shape
+        ldx = _rowmajor(x, "l2norm x")
+        y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rc = self.lib.ctclip_l2norm_rows(_p(x), _p(y), _p(inv), rows, cols, ldx, float(eps), dcode(x.dtype), dcode(out_dtype),
+                                         _stream())
+        _lib.check(rc, "ctclip_l2norm_rows")
+        return y, inv
+
+    # ------------------------------------------------------------------ PEG
+    def peg_fwd(self, x, w, bias):
+        B, D1, D2, D3, C = x.shape
+        assert x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+        y = torch.empty_like(x)
+        rc = self.lib.ctclip_peg_fwd(_p(x), _p(w), _p(bias), _p(y), B, D1, D2, D3, C, dcode(x.dtype), _stream())
+        _lib.check(rc, "ctclip_peg_fwd")
+        return y
+
+    def peg_bwd(self, dy, x, w, dw=None, db=None):
+        B, D1, D2, D3, C = x.shape
+        assert dy.is_contiguous() and x.is_contiguous()
+        dx = torch.empty_like(x)
+        rc = self.lib.ctclip_peg_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, D1, D2, D3, C, dcode(x.dtype), _stream())
+        _lib.check(rc, "ctclip_peg_bwd")
+        return dx
+
+    # ------------------------------------------------------------------ attention
+    def head_transpose(self, x, nseq, H, L, D):
+        Lp = (L + 7) // 8 * 8
+        xt = torch.empty((nseq, H, D, Lp), dtype=x.dtype, device=x.device)
+        rc = self.lib.ctclip_head_transpose(_p(x), _p(xt), nseq, H, L, Lp, D, _rowmajor(x, "head_transpose x"), dcode(x.dtype),
+                                            _stream())
+        _lib.check(rc, "ctclip_head_transpose")
+        return xt
+
+    def qk_norm_fwd(self, x, scale_vec, H, D):
+        M = x.shape[0]
+        y = torch.empty((M, H * D), dtype=x.dtype, device=x.device)
+        inv = torch.empty((M, H), dtype=torch.float32, device=x.device)
+        rc = self.lib.ctclip_qk_norm_fwd(_p(x), _p(scale_vec), _p(y), _p(inv), M, H, D, _rowmajor(x, "x"), H * D, dcode(x.dtype),
+                                         _stream())
+        _lib.check(rc, "ctclip_qk_norm_fwd")
+        return y, inv
+
+    def qk_norm_bwd(self, dy, x, inv, scale_vec, dx, dscale, H, D):
+        M = x.shape[0]
+        rc = self.lib.ctclip_qk_norm_bwd(_p(dy), _p(x), _p(inv), _p(scale_vec), _p(dx), _p(dscale), M, H, D, _rowmajor(dy, "dy"),
+                                         _rowmajor(x, "x"), _rowmajor(dx, "dx"), dcode(x.dtype), _stream())
+        _lib.check(rc, "ctclip_qk_norm_bwd")
+        return dx
+
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True):
+        M = nseq * L
+        Lp = vt.shape[-1]
+        o = torch.empty((M, H * D), dtype=q.dtype, device=q.device)
+        lse = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device) if want_lse else None
+        rc = self.lib.ctclip_attn_fwd(_p(q), _p(k), _p(vt), _p(bias), _p(keymask), _p(o), _p(lse), nseq, H, L, Lp, D,
+                                      _rowmajor(q, "q"), _rowmajor(k, "k"), H * D, float(scale), dcode(q.dtype), _stream())
+        _lib.check(rc, "ctclip_attn_fwd")
+        return o, lse
+
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale):
+        Lp = qt.shape[-1]
+        delta = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device)
+        rc = self.lib.ctclip_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(o), _p(dout), _p(dot), _p(lse), _p(bias),
+                                      _p(keymask), _p(delta), _p(dq), _p(dk), _p(dv), _p(dbias), nseq, H, L, Lp, D,
+                                      _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(o, "o"),
+                                      _rowmajor(dout, "dout"), _rowmajor(dq, "dq"), _rowmajor(dk, "dk"), _rowmajor(dv, "dv"),
+                                      float(scale), dcode(q.dtype), _stream())
+        _lib.check(rc, "ctclip_attn_bwd")
+
+    # ------------------------------------------------------------------ elementwise / streaming
+    def geglu_fwd(self, u):
+        M, H2 = u.shape
+        g = torch.empty((M, H2 // 2), dtype=u.dtype, device=u.device)
+        _lib.check(self.lib.ctclip_geglu_fwd(_p(u), _p(g), M, H2 // 2, dcode(u.dtype), _stream()), "ctclip_geglu_fwd")
+        return g
+
+    def geglu_bwd(self, dg, u):
+        M, H2 = u.shape
+        du = torch.empty_like(u)
+        _lib.check(self.lib.ctclip_geglu_bwd(_p(dg), _p(u), _p(du), M, H2 // 2, dcode(u.dtype), _stream()), "ctclip_geglu_bwd")
+        return du
+
+    def gelu_fwd(self, u):
+        h = torch.empty_like(u)
+        _lib.check(self.lib.ctclip_gelu_fwd(_p(u), _p(h), u.numel(), dcode(u.dtype), _stream()), "ctclip_gelu_fwd")
+        return h
+
+    def gelu_bwd(self, dh, u):
+        du = torch.empty_like(u)
+        _lib.check(self.lib.ctclip_gelu_bwd(_p(dh), _p(u), _p(du), u.numel(), dcode(u.dtype), _stream()), "ctclip_gelu_bwd")
+        return du
+
+    def leaky_relu_fwd(self, x, slope):
+        y = torch.empty_like(x)
+        _lib.check(self.lib.ctclip_leaky_relu_fwd(_p(x), _p(y), x.numel(), float(slope), _stream()), "ctclip_leaky_relu_fwd")
+        return y
+
+    def leaky_relu_bwd(self, dy, x, slope):
+        dx = torch.empty_like(x)
+        _lib.check(self.lib.ctclip_leaky_relu_bwd(_p(dy), _p(x), _p(dx), x.numel(), float(slope), _stream()),
+                   "ctclip_leaky_relu_bwd")
+        return dx
+
+    def colsum(self, x, out, N=None):
+        M = x.shape[0]
+        N = x.shape[1] if N is None else N
+        _lib.check(self.lib.ctclip_colsum(_p(x), _p(out), M, N, _rowmajor(x, "colsum x"), dcode(x.dtype), _stream()),
+                   "ctclip_colsum")
+        return out
+
+    def permute0213(self, x):
+        A, B, C, D = x.shape
+        assert x.is_contiguous()
+        y = torch.empty((A, C, B, D), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.ctclip_permute0213(_p(x), _p(y), A, B, C, D, dcode(x.dtype), _stream()), "ctclip_permute0213")
+        return y
+
+    def pool_fwd(self, x):
+        B, t, R = x.shape
+        assert x.is_contiguous()
+        y = torch.empty((B, R), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.ctclip_pool_fwd(_p(x), _p(y), B, t, R, dcode(x.dtype), _stream()), "ctclip_pool_fwd")
+        return y
+
+    def pool_bwd(self, dy, t):
+        B, R = dy.shape
+        assert dy.is_contiguous()
+        dx = torch.empty((B, t, R), dtype=dy.dtype, device=dy.device)
+        _lib.check(self.lib.ctclip_pool_bwd(_p(dy), _p(dx), B, t, R, dcode(dy.dtype), _stream()), "ctclip_pool_bwd")
+        return dx
+
+    def convert_pad(self, src, rows_dst, cols_dst, dtype, colscale=None, out=None):
+        rows, cols = src.shape
+        if out is None:
+            out = torch.empty((rows_dst, cols_dst), dtype=dtype, device=src.device)
+        rc = self.lib.ctclip_convert_pad(_p(src), _p(out), _p(colscale), rows, cols, _rowmajor(src, "convert src"), rows_dst,
+                                         cols_dst, _rowmajor(out, "convert dst"), dcode(src.dtype), dcode(out.dtype), _stream())
+        _lib.check(rc, "ctclip_convert_pad")
+        return out
+
+    def cpb_expand(self, tab, gh, gw):
+        ncls, H = tab.shape
+        L = gh * gw
+        bias = torch.empty((H, L, L), dtype=torch.float32, device=tab.device)
+        _lib.check(self.lib.ctclip_cpb_expand(_p(tab), _p(bias), H, gh, gw, _stream()), "ctclip_cpb_expand")
+        return bias
+
+    def cpb_reduce(self, dbias, gh, gw):
+        H = dbias.shape[0]
+        dtab = torch.empty(((2 * gh - 1) * (2 * gw - 1), H), dtype=torch.float32, device=dbias.device)
+        _lib.check(self.lib.ctclip_cpb_reduce(_p(dbias), _p(dtab), H, gh, gw, _stream()), "ctclip_cpb_reduce")
+        return dtab
+
+    def bert_embed_fwd(self, ids, word, pos, type0, dtype):
+        B, T = ids.shape
+        Hd = word.shape[1]
+        x = torch.empty((B * T, Hd), dtype=dtype, device=word.device)
+        rc = self.lib.ctclip_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(x), B * T, T, Hd, dcode(dtype), _stream())
+        _lib.check(rc, "ctclip_bert_embed_fwd")
+        return x
+
+    def bert_embed_bwd(self, ids, dx, dword, dpos, dtype0):
+        B, T = ids.shape
+        Hd = dx.shape[1]
+        rc = self.lib.ctclip_bert_embed_bwd(_p(ids), _p(dx), _p(dword), _p(dpos), _p(dtype0), B * T, T, Hd, dcode(dx.dtype),
+                                            _stream())
+        _lib.check(rc, "ctclip_bert_embed_bwd")
+
+    # ------------------------------------------------------------------ VQ
+    def vq_gather(self, embed, idx, dtype):
+        M = idx.numel()
+        d = embed.shape[1]
+        out = torch.empty((M, d), dtype=dtype, device=embed.device)
+        _lib.check(self.lib.ctclip_vq_gather(_p(embed), _p(idx), _p(out), M, d, dcode(dtype), _stream()), "ctclip_vq_gather")
+        return out
+
+    def vq_ema(self, idx, xn, cluster_size, embed, decay):
+        C, d = embed.shape
+        bins = torch.zeros(C, dtype=torch.float32, device=embed.device)
+        esum = torch.zeros((C, d), dtype=torch.float32, device=embed.device)
+        _lib.check(self.lib.ctclip_vq_ema_accum(_p(idx), _p(xn), _p(bins), _p(esum), idx.numel(), d, dcode(xn.dtype), _stream()),
+                   "ctclip_vq_ema_accum")
+        return bins, esum
+
+    def vq_ema_update(self, cluster_size, embed, bins, esum, decay):
+        C, d = embed.shape
+        _lib.check(self.lib.ctclip_vq_ema_update(_p(cluster_size), _p(embed), _p(bins), _p(esum), C, d, float(decay), _stream()),
+                   "ctclip_vq_ema_update")
+
+    # ------------------------------------------------------------------ CLIP head
+    def visual_latent_fwd(self, x, w):
+        Bm, K = x.shape
+        N = w.shape[0]
+        assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+        y = torch.zeros((Bm, N), dtype=torch.float32, device=x.device)
+        for b0 in range(0, Bm, 8):
+            nb = min(8, Bm - b0)
+            rc = self.lib.ctclip_visual_latent_fwd(_p(x[b0:]), _p(w), _p(y[b0:]), nb, N, K, dcode(x.dtype), _stream())
+            _lib.check(rc, "ctclip_visual_latent_fwd")
+        return y
+
+    def visual_latent_bwd(self, dy, x, w, dw=None, accumulate=False, want_dx=True):
+        Bm, K = x.shape
+        N = w.shape[0]
+        assert dy.dtype == torch.float32 and dy.is_contiguous()
+        dx = torch.empty_like(x) if want_dx else None
+        for b0 in range(0, Bm, 8):
+            nb = min(8, Bm - b0)
+            rc = self.lib.ctclip_visual_latent_bwd(_p(dy[b0:]), _p(x[b0:]), _p(w), _p(dx[b0:]) if want_dx else None, _p(dw), nb, N,
+                                                   K, int(accumulate or b0 > 0), dcode(x.dtype), _stream())
+            _lib.check(rc, "ctclip_visual_latent_bwd")
+        return dx
+
+    def clip_loss(self, tl, il, temperature, want_grads=True, want_logits=False):
+        G, Dl = tl.shape
+        assert tl.dtype == torch.float32 and il.dtype == torch.float32 and tl.is_contiguous() and il.is_contiguous()
+        dev = tl.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        logits = torch.empty((G, G), dtype=torch.float32, device=dev) if want_logits else None
+        dtl = torch.empty_like(tl) if want_grads else None
+        dil = torch.empty_like(il) if want_grads else None
+        dtemp = torch.zeros(1, dtype=torch.float32, device=dev) if want_grads else None
+        rc = self.lib.ctclip_clip_loss(_p(tl), _p(il), _p(temperature), _p(out), _p(logits), _p(dtl), _p(dil), _p(dtemp), G, Dl,
+                                       _stream())
+        _lib.check(rc, "ctclip_clip_loss")
+        return out, logits, dtl, dil, dtemp
+
+    def scale_by_scalar(self, x, scalar):
+        _lib.check(self.lib.ctclip_scale_by_scalar(_p(x), _p(scalar), x.numel(), _stream()), "ctclip_scale_by_scalar")
+        return x
+
+    # ------------------------------------------------------------------ optimiser
+    def grad_norm_clip(self, g, max_norm, extra_sq=None):
+        out = torch.empty(2, dtype=torch.float32, device=g.device)
+        ws = self.workspace(g.device, self.lib.ctclip_grad_norm_workspace())
+        rc = self.lib.ctclip_grad_norm_clip(_p(g), g.numel(), _p(extra_sq), float(max_norm or 0.0), _p(out), _p(ws), ws.numel(),
+                                            _stream())
+        _lib.check(rc, "ctclip_grad_norm_clip")
+        return out
+
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None):
+        rc = self.lib.ctclip_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                       int(step), float(weight_decay), _p(clip), _stream())
+        _lib.check(rc, "ctclip_adam_step")
+
+
+_active = None
+
+
+def get():
+    """The active backend; instantiates the HIP one on first use (ImportError if the .so is missing)."""
+    global _active
+    if _active is None:
+        _active = HipBackend()
+    return _active
+
+
+def use(backend):
+    """TEST HOOK: swap the primitive implementation (tests/ref_backend.py).  Returns the previous one."""
+    global _active
+    prev, _active = _active, backend
+    return prev

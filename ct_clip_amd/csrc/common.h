@@ -1,0 +1,120 @@
+// Common device helpers for the CT-CLIP gfx950 (CDNA4 / MI355X) kernels.
+// Written for wave64 + MFMA directly; no CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CTCLIP_OK 0
+#define CTCLIP_EBADARG (-1)
+#define CTCLIP_EUNSUPPORTED (-2)
+#define CTCLIP_EWORKSPACE (-3)
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+extern "C" void ctclip_set_error(const char* msg);
+int ctclip_check_launch(const char* what);
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kDtype = DT_F32;
+  static constexpr int kPer16B = 4;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = DT_BF16;
+  static constexpr int kPer16B = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (vectorised: 16 B for bf16, 2 x 16 B for f32). Pointers 16-B aligned.
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(a[i] << 16); v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  u32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = a;
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+  const u32x2 a = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u);
+  v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+  f32x4 a; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+  u32x2 a; a[0] = pack2bf(v[0], v[1]); a[1] = pack2bf(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(p) = a;
+}
+
+// wave64 reductions (all 64 lanes participate)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reductions for blockDim.x a multiple of 64 (<= 1024); `red` = >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,358 @@
+// MFMA GEMM for gfx950:  C[m,n] = alpha * sum_k A(m,k) * B(n,k)  (+ bias[n]) (+ residual[m,n]) (+ C_old)
+//
+//   A(m,k) = A[m*lda + k]  (a_kc = 1, "k-contiguous")   or  A[k*lda + m]  (a_kc = 0)
+//   B(n,k) = B[n*ldb + k]  (b_kc = 1)                    or  B[k*ldb + n]  (b_kc = 0)
+//
+// so that the three products of a Linear layer share one kernel body:
+//   forward  y  = x  W^T   : (a_kc, b_kc) = (1, 1)
+//   grad-in  dx = dy W     : (1, 0)
+//   grad-w   dW = dy^T x   : (0, 0)   (contraction over the token axis; split-K + f32 atomics)
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, k-tile = 128 bytes per row
+// (64 bf16 / 32 f32).  Tiles are staged global -> VGPR -> LDS ([row][8 x 16-B chunks], chunk index
+// XOR-swizzled with row&7) with the next tile's global loads in flight under the current tile's
+// MFMAs.  When the contraction index is NOT the contiguous one in memory the transposition happens
+// in registers on the way to LDS (dword loads of 2 adjacent rows x 8 k, v_perm packs), so the LDS
+// image and the MFMA loop are identical for every layout.
+//
+// MFMA operand mapping: lane (i = l&15, g = l>>4) reads chunks 2g and 2g+1 of its row.  The hardware
+// multiplies element e of lane (i,g) of A with element e of lane (j,g) of B, so any k-assignment is
+// valid as long as A and B use the same one; bf16 uses 2 x mfma_f32_16x16x32_bf16 per fragment pair,
+// f32 uses 8 x mfma_f32_16x16x4f32 (exact f32 FMA chain -- the parity mode).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int ROWB = 128;  // bytes of k per tile row
+
+enum { EPI_STD = 0, EPI_ARGMAX = 1 };
+
+struct GemmParams {
+  const void* A; const void* B; void* C; const float* bias; const void* residual;
+  int64_t M, N, K, lda, ldb, ldc, ldr;
+  int out_dtype, res_dtype, accumulate, atomic_out;
+  float alpha;
+  int k_per_split;  // multiple of the k-tile
+  int ntm, ntn;
+  // argmax epilogue
+  float* part_val; int32_t* part_idx; int nparts;
+};
+
+template <typename T> struct Tile;
+template <> struct Tile<bf16_t> { static constexpr int BK = 64, CE = 8; };
+template <> struct Tile<float> { static constexpr int BK = 32, CE = 4; };
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
+// ---- staging: global -> registers (16 dwords per operand per thread)
+template <typename T, bool KC>
+__device__ __forceinline__ void stage_load(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows,
+                                           int64_t k0, int64_t kend, uint32_t (&r)[16]) {
+  const int t = threadIdx.x;
+  constexpr int CE = Tile<T>::CE;
+  if constexpr (KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = t + NTHREADS * j, row = idx >> 3, chunk = idx & 7;
+      const int64_t gr = row0 + row, gk = k0 + chunk * CE;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (gr < nrows && gk < kend) v = *reinterpret_cast<const u32x4*>(base + gr * ld + gk);
+      r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    }
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = t + NTHREADS * j, m = idx & 127, kg = idx >> 7;
+      const int64_t gr = row0 + m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t gk = k0 + kg * 4 + e;
+        r[4 * j + e] = (gr < nrows && gk < kend) ? *reinterpret_cast<const uint32_t*>(base + gk * ld + gr) : 0u;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = t + NTHREADS * j, mp = idx & 63, kg = idx >> 6;
+      const int64_t gr = row0 + 2 * mp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t gk = k0 + kg * 8 + e;
+        r[8 * j + e] = (gr < nrows && gk < kend) ? *reinterpret_cast<const uint32_t*>(base + gk * ld + gr) : 0u;
+      }
+    }
+  }
+}
+
+// ---- staging: registers -> LDS tile
+template <typename T, bool KC>
+__device__ __forceinline__ void stage_store(char* __restrict__ lds, const uint32_t (&r)[16]) {
+  const int t = threadIdx.x;
+  if constexpr (KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = t + NTHREADS * j, row = idx >> 3, chunk = idx & 7;
+      u32x4 v = {r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+      *reinterpret_cast<u32x4*>(lds + swz(row, chunk)) = v;
+    }
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = t + NTHREADS * j, m = idx & 127, kg = idx >> 7;
+      u32x4 v = {r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+      *reinterpret_cast<u32x4*>(lds + swz(m, kg)) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = t + NTHREADS * j, mp = idx & 63, kg = idx >> 6;
+      u32x4 lo, hi;  // lo: row 2mp (low halves of each dword), hi: row 2mp+1
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t d0 = r[8 * j + 2 * e], d1 = r[8 * j + 2 * e + 1];
+        lo[e] = (d0 & 0xffffu) | (d1 << 16);
+        hi[e] = (d0 >> 16) | (d1 & 0xffff0000u);
+      }
+      *reinterpret_cast<u32x4*>(lds + swz(2 * mp, kg)) = lo;
+      *reinterpret_cast<u32x4*>(lds + swz(2 * mp + 1, kg)) = hi;
+    }
+  }
+}
+
+template <typename T, bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * BM * ROWB];
+  char* ldsA = lds;
+  char* ldsB = lds + BM * ROWB;
+  constexpr int BK = Tile<T>::BK;
+
+  // XCD-aware tile order: consecutive tile ids (which share an A row panel) stay on one XCD / L2.
+  const int ntiles = p.ntm * p.ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, within = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tm = bid / p.ntn, tn = bid % p.ntn;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  if (kbeg >= kend) return;
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t ra[16], rb[16];
+  stage_load<T, AKC>(A, p.lda, m0, p.M, kbeg, kend, ra);
+  stage_load<T, BKC>(B, p.ldb, n0, p.N, kbeg, kend, rb);
+  stage_store<T, AKC>(ldsA, ra);
+  stage_store<T, BKC>(ldsB, rb);
+  __syncthreads();
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK) < kend;
+    if (more) {
+      stage_load<T, AKC>(A, p.lda, m0, p.M, k0 + BK, kend, ra);
+      stage_load<T, BKC>(B, p.ldb, n0, p.N, k0 + BK, kend, rb);
+    }
+    // fragments: lane (li, lg) reads chunks 2lg, 2lg+1 of its row
+    u32x4 af[4][2], bfr[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int ar = wm * 64 + f * 16 + li, br = wn * 64 + f * 16 + li;
+      af[f][0] = *reinterpret_cast<const u32x4*>(ldsA + swz(ar, 2 * lg));
+      af[f][1] = *reinterpret_cast<const u32x4*>(ldsA + swz(ar, 2 * lg + 1));
+      bfr[f][0] = *reinterpret_cast<const u32x4*>(ldsB + swz(br, 2 * lg));
+      bfr[f][1] = *reinterpret_cast<const u32x4*>(ldsB + swz(br, 2 * lg + 1));
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a][s]),
+                                                                __builtin_bit_cast(bf16x8, bfr[b][s]), acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[a][s][e]),
+                                                               __uint_as_float(bfr[b][s][e]), acc[a][b], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+    if (more) {
+      stage_store<T, AKC>(ldsA, ra);
+      stage_store<T, BKC>(ldsB, rb);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  acc[a][b][r] is C[m0 + wm*64 + a*16 + lg*4 + r][n0 + wn*64 + b*16 + li]
+  if constexpr (EPI == EPI_STD) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 64 + a * 16 + lg * 4 + r;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int64_t col = n0 + wn * 64 + b * 16 + li;
+          if (col >= p.N) continue;
+          float v = acc[a][b][r] * p.alpha;
+          if (blockIdx.y == 0) {
+            if (p.bias) v += p.bias[col];
+            if (p.residual) {
+              v += (p.res_dtype == DT_F32) ? reinterpret_cast<const float*>(p.residual)[row * p.ldr + col]
+                                           : bf2f(reinterpret_cast<const bf16_t*>(p.residual)[row * p.ldr + col]);
+            }
+          }
+          if (p.out_dtype == DT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + row * p.ldc + col;
+            if (p.atomic_out) atomicAdd(c, v);
+            else *c = p.accumulate ? (*c + v) : v;
+          } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col;
+            *c = f2bf(p.accumulate ? (bf2f(*c) + v) : v);
+          }
+        }
+      }
+  } else {
+    // row-wise arg-max over this wave's 64 columns -> partial (value, index) per (row, tn*2+wn);
+    // ties resolve to the lowest column index (torch.argmax semantics on CPU).
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best = -INFINITY; int bidx = 0x7fffffff;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int64_t col = n0 + wn * 64 + b * 16 + li;
+          const float v = acc[a][b][r];
+          if (col < p.N && (v > best || (v == best && (int)col < bidx))) { best = v; bidx = (int)col; }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bidx, o, 64);
+          if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        const int64_t row = m0 + wm * 64 + a * 16 + lg * 4 + r;
+        if (li == 0 && row < p.M) {
+          p.part_val[row * p.nparts + tn * 2 + wn] = best;
+          p.part_idx[row * p.nparts + tn * 2 + wn] = bidx;
+        }
+      }
+  }
+}
+
+__global__ void argmax_reduce_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int64_t* __restrict__ out,
+                                     float* __restrict__ out_val, int64_t M, int nparts) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  float best = -INFINITY; int bidx = 0x7fffffff;
+  for (int i = 0; i < nparts; ++i) {
+    const float v = pv[row * nparts + i]; const int ix = pi[row * nparts + i];
+    if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; }
+  }
+  out[row] = bidx;
+  if (out_val) out_val[row] = best;
+}
+
+template <typename T, int EPI>
+int launch_layout(const GemmParams& p, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, true, EPI>), grid, dim3(NTHREADS), 0, stream, p);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, false, EPI>), grid, dim3(NTHREADS), 0, stream, p);
+  else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<T, false, false, EPI>), grid, dim3(NTHREADS), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, false, true, EPI>), grid, dim3(NTHREADS), 0, stream, p);
+  return ctclip_check_launch("gemm");
+}
+
+int check_operands(const void* A, const void* B, int64_t lda, int64_t ldb, int64_t M, int64_t N, int64_t K, int a_kc,
+                   int b_kc, int in_dtype) {
+  if (!A || !B || M <= 0 || N <= 0 || K <= 0) { ctclip_set_error("gemm: null operand or empty shape"); return CTCLIP_EBADARG; }
+  if (in_dtype != DT_F32 && in_dtype != DT_BF16) { ctclip_set_error("gemm: unsupported dtype"); return CTCLIP_EUNSUPPORTED; }
+  const int es = in_dtype == DT_F32 ? 4 : 2, ce = 16 / es;
+  auto bad16 = [&](const void* ptr, int64_t ld) { return ((uintptr_t)ptr % 16) != 0 || (ld % ce) != 0; };
+  // non-k-contiguous bf16 operands are read as dwords (2 adjacent rows): the pitch must be even and cover the
+  // row count rounded up to even (an odd last row reads one in-bounds element past it and discards the result)
+  auto bad4 = [&](const void* ptr, int64_t ld, int64_t rows) { return ((uintptr_t)ptr % 4) != 0 || (es == 2 && ((ld % 2) || (ld < rows + (rows & 1)))); };
+  if (a_kc ? (bad16(A, lda) || (K % ce)) : bad4(A, lda, M)) { ctclip_set_error("gemm: A alignment (k-contiguous needs 16-B rows and K%chunk==0; else even lda/M)"); return CTCLIP_EBADARG; }
+  if (b_kc ? (bad16(B, ldb) || (K % ce)) : bad4(B, ldb, N)) { ctclip_set_error("gemm: B alignment"); return CTCLIP_EBADARG; }
+  return CTCLIP_OK;
+}
+
+}  // namespace
+
+// C-ABI ----------------------------------------------------------------------------------------
+// Replaces torch F.linear / nn.Linear forward+backward on the reference hot path
+// (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF modeling_bert dense layers).
+extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M,
+                           int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc,
+                           int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha,
+                           hipStream_t stream) {
+  int rc = check_operands(A, B, lda, ldb, M, N, K, a_kc, b_kc, in_dtype);
+  if (rc) return rc;
+  if (!C) { ctclip_set_error("gemm: null C"); return CTCLIP_EBADARG; }
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+  p.out_dtype = out_dtype; p.res_dtype = res_dtype; p.accumulate = accumulate; p.alpha = alpha;
+  p.ntm = (int)cdiv(M, BM); p.ntn = (int)cdiv(N, BN);
+  const int bk = in_dtype == DT_F32 ? 32 : 64;
+  int64_t ktiles = cdiv(K, bk);
+  if (split_k < 1) split_k = 1;
+  if (split_k > ktiles) split_k = (int)ktiles;
+  if (split_k > 1 && out_dtype != DT_F32) { ctclip_set_error("gemm: split-K needs f32 output"); return CTCLIP_EUNSUPPORTED; }
+  p.k_per_split = (int)(cdiv(ktiles, split_k) * bk);
+  split_k = (int)cdiv(K, p.k_per_split);
+  p.atomic_out = split_k > 1;
+  if (p.atomic_out && !accumulate) {
+    if (hipMemset2DAsync(C, ldc * 4, 0, N * 4, M, stream) != hipSuccess) { ctclip_set_error("gemm: memset failed"); return -1000; }
+  }
+  dim3 grid(p.ntm * p.ntn, split_k);
+  if (in_dtype == DT_F32) return launch_layout<float, EPI_STD>(p, a_kc, b_kc, grid, stream);
+  return launch_layout<bf16_t, EPI_STD>(p, a_kc, b_kc, grid, stream);
+}
+
+// Row-wise arg-max of A B^T without materialising the product (vector-quantiser code assignment:
+// vector_quantize_pytorch CosineSimCodebook.forward, called at ctvit.py:403).
+// workspace: M * nparts * 8 bytes, nparts = 2 * ceil(N / 128).
+extern "C" int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N) { return M * 2 * cdiv(N, BN) * 8; }
+
+extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N,
+                                  int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace,
+                                  int64_t workspace_bytes, hipStream_t stream) {
+  int rc = check_operands(A, B, lda, ldb, M, N, K, 1, 1, in_dtype);
+  if (rc) return rc;
+  if (workspace_bytes < ctclip_gemm_argmax_workspace(M, N) || !workspace) { ctclip_set_error("gemm_argmax: workspace too small"); return CTCLIP_EWORKSPACE; }
+  GemmParams p{};
+  p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.alpha = 1.f;
+  p.ntm = (int)cdiv(M, BM); p.ntn = (int)cdiv(N, BN);
+  const int bk = in_dtype == DT_F32 ? 32 : 64;
+  p.k_per_split = (int)(cdiv(K, bk) * bk);
+  p.nparts = 2 * p.ntn;
+  p.part_val = reinterpret_cast<float*>(workspace);
+  p.part_idx = reinterpret_cast<int32_t*>(p.part_val + M * p.nparts);
+  dim3 grid(p.ntm * p.ntn, 1);
+  rc = (in_dtype == DT_F32) ? launch_layout<float, EPI_ARGMAX>(p, 1, 1, grid, stream)
+                            : launch_layout<bf16_t, EPI_ARGMAX>(p, 1, 1, grid, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(argmax_reduce_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, stream, p.part_val, p.part_idx, out_idx,
+                     out_val, M, p.nparts);
+  return ctclip_check_launch("argmax_reduce");
+}

@@ -1,0 +1,268 @@
+// CLIP head of CT-CLIP on gfx950:
+//   * to_visual_latent (ct_clip.py:564,767): Linear(h*w*dim -> dim_latent, no bias) at M = per-GPU batch.
+//     K = 294 912, N = 512, M = 8: a pure HBM stream of the 151 M-parameter weight (GEMV-like), forward and backward.
+//   * l2norm + logits * exp(temperature) + symmetric InfoNCE in the exp/sum/log(t+1e-20) form, forward AND
+//     backward in one launch (ct_clip.py:771,796,845-846,858-878,890-901).
+#include "common.h"
+
+namespace {
+
+constexpr int VL_MAXB = 8;    // rows of X per call (the host loops over chunks of 8 samples)
+constexpr int VL_KCH = 2048;  // k-chunk per block
+
+// Y[b][n] += sum_{k in chunk} X[b][k] * W[n][k].  block = 4 waves x 4 weight rows; X chunk staged in LDS as f32.
+template <typename T>
+__global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, const T* __restrict__ W, float* __restrict__ Y, int Bm,
+                                                       int N, int64_t K) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [Bm][VL_KCH]
+  const int64_t k0 = (int64_t)blockIdx.y * VL_KCH;
+  const int kc = (int)((K - k0) < VL_KCH ? (K - k0) : VL_KCH);
+  for (int i = threadIdx.x; i < Bm * (VL_KCH / 8); i += 256) {
+    const int b = i / (VL_KCH / 8), c = (i % (VL_KCH / 8)) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (c < kc) load8(X + (int64_t)b * K + k0 + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xs[b * VL_KCH + c + e] = v[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  float acc[4][VL_MAXB];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int b = 0; b < VL_MAXB; ++b) acc[r][b] = 0.f;
+  for (int c = lane * 8; c < kc; c += 512) {
+    float w[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n0 + r < N) load8(W + (int64_t)(n0 + r) * K + k0 + c, w[r]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[r][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < VL_MAXB; ++b) {
+      if (b < Bm) {
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = xs[b * VL_KCH + c + e];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][b] += w[r][e] * xv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int b = 0; b < VL_MAXB; ++b) {
+      if (b < Bm) {
+        const float t = wave_sum(acc[r][b]);
+        if (lane == 0 && n0 + r < N) atomicAdd(Y + (int64_t)b * N + n0 + r, t);
+      }
+    }
+}
+
+// Each thread owns 8 consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
+template <typename T>
+__global__ __launch_bounds__(128) void vlat_bwd_kernel(const float* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ W,
+                                                       T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K,
+                                                       int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float dys[];  // [Bm][N]
+  for (int i = threadIdx.x; i < Bm * N; i += 128) dys[i] = dY[i];
+  __syncthreads();
+  const int64_t k = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 8;
+  if (k >= K) return;
+  float xv[VL_MAXB][8], dx[VL_MAXB][8];
+#pragma unroll
+  for (int b = 0; b < VL_MAXB; ++b) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xv[b][e] = 0.f; dx[b][e] = 0.f; }
+    if (b < Bm) load8(X + (int64_t)b * K + k, xv[b]);
+  }
+  for (int n = 0; n < N; ++n) {
+    float w[8], g[8];
+    load8(W + (int64_t)n * K + k, w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < VL_MAXB; ++b) {
+      if (b < Bm) {
+        const float d = dys[b * N + n];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dx[b][e] += d * w[e]; g[e] += d * xv[b][e]; }
+      }
+    }
+    if (dW) {
+      float* dst = dW + (int64_t)n * K + k;
+      if (accumulate) {
+        float old[8];
+        load8(dst, old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += old[e];
+      }
+      store8(dst, g);
+    }
+  }
+  if (dX) {
+#pragma unroll
+    for (int b = 0; b < VL_MAXB; ++b)
+      if (b < Bm) store8(dX + (int64_t)b * K + k, dx[b]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- CLIP loss
+// single block.  tl, il: (G, Dl) raw (pre-l2norm) latents f32.  out[0] = loss, out[1] = exp(temperature).
+// grads: dtl, dil (G, Dl) f32, dtemp[0] (+=).  logits (G,G) optional.
+__global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ tl, const float* __restrict__ il,
+                                                        const float* __restrict__ temperature, float* __restrict__ out,
+                                                        float* __restrict__ logits, float* __restrict__ dtl, float* __restrict__ dil,
+                                                        float* __restrict__ dtemp, int G, int Dl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* S = sm;                  // G*G : logits, later dS
+  float* tinv = S + G * G;        // G
+  float* iinv = tinv + G;         // G
+  float* rsum = iinv + G;         // G
+  float* csum = rsum + G;         // G
+  float* red = csum + G;          // 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float temp = __expf(temperature[0]);
+  const float eps = 1e-20f;
+  // 1. inverse norms (F.normalize eps 1e-12)
+  for (int r = wave; r < 2 * G; r += 4) {
+    const float* src = (r < G) ? tl + (int64_t)r * Dl : il + (int64_t)(r - G) * Dl;
+    float s = 0.f;
+    for (int c = lane; c < Dl; c += 64) s += src[c] * src[c];
+    s = wave_sum(s);
+    if (lane == 0) { const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f); if (r < G) tinv[r] = inv; else iinv[r - G] = inv; }
+  }
+  __syncthreads();
+  // 2. logits S[i][j] = temp * <t_i, v_j> * tinv_i * iinv_j   (rows = texts, cols = images)
+  for (int ij = wave; ij < G * G; ij += 4) {
+    const int i = ij / G, j = ij % G;
+    float s = 0.f;
+    for (int c = lane; c < Dl; c += 64) s += tl[(int64_t)i * Dl + c] * il[(int64_t)j * Dl + c];
+    s = wave_sum(s);
+    if (lane == 0) { const float v = s * tinv[i] * iinv[j] * temp; S[ij] = v; if (logits) logits[ij] = v; }
+  }
+  __syncthreads();
+  // 3. row / column sums of exp(S)
+  for (int r = tid; r < 2 * G; r += 256) {
+    float s = 0.f;
+    if (r < G) { for (int j = 0; j < G; ++j) s += __expf(S[r * G + j]); rsum[r] = s; }
+    else { const int j = r - G; for (int i = 0; i < G; ++i) s += __expf(S[i * G + j]); csum[j] = s; }
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < G; i += 256) {
+    const float e = __expf(S[i * G + i]);
+    part += -2.f * __logf(e + eps) + __logf(rsum[i] + eps) + __logf(csum[i] + eps);
+  }
+  const float total = block_sum(part, red);
+  if (tid == 0) { out[0] = total / (2.f * G); out[1] = temp; }
+  if (!dtl) return;
+  // 4. dS (in place), d temperature
+  float dth = 0.f;
+  for (int ij = tid; ij < G * G; ij += 256) {
+    const int i = ij / G, j = ij % G;
+    const float s = S[ij], e = __expf(s);
+    float d = e / (rsum[i] + eps) + e / (csum[j] + eps);
+    if (i == j) d -= 2.f * e / (e + eps);
+    d /= (2.f * G);
+    dth += d * s;
+    S[ij] = d;
+  }
+  __syncthreads();
+  const float dtheta = block_sum(dth, red);
+  if (tid == 0 && dtemp) dtemp[0] += dtheta;
+  // 5. latent grads through logits and l2norm:  u = raw * inv ;  du_t[i] = temp * sum_j dS_ij u_v[j] ; d raw = inv (du - u <u,du>)
+  for (int r = wave; r < 2 * G; r += 4) {
+    const bool text = r < G;
+    const int row = text ? r : r - G;
+    const float* raw = text ? tl + (int64_t)row * Dl : il + (int64_t)row * Dl;
+    const float inv = text ? tinv[row] : iinv[row];
+    float dot = 0.f;
+    // Dl <= 64 * 16
+    float du[16], u[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = q * 64 + lane;
+      du[q] = 0.f; u[q] = 0.f;
+      if (c < Dl) {
+        float a = 0.f;
+        for (int o = 0; o < G; ++o) {
+          const float d = text ? S[row * G + o] : S[o * G + row];
+          const float ou = text ? il[(int64_t)o * Dl + c] * iinv[o] : tl[(int64_t)o * Dl + c] * tinv[o];
+          a += d * ou;
+        }
+        du[q] = a * temp;
+        u[q] = raw[c] * inv;
+        dot += u[q] * du[q];
+      }
+    }
+    dot = wave_sum(dot);
+    float* dst = text ? dtl + (int64_t)row * Dl : dil + (int64_t)row * Dl;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = q * 64 + lane;
+      if (c < Dl) dst[c] = inv * (du[q] - u[q] * dot);
+    }
+  }
+}
+
+__global__ void scale_by_scalar_kernel(float* __restrict__ x, const float* __restrict__ s, int64_t n) {
+  const float f = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= f;
+}
+
+}  // namespace
+
+// Y (Bm, N) f32 = X (Bm, K) W^T (N, K).  Y must be zero on entry (split-K partial sums are added atomically).
+extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, hipStream_t s) {
+  if (!X || !W || !Y || Bm < 1 || Bm > VL_MAXB || K % 8) { ctclip_set_error("visual_latent_fwd: batch must be 1..8 per call and K a multiple of 8"); return CTCLIP_EBADARG; }
+  dim3 grid((unsigned)cdiv(N, 16), (unsigned)cdiv(K, VL_KCH));
+  const size_t shm = (size_t)Bm * VL_KCH * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    raised = true;
+  }
+  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_fwd_kernel<float>, grid, dim3(256), shm, s, (const float*)X, (const float*)W, Y, Bm, N, K);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_fwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)X, (const bf16_t*)W, Y, Bm, N, K);
+  else return CTCLIP_EUNSUPPORTED;
+  return ctclip_check_launch("visual_latent_fwd");
+}
+// dX (Bm, K) in `dtype` (may be null), dW (N, K) f32 overwritten or accumulated (may be null).
+extern "C" int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K,
+                                        int accumulate, int dtype, hipStream_t s) {
+  if (!dY || !X || !W || Bm < 1 || Bm > VL_MAXB || K % 8 || (int64_t)Bm * N * 4 > 64 * 1024) { ctclip_set_error("visual_latent_bwd: bad args"); return CTCLIP_EBADARG; }
+  dim3 grid((unsigned)cdiv(K / 8, 128));
+  const size_t shm = (size_t)Bm * N * sizeof(float);
+  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_bwd_kernel<float>, grid, dim3(128), shm, s, dY, (const float*)X, (const float*)W, (float*)dX, dW, Bm, N, K, accumulate);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_bwd_kernel<bf16_t>, grid, dim3(128), shm, s, dY, (const bf16_t*)X, (const bf16_t*)W, (bf16_t*)dX, dW, Bm, N, K, accumulate);
+  else return CTCLIP_EUNSUPPORTED;
+  return ctclip_check_launch("visual_latent_bwd");
+}
+// CLIP symmetric InfoNCE forward + backward.  G <= 128, Dl <= 1024.  out: [loss, exp(temperature)].
+extern "C" int ctclip_clip_loss(const float* text_latents, const float* image_latents, const float* temperature, float* out, float* logits,
+                                float* d_text, float* d_image, float* d_temperature, int G, int Dl, hipStream_t s) {
+  if (!text_latents || !image_latents || !temperature || !out || G < 1 || G > 128 || Dl > 1024) { ctclip_set_error("clip_loss: G <= 128 and Dl <= 1024 required"); return CTCLIP_EBADARG; }
+  const size_t shm = ((size_t)G * G + 4 * G + 16) * sizeof(float);
+  if (shm > 48 * 1024) {
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void*)clip_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); raised = true; }
+  }
+  hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(256), shm, s, text_latents, image_latents, temperature, out, logits, d_text, d_image, d_temperature, G, Dl);
+  return ctclip_check_launch("clip_loss");
+}
+extern "C" int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s) {
+  int64_t b = cdiv(n, 256); if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)b), dim3(256), 0, s, x, scalar, n);
+  return ctclip_check_launch("scale_by_scalar");
+}

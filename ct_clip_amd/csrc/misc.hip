@@ -1,0 +1,375 @@
+// Streaming (HBM-bound) kernels of the CT-CLIP hot path: GEGLU / GELU, bias-gradient column sums, token-grid
+// permutation, depth mean-pool, dtype conversion with padding (weight shadows), continuous-position-bias
+// gather/scatter, BERT embedding gather / scatter-add, vector-quantiser gather and EMA statistics.
+// All use 16-byte accesses (8 x bf16 / 2 x 4 x f32 per lane) and grid-stride loops.
+#include "common.h"
+
+namespace {
+
+constexpr int64_t MAXBLOCKS = 256 * 16;
+inline dim3 grid_for(int64_t nthreads) { int64_t b = cdiv(nthreads, 256); if (b > MAXBLOCKS) b = MAXBLOCKS; if (b < 1) b = 1; return dim3((unsigned)b); }
+
+// ---- GEGLU (attention.py:39-42): u = [x | gate] (M, 2*Hp);  g = x * gelu(gate)
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ u, T* __restrict__ g, int64_t M, int Hp) {
+  const int G = Hp / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / G; const int c = (int)(i % G) * 8;
+    float a[8], b[8], o[8];
+    load8(u + row * 2 * Hp + c, a);
+    load8(u + row * 2 * Hp + Hp + c, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * gelu_erf(b[e]);
+    store8(g + row * Hp + c, o);
+  }
+}
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ u, T* __restrict__ du, int64_t M, int Hp) {
+  const int G = Hp / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / G; const int c = (int)(i % G) * 8;
+    float a[8], b[8], d[8], o1[8], o2[8];
+    load8(u + row * 2 * Hp + c, a);
+    load8(u + row * 2 * Hp + Hp + c, b);
+    load8(dg + row * Hp + c, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o1[e] = d[e] * gelu_erf(b[e]); o2[e] = d[e] * a[e] * gelu_erf_grad(b[e]); }
+    store8(du + row * 2 * Hp + c, o1);
+    store8(du + row * 2 * Hp + Hp + c, o2);
+  }
+}
+// ---- GELU (HF BertIntermediate, gelu-erf)
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8], o[8];
+    load8(u + i * 8, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = gelu_erf(a[e]);
+    store8(h + i * 8, o);
+  }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8], d[8], o[8];
+    load8(u + i * 8, a);
+    load8(dh + i * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_erf_grad(a[e]);
+    store8(du + i * 8, o);
+  }
+}
+// ---- LeakyReLU (attention.py:19-20), f32 only (position-bias MLP)
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float v = x[i]; y[i] = v > 0.f ? v : v * slope; }
+}
+__global__ void leaky_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// ---- out[n] += sum_m x[m][n]   (bias gradients).  block: 32 column-groups of 8 x 8 row lanes; 512 rows per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ld) {
+  __shared__ float red[8][256];
+  const int cgp = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.y * 32 + cgp) * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c < N) {
+    const int64_t r0 = (int64_t)blockIdx.x * 512;
+    for (int64_t r = r0 + rl; r < r0 + 512 && r < M; r += 8) {
+      float v[8];
+      load8(x + r * ld + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cgp * 8 + e] = acc[e];
+  __syncthreads();
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+    atomicAdd(out + col, t);
+  }
+}
+
+// ---- (A, B, C, D) -> (A, C, B, D)   (ctvit.py:297-305 rearranges between the spatial and temporal phases)
+template <typename T>
+__global__ void permute0213_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t A, int B, int C, int D) {
+  const int G = D / 8;
+  const int64_t n = A * B * C * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G); int64_t r = i / G;
+    const int b = (int)(r % B); r /= B;
+    const int c = (int)(r % C); const int64_t a = r / C;   // output index (a, c, b)
+    float v[8];
+    load8(x + ((a * B + b) * C + c) * D + g * 8, v);
+    store8(y + ((a * C + c) * B + b) * D + g * 8, v);
+  }
+}
+
+// ---- mean over the depth-token axis (ct_clip.py:724): x (B, t, R) -> y (B, R); backward broadcasts dy / t
+template <typename T>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t B, int t, int64_t R) {
+  const int64_t G = R / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / G, c = (i % G) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int tau = 0; tau < t; ++tau) {
+      float v[8];
+      load8(x + (b * t + tau) * R + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    const float inv = 1.f / t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    store8(y + b * R + c, acc);
+  }
+}
+template <typename T>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t B, int t, int64_t R) {
+  const int64_t G = R / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * t * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = (i % G) * 8; const int64_t bt = i / G; const int64_t b = bt / t;
+    float v[8];
+    load8(dy + b * R + c, v);
+    const float inv = 1.f / t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= inv;
+    store8(dx + bt * R + c, v);
+  }
+}
+
+// ---- dst[r][c] = (r < rows && c < cols) ? src[r*lds + c] * colscale[c] : 0   over (rows_dst, cols_dst); any dtypes
+template <typename TS, typename TD>
+__global__ void convert_pad_kernel(const TS* __restrict__ src, TD* __restrict__ dst, const float* __restrict__ colscale, int64_t rows,
+                                   int64_t cols, int64_t lds_, int64_t rows_dst, int64_t cols_dst, int64_t ldd) {
+  const int64_t n = rows_dst * cols_dst;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols_dst, c = i % cols_dst;
+    float v = 0.f;
+    if (r < rows && c < cols) { v = Elem<TS>::ld(src + r * lds_ + c); if (colscale) v *= colscale[c]; }
+    Elem<TD>::st(dst + r * ldd + c, v);
+  }
+}
+
+// ---- continuous position bias (attention.py:257-276): table (nclass, H) -> bias (H, L, L), L = gh*gw,
+//      class(i,j) = (iy-jy+gh-1)*(2gw-1) + (ix-jx+gw-1).  Backward: table-grad gather of dbias (deterministic).
+__global__ void cpb_expand_kernel(const float* __restrict__ tab, float* __restrict__ bias, int H, int gh, int gw) {
+  const int L = gh * gw;
+  const int64_t n = (int64_t)H * L * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % L); const int ii = (int)((i / L) % L); const int h = (int)(i / ((int64_t)L * L));
+    const int cls = (ii / gw - j / gw + gh - 1) * (2 * gw - 1) + (ii % gw - j % gw + gw - 1);
+    bias[i] = tab[(int64_t)cls * H + h];
+  }
+}
+__global__ void cpb_reduce_kernel(const float* __restrict__ dbias, float* __restrict__ dtab, int H, int gh, int gw) {
+  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncls * H) return;
+  const int h = i % H, cls = i / H;
+  const int dy = cls / (2 * gw - 1) - (gh - 1), dx = cls % (2 * gw - 1) - (gw - 1);
+  float t = 0.f;
+  for (int iy = (dy > 0 ? dy : 0); iy < gh && iy - dy < gh; ++iy)
+    for (int ix = (dx > 0 ? dx : 0); ix < gw && ix - dx < gw; ++ix) {
+      const int qi = iy * gw + ix, kj = (iy - dy) * gw + (ix - dx);
+      t += dbias[((int64_t)h * L + qi) * L + kj];
+    }
+  dtab[(int64_t)cls * H + h] = t;
+}
+
+// ---- BERT embeddings (HF BertEmbeddings): x[r] = word[ids[r]] + pos[r % T] + type[0]
+template <typename T>
+__global__ void bert_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                      const float* __restrict__ type0, T* __restrict__ x, int64_t rows, int Tlen, int Hd) {
+  const int G = Hd / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / G; const int c = (int)(i % G) * 4;
+    float a[4], b[4], d[4], o[4];
+    load4(word + ids[r] * Hd + c, a);
+    load4(pos + (r % Tlen) * Hd + c, b);
+    load4(type0 + c, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] + b[e] + d[e];
+    store4(x + r * Hd + c, o);
+  }
+}
+template <typename T>
+__global__ void bert_embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx, float* __restrict__ dword,
+                                      float* __restrict__ dpos, float* __restrict__ dtype0, int64_t rows, int Tlen, int Hd) {
+  const int G = Hd / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / G; const int c = (int)(i % G) * 4;
+    float g[4];
+    load4(dx + r * Hd + c, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (dword) atomicAdd(dword + ids[r] * Hd + c + e, g[e]);
+      if (dpos) atomicAdd(dpos + (r % Tlen) * Hd + c + e, g[e]);
+      if (dtype0) atomicAdd(dtype0 + c + e, g[e]);
+    }
+  }
+}
+
+// ---- vector quantiser (vector_quantize_pytorch 1.1.2 cosine codebook; called at ctvit.py:403)
+template <typename T>
+__global__ void vq_gather_kernel(const float* __restrict__ embed, const int64_t* __restrict__ idx, T* __restrict__ out, int64_t M, int d) {
+  const int G = d / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / G; const int c = (int)(i % G) * 4;
+    float v[4];
+    load4(embed + idx[r] * d + c, v);
+    store4(out + r * d + c, v);
+  }
+}
+// bins[code] += 1 ; esum[code] += xn[row]   (f32 atomics: order-independent up to f32 rounding)
+template <typename T>
+__global__ void vq_ema_accum_kernel(const int64_t* __restrict__ idx, const T* __restrict__ xn, float* __restrict__ bins,
+                                    float* __restrict__ esum, int64_t M, int d) {
+  const int G = d / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / G; const int g = (int)(i % G);
+    const int64_t code = idx[r];
+    float v[4];
+    load4(xn + r * d + g * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(esum + code * d + g * 4 + e, v[e]);
+    if (g == 0) atomicAdd(bins + code, 1.f);
+  }
+}
+// one wave per code: cluster_size <- lerp ; embed <- decay*embed + (1-decay)*(bins ? l2norm(esum/bins) : l2norm(embed))
+__global__ __launch_bounds__(256) void vq_ema_update_kernel(float* __restrict__ cluster, float* __restrict__ embed,
+                                                            const float* __restrict__ bins, const float* __restrict__ esum, int C, int d,
+                                                            float decay) {
+  const int lane = threadIdx.x & 63;
+  const int code = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (code >= C) return;
+  const float b = bins[code];
+  if (lane == 0) cluster[code] = cluster[code] * decay + b * (1.f - decay);
+  const float* src = (b == 0.f) ? embed + (int64_t)code * d : esum + (int64_t)code * d;
+  const float div = (b == 0.f) ? 1.f : b;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = src[c] / div; s += v * v; }
+  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int c = lane; c < d; c += 64) {
+    const float v = src[c] / div * inv;
+    embed[(int64_t)code * d + c] = embed[(int64_t)code * d + c] * decay + v * (1.f - decay);
+  }
+}
+
+}  // namespace
+
+#define BY_DTYPE(dtype, CALL)                                                 \
+  if (dtype == DT_F32) { using T = float; CALL; }                             \
+  else if (dtype == DT_BF16) { using T = bf16_t; CALL; }                      \
+  else { ctclip_set_error("unsupported dtype"); return CTCLIP_EUNSUPPORTED; }
+
+extern "C" int ctclip_geglu_fwd(const void* u, void* g, int64_t M, int Hp, int dtype, hipStream_t s) {
+  if (!u || !g || Hp % 8) { ctclip_set_error("geglu_fwd: hidden must be a multiple of 8"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(geglu_fwd_kernel<T>, grid_for(M * Hp / 8), dim3(256), 0, s, (const T*)u, (T*)g, M, Hp));
+  return ctclip_check_launch("geglu_fwd");
+}
+extern "C" int ctclip_geglu_bwd(const void* dg, const void* u, void* du, int64_t M, int Hp, int dtype, hipStream_t s) {
+  if (!dg || !u || !du || Hp % 8) { ctclip_set_error("geglu_bwd: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(geglu_bwd_kernel<T>, grid_for(M * Hp / 8), dim3(256), 0, s, (const T*)dg, (const T*)u, (T*)du, M, Hp));
+  return ctclip_check_launch("geglu_bwd");
+}
+extern "C" int ctclip_gelu_fwd(const void* u, void* h, int64_t n, int dtype, hipStream_t s) {
+  if (!u || !h || n % 8) { ctclip_set_error("gelu_fwd: n must be a multiple of 8"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(gelu_fwd_kernel<T>, grid_for(n / 8), dim3(256), 0, s, (const T*)u, (T*)h, n / 8));
+  return ctclip_check_launch("gelu_fwd");
+}
+extern "C" int ctclip_gelu_bwd(const void* dh, const void* u, void* du, int64_t n, int dtype, hipStream_t s) {
+  if (!dh || !u || !du || n % 8) { ctclip_set_error("gelu_bwd: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<T>, grid_for(n / 8), dim3(256), 0, s, (const T*)dh, (const T*)u, (T*)du, n / 8));
+  return ctclip_check_launch("gelu_bwd");
+}
+extern "C" int ctclip_leaky_relu_fwd(const float* x, float* y, int64_t n, float slope, hipStream_t s) {
+  hipLaunchKernelGGL(leaky_fwd_kernel, grid_for(n), dim3(256), 0, s, x, y, n, slope);
+  return ctclip_check_launch("leaky_relu_fwd");
+}
+extern "C" int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, float slope, hipStream_t s) {
+  hipLaunchKernelGGL(leaky_bwd_kernel, grid_for(n), dim3(256), 0, s, dy, x, dx, n, slope);
+  return ctclip_check_launch("leaky_relu_bwd");
+}
+// out (f32, N) += column sums of x (M, N)
+extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, hipStream_t s) {
+  if (!x || !out || N % 8 || ld % 8) { ctclip_set_error("colsum: N and ld must be multiples of 8"); return CTCLIP_EBADARG; }
+  dim3 grid((unsigned)cdiv(M, 512), (unsigned)cdiv(N, 256));
+  BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, out, M, N, ld));
+  return ctclip_check_launch("colsum");
+}
+extern "C" int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s) {
+  if (!x || !y || D % 8) { ctclip_set_error("permute0213: D must be a multiple of 8"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(permute0213_kernel<T>, grid_for(A * B * C * D / 8), dim3(256), 0, s, (const T*)x, (T*)y, A, B, C, D));
+  return ctclip_check_launch("permute0213");
+}
+extern "C" int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s) {
+  if (!x || !y || R % 8) { ctclip_set_error("pool_fwd: R must be a multiple of 8"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(pool_fwd_kernel<T>, grid_for(B * R / 8), dim3(256), 0, s, (const T*)x, (T*)y, B, t, R));
+  return ctclip_check_launch("pool_fwd");
+}
+extern "C" int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, hipStream_t s) {
+  if (!dy || !dx || R % 8) { ctclip_set_error("pool_bwd: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(pool_bwd_kernel<T>, grid_for(B * t * R / 8), dim3(256), 0, s, (const T*)dy, (T*)dx, B, t, R));
+  return ctclip_check_launch("pool_bwd");
+}
+extern "C" int ctclip_convert_pad(const void* src, void* dst, const float* colscale, int64_t rows, int64_t cols, int64_t lds_,
+                                  int64_t rows_dst, int64_t cols_dst, int64_t ldd, int src_dtype, int dst_dtype, hipStream_t s) {
+  if (!src || !dst) return CTCLIP_EBADARG;
+  dim3 g = grid_for(rows_dst * cols_dst);
+#define L(TS, TD) hipLaunchKernelGGL((convert_pad_kernel<TS, TD>), g, dim3(256), 0, s, (const TS*)src, (TD*)dst, colscale, rows, cols, lds_, rows_dst, cols_dst, ldd)
+  if (src_dtype == DT_F32 && dst_dtype == DT_F32) L(float, float);
+  else if (src_dtype == DT_F32 && dst_dtype == DT_BF16) L(float, bf16_t);
+  else if (src_dtype == DT_BF16 && dst_dtype == DT_F32) L(bf16_t, float);
+  else if (src_dtype == DT_BF16 && dst_dtype == DT_BF16) L(bf16_t, bf16_t);
+  else return CTCLIP_EUNSUPPORTED;
+#undef L
+  return ctclip_check_launch("convert_pad");
+}
+extern "C" int ctclip_cpb_expand(const float* tab, float* bias, int H, int gh, int gw, hipStream_t s) {
+  const int64_t L = (int64_t)gh * gw;
+  hipLaunchKernelGGL(cpb_expand_kernel, grid_for(H * L * L), dim3(256), 0, s, tab, bias, H, gh, gw);
+  return ctclip_check_launch("cpb_expand");
+}
+extern "C" int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s) {
+  const int n = (2 * gh - 1) * (2 * gw - 1) * H;
+  hipLaunchKernelGGL(cpb_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dbias, dtab, H, gh, gw);
+  return ctclip_check_launch("cpb_reduce");
+}
+extern "C" int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows,
+                                     int Tlen, int Hd, int dtype, hipStream_t s) {
+  if (!ids || !word || !pos || !type0 || !x || Hd % 8) { ctclip_set_error("bert_embed_fwd: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(bert_embed_fwd_kernel<T>, grid_for(rows * Hd / 4), dim3(256), 0, s, ids, word, pos, type0, (T*)x, rows, Tlen, Hd));
+  return ctclip_check_launch("bert_embed_fwd");
+}
+extern "C" int ctclip_bert_embed_bwd(const int64_t* ids, const void* dx, float* dword, float* dpos, float* dtype0, int64_t rows, int Tlen,
+                                     int Hd, int dtype, hipStream_t s) {
+  if (!ids || !dx || Hd % 8) { ctclip_set_error("bert_embed_bwd: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(bert_embed_bwd_kernel<T>, grid_for(rows * Hd / 4), dim3(256), 0, s, ids, (const T*)dx, dword, dpos, dtype0, rows, Tlen, Hd));
+  return ctclip_check_launch("bert_embed_bwd");
+}
+extern "C" int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t M, int d, int dtype, hipStream_t s) {
+  if (!embed || !idx || !out || d % 8) { ctclip_set_error("vq_gather: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(vq_gather_kernel<T>, grid_for(M * d / 4), dim3(256), 0, s, embed, idx, (T*)out, M, d));
+  return ctclip_check_launch("vq_gather");
+}
+extern "C" int ctclip_vq_ema_accum(const int64_t* idx, const void* xn, float* bins, float* esum, int64_t M, int d, int dtype, hipStream_t s) {
+  if (!idx || !xn || !bins || !esum || d % 8) { ctclip_set_error("vq_ema_accum: bad args"); return CTCLIP_EBADARG; }
+  BY_DTYPE(dtype, hipLaunchKernelGGL(vq_ema_accum_kernel<T>, grid_for(M * d / 4), dim3(256), 0, s, idx, (const T*)xn, bins, esum, M, d));
+  return ctclip_check_launch("vq_ema_accum");
+}
+extern "C" int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s) {
+  if (!cluster || !embed || !bins || !esum) return CTCLIP_EBADARG;
+  hipLaunchKernelGGL(vq_ema_update_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, cluster, embed, bins, esum, C, d, decay);
+  return ctclip_check_launch("vq_ema_update");
+}

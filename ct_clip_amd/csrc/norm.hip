@@ -1,0 +1,298 @@
+// Row statistics kernels: LayerNorm forward/backward, patch gather + LayerNorm (CTViT patch embedding
+// front-end), l2 row normalisation.  All HBM-bound: one wave64 per row, 16-byte vector accesses,
+// statistics in f32 with wave shuffles (no atomics: deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;  // up to 64 lanes * 8 * 4 = 2048 columns per row
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float v[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      load8(xr + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  T* yr = y + row * cols;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (v[i][e] - mean) * rstd;
+        if (gamma) t *= gamma[c + e];
+        if (beta) t += beta[c + e];
+        o[e] = t;
+      }
+      store8(yr + c, o);
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
+// Per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy are written to part[block][2][cols].
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t rows, int cols) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[LN_MAXV][8], db[LN_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        float a[8], b[8];
+        load8(dy + row * cols + c, a);
+        load8(x + row * cols + c, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (b[e] - mu) * rs;
+          g[i][e] = gamma ? a[e] * gamma[c + e] : a[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          dg[i][e] += a[e] * xh[i][e];
+          db[i][e] += a[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / cols;
+    s2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
+        store8(dx + row * cols + c, o);
+      }
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sm[(wave * 2 + 0) * cols + c + e] = dg[i][e]; sm[(wave * 2 + 1) * cols + c + e] = db[i][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+    const int which = c / cols, col = c % cols;
+    float t = 0.f;
+    for (int w = 0; w < 4; ++w) t += sm[(w * 2 + which) * cols + col];
+    part[((int64_t)blockIdx.x * 2 + which) * cols + col] = t;
+  }
+}
+
+// out[c] += sum_b part[b][which][c]
+__global__ void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         int nblocks, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * cols) return;
+  const int which = c / cols, col = c % cols;
+  float* dst = which == 0 ? dgamma : dbeta;
+  if (!dst) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += part[((int64_t)b * 2 + which) * cols + col];
+  dst[col] += t;
+}
+
+// CTViT patch embedding front-end (ctvit.py:171-172): gather the (pt, p1, p2) patch of one token from the
+// (B,1,F,H,W) f32 volume in 16-byte row segments, LayerNorm over its pt*p1*p2 values (eps 1e-5, affine
+// folded into the following GEMM's weights by the host), write xhat as a K-padded row of the embed GEMM's A.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void patch_ln_kernel(const float* __restrict__ video, T* __restrict__ out, int F, int H,
+                                                       int W, int pt, int p1, int p2, int kpad, float eps) {
+  __shared__ float red[16];
+  const int t = F / pt, h = H / p1, w = W / p2;
+  const int K = pt * p1 * p2;
+  int64_t tok = blockIdx.x;
+  const int j = tok % w; const int i = (tok / w) % h; const int tau = (tok / ((int64_t)w * h)) % t; const int64_t b = tok / ((int64_t)w * h * t);
+  const float* vb = video + b * (int64_t)F * H * W;
+  constexpr int NV = 4;  // up to 256 * 4 * 4 = 4096 patch elements
+  float v[NV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int e = (q * 256 + threadIdx.x) * 4;
+    if (e < K) {
+      if constexpr (VEC) {
+        const int a = e / (p1 * p2), u = (e / p2) % p1, vv = e % p2;
+        load4(vb + ((int64_t)(tau * pt + a) * H + (i * p1 + u)) * W + j * p2 + vv, v[q]);
+      } else {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+          const int ee = e + z;
+          const int a = ee / (p1 * p2), u = (ee / p2) % p1, vv = ee % p2;
+          v[q][z] = ee < K ? vb[((int64_t)(tau * pt + a) * H + (i * p1 + u)) * W + j * p2 + vv] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int z = 0; z < 4; ++z) s += v[q][z];
+    }
+  }
+  const float mean = block_sum(s, red) / K;
+  float qv = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int e = (q * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int z = 0; z < 4; ++z)
+      if (e + z < K) { const float d = v[q][z] - mean; qv += d * d; }
+  }
+  const float rstd = rsqrtf(block_sum(qv, red) / K + eps);
+  T* o = out + tok * (int64_t)kpad;
+#pragma unroll
+  for (int q = 0; q < NV + 1; ++q) {
+    const int e = (q * 256 + threadIdx.x) * 4;
+    if (e < kpad) {
+      float r[4];
+#pragma unroll
+      for (int z = 0; z < 4; ++z) r[z] = (q < NV && e + z < K) ? (v[q < NV ? q : 0][z] - mean) * rstd : 0.f;
+      store4(o + e, r);
+    }
+  }
+}
+
+// y = x / max(||x||_2, eps) per row (F.normalize); optional inverse norm output
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const TI* __restrict__ x, TO* __restrict__ y, float* __restrict__ inv_out,
+                                                          int64_t rows, int cols, int64_t ldx, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      load8(x + row * ldx + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e] * v[i][e];
+    }
+  }
+  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
+  if (lane == 0 && inv_out) inv_out[row] = inv;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[i][e] * inv;
+      store8(y + row * cols + c, o);
+    }
+  }
+}
+
+}  // namespace
+
+// F.layer_norm / nn.LayerNorm forward (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm).
+extern "C" int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    int64_t rows, int cols, float eps, int dtype, hipStream_t stream) {
+  if (!x || !y || rows <= 0 || cols <= 0 || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_fwd: cols must be a multiple of 8 and <= 2048"); return CTCLIP_EBADARG; }
+  dim3 grid((unsigned)cdiv(rows, 4));
+  if (dtype == DT_F32) hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps);
+  else return CTCLIP_EUNSUPPORTED;
+  return ctclip_check_launch("layernorm_fwd");
+}
+
+extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) {
+  int64_t nb = cdiv(rows, 4); if (nb > 512) nb = 512;
+  return nb * 2 * cols * 4;
+}
+
+// LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
+extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                    void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype, void* workspace,
+                                    int64_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !dx || !mean || !rstd || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_bwd: bad args"); return CTCLIP_EBADARG; }
+  int64_t nb = cdiv(rows, 4); if (nb > 512) nb = 512;
+  const bool want = dgamma || dbeta;
+  if (want && (!workspace || workspace_bytes < ctclip_layernorm_bwd_workspace(rows, cols))) { ctclip_set_error("layernorm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  float* part = want ? (float*)workspace : nullptr;
+  const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
+  if (dtype == DT_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), shm, stream, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, part, rows, cols);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), shm, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, part, rows, cols);
+  else return CTCLIP_EUNSUPPORTED;
+  int rc = ctclip_check_launch("layernorm_bwd");
+  if (rc || !want) return rc;
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 256)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
+  return ctclip_check_launch("ln_partial_reduce");
+}
+
+// CTViT.to_patch_emb[0:2] (ctvit.py:171-172): Rearrange + LayerNorm statistics; out is (B*t*h*w, kpad).
+extern "C" int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, int W, int pt, int p1, int p2,
+                                   int kpad, float eps, int out_dtype, hipStream_t stream) {
+  const int K = pt * p1 * p2;
+  if (!video || !out || F % pt || H % p1 || W % p2 || K > 4096 || kpad < K || kpad % 4 || kpad > 5 * 1024) { ctclip_set_error("patch_ln_fwd: unsupported patch geometry (pt*p1*p2 <= 4096)"); return CTCLIP_EUNSUPPORTED; }
+  const int64_t ntok = B * (F / pt) * (H / p1) * (W / p2);
+  const bool vec = (p2 % 4 == 0) && (W % 4 == 0) && (((uintptr_t)video) % 16 == 0) && (K % 4 == 0);
+  dim3 grid((unsigned)ntok);
+#define LAUNCH(T, V) hipLaunchKernelGGL((patch_ln_kernel<T, V>), grid, dim3(256), 0, stream, video, (T*)out, F, H, W, pt, p1, p2, kpad, eps)
+  if (out_dtype == DT_F32) { if (vec) LAUNCH(float, true); else LAUNCH(float, false); }
+  else if (out_dtype == DT_BF16) { if (vec) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+  else return CTCLIP_EUNSUPPORTED;
+#undef LAUNCH
+  return ctclip_check_launch("patch_ln_fwd");
+}
+
+// F.normalize(x, dim=-1) rows (attention.py:22-23, ct_clip.py:49-50, VQ codebook l2norm).  in_dtype -> out_dtype.
+extern "C" int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype,
+                                  int out_dtype, hipStream_t stream) {
+  if (!x || !y || cols % 8 || cols > 64 * 8 * LN_MAXV || ldx % 8) { ctclip_set_error("l2norm_rows: cols must be a multiple of 8 and <= 2048"); return CTCLIP_EBADARG; }
+  dim3 grid((unsigned)cdiv(rows, 4));
+#define LAUNCH(TI, TO) hipLaunchKernelGGL((l2norm_rows_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)x, (TO*)y, inv, rows, cols, ldx, eps)
+  if (in_dtype == DT_F32 && out_dtype == DT_F32) LAUNCH(float, float);
+  else if (in_dtype == DT_F32 && out_dtype == DT_BF16) LAUNCH(float, bf16_t);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_BF16) LAUNCH(bf16_t, bf16_t);
+  else if (in_dtype == DT_BF16 && out_dtype == DT_F32) LAUNCH(bf16_t, float);
+  else return CTCLIP_EUNSUPPORTED;
+#undef LAUNCH
+  return ctclip_check_launch("l2norm_rows");
+}

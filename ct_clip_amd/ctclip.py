@@ -1,0 +1,109 @@
+"""CTCLIP (drop-in for ``ct_clip.CTCLIP``, reference CT_CLIP/ct_clip/ct_clip.py:407-901) on gfx950 kernels.
+
+Keeps the reference constructor / ``forward`` signature, return modes and ``state_dict`` keys.  Both towers, the pooling,
+the two latent projections, l2norm, the logit matmul and the symmetric InfoNCE run as HIP kernels; under
+``torch.distributed`` the loss uses gathered negatives (all-gather of the raw latents over RCCL).
+"""
+import copy
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import bert as _bert
+from . import distributed as _dist
+from . import functional as Fn
+from .ctvit import default_compute_dtype
+
+
+class CTCLIP(nn.Module):
+    def __init__(self, *, image_encoder=None, text_encoder=None, dim_text=512, dim_image=512, dim_latent=512,
+                 num_text_tokens=28897, text_enc_depth=6, text_seq_len=256, text_heads=8, text_dim_head=64,
+                 text_has_cls_token=False, text_pad_id=0, text_rotary_pos_emb=False, text_causal_mask=False,
+                 text_eos_id=None, text_encode_without_mask=False, visual_enc_depth=6, visual_heads=8, visual_dim_head=64,
+                 visual_image_size=256, visual_patch_size=32, visual_patch_dropout=0.5, visual_has_cls_token=False,
+                 channels=3, use_all_token_embeds=False, downsample_image_embeds=False,
+                 decoupled_contrastive_learning=False, extra_latent_projection=False, use_mlm=False,
+                 text_ssl_loss_weight=0.05, use_visual_ssl=False, visual_ssl=None, visual_ssl_type="simsiam",
+                 visual_ssl_hidden_layer=-1, simclr_temperature=0.1, image_ssl_loss_weight=0.05,
+                 multiview_loss_weight=0.1, checkpoint_during_training=False, tokenizer=None, compute_dtype=None,
+                 gather_negatives=True, **kwargs):
+        super().__init__()
+        self.dtype = torch.float32
+        self.dim_text, self.dim_image, self.dim_latent = dim_text, dim_image, dim_latent
+        if image_encoder is None or text_encoder is None:
+            raise NotImplementedError("CT-CLIP always supplies external encoders (run_train.py:17-42); the built-in "
+                                      "TextTransformer/VisionTransformer of ct_clip.py:103-385 are out of scope")
+        for flag, name in ((use_all_token_embeds, "use_all_token_embeds"), (downsample_image_embeds, "downsample_image_embeds"),
+                           (decoupled_contrastive_learning, "decoupled_contrastive_learning"),
+                           (extra_latent_projection, "extra_latent_projection"), (use_mlm, "use_mlm"),
+                           (use_visual_ssl or visual_ssl is not None, "use_visual_ssl"), (text_causal_mask, "text_causal_mask")):
+            if flag:
+                raise NotImplementedError(f"{name}=True is disabled in every CT-CLIP entry script (run_train.py:31-42)")
+        if not _bert.is_hf_bert(text_encoder):
+            raise NotImplementedError("text_encoder must be a HuggingFace BertModel (run_train.py:9)")
+        self.text_transformer = text_encoder
+        self.visual_transformer = image_encoder
+        self.text_pad_id = text_pad_id
+        self.use_mlm = False
+        self.use_visual_ssl = False
+        self.use_all_token_embeds = False
+        self.extra_latent_projection = False
+        self.decoupled_contrastive_learning = False
+        self.text_ssl_loss_weight = 0
+        self.image_ssl_loss_weight = 0
+        self.multiview_loss_weight = multiview_loss_weight
+
+        self.to_text_latent = nn.Linear(dim_text, dim_latent, bias=False)
+        self.to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False)
+        self.temperature = nn.Parameter(torch.tensor(1.0))
+        # kept for checkpoint-key compatibility (ct_clip.py:579-581); never used, never receive gradients
+        self.to_text_latent_extra = copy.deepcopy(self.to_text_latent)
+        self.to_visual_latent_extra = copy.deepcopy(self.to_visual_latent)
+
+        # ct_clip.py:585 downloads a tokenizer; offline-safe here: only fetched on demand by tokenize()
+        self.tokenizer = tokenizer
+        self.compute_dtype = compute_dtype or getattr(image_encoder, "compute_dtype", None) or default_compute_dtype()
+        if hasattr(image_encoder, "compute_dtype"):
+            image_encoder.compute_dtype = self.compute_dtype
+        self.gather_negatives = gather_negatives
+
+    def load(self, path):
+        path = Path(path)
+        assert path.exists()
+        self.load_state_dict(torch.load(str(path)))
+
+    def tokenize(self, prompt):
+        if self.tokenizer is None:
+            from transformers import BertTokenizer
+            self.tokenizer = BertTokenizer.from_pretrained("microsoft/BiomedVLP-CXR-BERT-specialized", do_lower_case=True)
+        dev = self.temperature.device
+        return self.tokenizer(prompt, return_tensors="pt", padding="max_length", truncation=True, max_length=512).to(dev)
+
+    def forward(self, text, image, device=None, return_loss=False, return_encodings=False, return_latents=False,
+                freeze_image_encoder=False, freeze_text_encoder=False, text_to_image=True, aug_text=None, aug_image=None):
+        # freeze_* are accepted and ignored exactly as in the reference (ct_clip.py:709-715)
+        if aug_text is not None or aug_image is not None:
+            raise NotImplementedError("multiview augmentation is never used by CT-CLIP's entry scripts")
+        dt = self.compute_dtype
+        ids, mask = text.input_ids, text.attention_mask
+        Bt, T = ids.shape
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)          # (Bt*T, dim_text)
+        enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)                 # (Bi, t, h, w, d)
+        Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
+        enc_image = Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1))                               # ct_clip.py:724,740
+        if return_encodings:
+            return enc_text.view(Bt, T, -1), enc_image
+        cls = enc_text.view(Bt, -1)[:, :self.dim_text]                                          # enc_text[:, 0, :] (ct_clip.py:762)
+        text_lat = Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)          # (Bt, Dl) f32, pre-l2norm
+        image_lat = Fn.visual_latent(enc_image, self.to_visual_latent.weight)                   # (Bi, Dl) f32, pre-l2norm
+        if return_latents:
+            return Fn.l2norm_f32(text_lat), Fn.l2norm_f32(image_lat), enc_tokens
+        if not return_loss:
+            # ct_clip.py:805-807: einsum('b d, b d -> b') * temp with broadcasting (e.g. 2 prompts vs 1 volume)
+            tl, il = Fn.l2norm_f32(text_lat), Fn.l2norm_f32(image_lat)
+            return (tl * il).sum(-1) * self.temperature.exp()
+        assert Bt == Bi, "contrastive loss needs as many texts as volumes"
+        if self.gather_negatives and _dist.world_size() > 1:
+            text_lat, image_lat = _dist.all_gather_latents(text_lat, image_lat)
+        return Fn.ClipLossFn.apply(text_lat, image_lat, self.temperature)

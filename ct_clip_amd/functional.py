@@ -1,0 +1,527 @@
+"""Autograd layer: torch.autograd.Function wrappers whose forward/backward are sequences of C-ABI kernel
+launches (``backend.get()``).  The backward formulas are hand-derived; ``tests/test_host_logic_cpu.py``
+checks them on CPU against the oracle by swapping in the pure-torch checker backend.
+
+Weight handling
+  * master parameters stay f32 with the reference's shapes/keys (state_dict compatibility);
+  * each Linear weight has a compute-dtype *shadow* (bf16 in performance mode), possibly padded / re-laid
+    out for 16-byte rows and MFMA tiles, refreshed when the parameter's version counter changes;
+  * weight gradients are written straight into ``param._ctclip_grad_sink`` (a view of the trainer's flat f32
+    gradient buffer, accumulated with split-K atomics) when present -- autograd then sees ``None`` for that
+    input; otherwise a fresh f32 gradient tensor is returned as usual.
+"""
+import torch
+from torch.autograd import Function
+
+from . import backend as _be
+
+
+def B():
+    return _be.get()
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------ shadows / sinks
+
+_WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    """Called by the fused optimiser (which updates parameters through raw kernels, invisible to torch's version
+    counters) so that every weight shadow is rebuilt on next use."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def shadow(param, tag, dtype, maker):
+    """Cached derived tensor of a parameter (recomputed when the parameter is modified)."""
+    cache = param.__dict__.setdefault("_ctclip_shadow", {})
+    key = (tag, dtype)
+    ent = cache.get(key)
+    stamp = (param._version, param.data_ptr(), _WEIGHT_EPOCH)
+    if ent is not None and ent[0] == stamp:
+        return ent[1]
+    with torch.no_grad():
+        val = maker()
+    cache[key] = (stamp, val)
+    return val
+
+
+def plain_shadow(weight, dtype, kpad=None, npad=None):
+    """(N, K) f32 -> (Np, Kp) compute dtype, zero padded."""
+    N, K = weight.shape
+    Np, Kp = npad or N, kpad or K
+
+    def make():
+        w = weight.detach()
+        if dtype == torch.float32 and Np == N and Kp == K and w.is_contiguous():
+            return w
+        return B().convert_pad(w, Np, Kp, dtype)
+    return shadow(weight, ("plain", Np, Kp), dtype, make)
+
+
+def sink_of(param):
+    return getattr(param, "_ctclip_grad_sink", None)
+
+
+def _split_k_for(n_rows, n_cols, K, dtype):
+    tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
+    bk = 32 if dtype == torch.float32 else 64
+    ktiles = (K + bk - 1) // bk
+    return max(1, min(ktiles, 1024 // max(tiles, 1)))
+
+
+def weight_grad(dy, x, weight, segments, K):
+    """dW[r0:r0+n, :K] (+)= dy[:, c0:c0+n]^T @ x[:, :K]   for (r0, n, c0) in segments.  Returns grad or None (sink)."""
+    sink = sink_of(weight)
+    if sink is None:
+        dst = torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
+    else:
+        dst = sink
+    dst2 = dst.view(weight.shape[0], -1)
+    for (r0, n, c0) in segments:
+        B().gemm(dy[:, c0:c0 + n], x[:, :K], a_kc=False, b_kc=False, out=dst2[r0:r0 + n, :K], accumulate=True,
+                 split_k=_split_k_for(n, K, dy.shape[0], dy.dtype), M=n, N=K, K=dy.shape[0])
+    return None if sink is not None else dst
+
+
+def vec_grad(param, compute):
+    """compute(dst) accumulates a vector gradient into dst (f32, param-shaped).  Returns grad or None (sink)."""
+    sink = sink_of(param)
+    dst = sink if sink is not None else torch.zeros(param.shape, dtype=torch.float32, device=param.device)
+    compute(dst)
+    return None if sink is not None else dst
+
+
+# ------------------------------------------------------------------------------------------ Linear
+
+class LinearFn(Function):
+    """y = x @ Wshadow^T (+ bias) (+ residual).  ``segments``/``K`` describe how dW maps back onto the real weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype):
+        y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
+                     out_dtype=out_dtype or x.dtype)
+        ctx.save_for_backward(x, wsh)
+        ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
+        ctx.has_res = residual is not None
+        ctx.res_dtype = residual.dtype if residual is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wsh = ctx.saved_tensors
+        dy = dy.contiguous()
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
+        dyc = dy if dy.dtype == x.dtype else B().convert_pad(dy, dy.shape[0], dy.shape[1], x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
+            if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
+                dx = dx[:, :x.shape[1]]
+        dw = None
+        if ctx.weight.requires_grad:
+            dw = weight_grad(dyc, x, ctx.weight, ctx.segments, ctx.K)
+        db = None
+        if ctx.bias is not None and ctx.bias.requires_grad:
+            db = vec_grad(ctx.bias, lambda dst: B().colsum(dyc, dst, N=ctx.bias.numel()))
+        return dx, dw, db, dres, None, None, None, None
+
+
+def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None):
+    """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros)."""
+    N, K = weight.shape
+    wsh = plain_shadow(weight, x.dtype, kpad=kpad)
+    return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype)
+
+
+def geglu_hidden_pad(inner):
+    return round_up(inner, 128)
+
+
+def linear_geglu_in(x, weight):
+    """FeedForward[1]: Linear(d, 2*inner, no bias) (attention.py:48) producing the padded [x | gate] layout (M, 2*Hp)."""
+    two_inner, K = weight.shape
+    inner = two_inner // 2
+    Hp = geglu_hidden_pad(inner)
+
+    def make():
+        w = weight.detach()
+        out = torch.empty((2 * Hp, K), dtype=x.dtype, device=w.device)
+        B().convert_pad(w[:inner], Hp, K, x.dtype, out=out[:Hp])
+        B().convert_pad(w[inner:], Hp, K, x.dtype, out=out[Hp:])
+        return out
+    wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make)
+    return LinearFn.apply(x, weight, None, None, wsh, [(0, inner, 0), (inner, inner, Hp)], K, None)
+
+
+def linear_geglu_out(g, weight, residual):
+    """FeedForward[4]: Linear(inner, d, no bias) (attention.py:51) consuming the padded hidden (M, Hp), + residual."""
+    N, inner = weight.shape
+    Hp = g.shape[1]
+    wsh = plain_shadow(weight, g.dtype, kpad=Hp)
+    return LinearFn.apply(g, weight, None, residual, wsh, [(0, N, 0)], inner, None)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = B().layernorm_fwd(x, gamma.detach() if gamma is not None else None,
+                                          beta.detach() if beta is not None else None, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        g, b = ctx.gamma, ctx.beta
+        want_g = g is not None and g.requires_grad
+        want_b = b is not None and b.requires_grad
+        gs = sink_of(g) if want_g else None
+        bs = sink_of(b) if want_b else None
+        dgam = (gs if gs is not None else torch.zeros_like(g, dtype=torch.float32)) if want_g else None
+        dbet = (bs if bs is not None else torch.zeros_like(b, dtype=torch.float32)) if want_b else None
+        dx = B().layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet)
+        return dx, (None if (not want_g or gs is not None) else dgam), (None if (not want_b or bs is not None) else dbet), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------ patch embedding
+
+class PatchEmbedFn(Function):
+    """CTViT.to_patch_emb (ctvit.py:170-175): Rearrange + LayerNorm(K) + Linear(K, d) + LayerNorm(d).
+
+    The first LayerNorm's affine is folded into the GEMM (W' = W * gamma1 per column, b' = W beta1 + b) so the
+    gather kernel writes xhat once and no dX GEMM is needed for gamma1/beta1:
+        dW = G * gamma1 + db' (x) beta1,  dgamma1 = sum_n W * G,  dbeta1 = W^T db',  G = dZ^T xhat.
+    """
+
+    @staticmethod
+    def forward(ctx, video, g1, b1, W, bl, g2, b2, pt, p1, p2, dtype):
+        be = B()
+        N, K = W.shape
+        kpad = round_up(K, 64)
+        xhat = be.patch_ln(video, pt, p1, p2, kpad, 1e-5, dtype)
+        g1d, b1d = g1.detach(), b1.detach()
+        Wf = be.convert_pad(W.detach(), N, kpad, dtype, colscale=g1d)
+        # b' = W beta1 + b  (f32 GEMV through the same GEMM kernel; K padded to a 16-byte multiple by construction)
+        bf = be.gemm(W.detach(), b1d.view(1, K), residual=bl.detach().view(N, 1), out_dtype=torch.float32).view(N)
+        z = be.gemm(xhat, Wf, bias=bf)
+        y, mean, rstd = be.layernorm_fwd(z, g2.detach(), b2.detach(), 1e-5)
+        ctx.save_for_backward(xhat, z, mean, rstd)
+        ctx.params = (g1, b1, W, bl, g2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = B()
+        xhat, z, mean, rstd = ctx.saved_tensors
+        g1, b1, W, bl, g2, b2 = ctx.params
+        N, K = W.shape
+        g2s, b2s = sink_of(g2), sink_of(b2)
+        dg2 = g2s if g2s is not None else torch.zeros_like(g2)
+        db2 = b2s if b2s is not None else torch.zeros_like(b2)
+        dz = be.layernorm_bwd(dy.contiguous(), z, g2.detach(), mean, rstd, dg2, db2)
+        dbp = torch.zeros(N, dtype=torch.float32, device=dz.device)
+        be.colsum(dz, dbp)
+        G = torch.zeros((N, K), dtype=torch.float32, device=dz.device)
+        be.gemm(dz, xhat[:, :K], a_kc=False, b_kc=False, out=G, accumulate=True,
+                split_k=_split_k_for(N, K, dz.shape[0], dz.dtype), M=N, N=K, K=dz.shape[0])
+        # parameter-space epilogue (N x K elementwise, tiny next to the token stream)
+        Wd, g1d, b1d = W.detach(), g1.detach(), b1.detach()
+        dW = G * g1d[None, :] + dbp[:, None] * b1d[None, :]
+        dg1 = (Wd * G).sum(0)
+        db1 = Wd.t() @ dbp
+
+        def give(param, val):
+            s = sink_of(param)
+            if s is None:
+                return val
+            s.add_(val.view_as(s))
+            return None
+        return (None, give(g1, dg1), give(b1, db1), give(W, dW), give(bl, dbp),
+                None if g2s is not None else dg2, None if b2s is not None else db2, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------ PEG
+
+class PegFn(Function):
+    @staticmethod
+    def forward(ctx, x5, weight, bias):
+        w27 = weight.detach().reshape(weight.shape[0], 27)
+        y = B().peg_fwd(x5, w27, bias.detach())
+        ctx.save_for_backward(x5)
+        ctx.weight, ctx.bias = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x5,) = ctx.saved_tensors
+        w, b = ctx.weight, ctx.bias
+        ws, bs = sink_of(w), sink_of(b)
+        dw = ws.view(-1, 27) if ws is not None else torch.zeros((w.shape[0], 27), dtype=torch.float32, device=dy.device)
+        db = bs if bs is not None else torch.zeros_like(b)
+        dx = B().peg_bwd(dy.contiguous(), x5, w.detach().reshape(w.shape[0], 27), dw, db)
+        return dx, (None if ws is not None else dw.view_as(w)), (None if bs is not None else db)
+
+
+def peg_residual(x5, weight, bias):
+    """x + PEG(x) on a contiguous (b, D1, D2, D3, C) view (attention.py:63-84,324)."""
+    return PegFn.apply(x5, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ attention
+
+class CosineAttnFn(Function):
+    """attention.py:145-178 (self-attention, no null kv): l2norm(q)*q_scale, l2norm(k)*k_scale, sim*8 (+bias), softmax, @v."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale):
+        be = B()
+        HD = H * D
+        k, v = kv[:, :HD], kv[:, HD:]
+        qh, qinv = be.qk_norm_fwd(q, q_scale.detach(), H, D)
+        kh, kinv = be.qk_norm_fwd(k, k_scale.detach(), H, D)
+        vt = be.head_transpose(v, nseq, H, L, D)
+        o, lse = be.attn_fwd(qh, kh, vt, bias, None, nseq, H, L, D, scale)
+        ctx.save_for_backward(q, kv, qh, kh, qinv, kinv, o, lse, bias if bias is not None else q.new_empty(0))
+        ctx.scales = (q_scale, k_scale)
+        ctx.dims = (nseq, L, H, D, scale, bias is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        be = B()
+        q, kv, qh, kh, qinv, kinv, o, lse, bias = ctx.saved_tensors
+        nseq, L, H, D, scale, has_bias = ctx.dims
+        q_scale, k_scale = ctx.scales
+        HD = H * D
+        do = do.contiguous()
+        k, v = kv[:, :HD], kv[:, HD:]
+        qt = be.head_transpose(qh, nseq, H, L, D)
+        kt = be.head_transpose(kh, nseq, H, L, D)
+        dot = be.head_transpose(do, nseq, H, L, D)
+        dqh = torch.empty_like(qh)
+        dkv = torch.empty_like(kv)
+        dkh = torch.empty_like(kh)
+        dbias = torch.zeros_like(bias) if (has_bias and ctx.needs_input_grad[4]) else None
+        be.attn_bwd(qh, kh, v, qt, kt, o, do, dot, lse, bias if has_bias else None, None, dqh, dkh, dkv[:, HD:], dbias,
+                    nseq, H, L, D, scale)
+        qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
+        dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
+        dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
+        dq = torch.empty_like(q)
+        be.qk_norm_bwd(dqh, q, qinv, q_scale.detach(), dq, dqs, H, D)
+        be.qk_norm_bwd(dkh, k, kinv, k_scale.detach(), dkv[:, :HD], dks, H, D)
+        return (dq, dkv, None if qs_sink is not None else dqs, None if ks_sink is not None else dks, dbias,
+                None, None, None, None, None)
+
+
+class SdpaFn(Function):
+    """HF BertSelfAttention core: softmax(q k^T / sqrt(d) + mask) v; q, k, v are (M, H*D) activations."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, keymask, nseq, L, H, D, scale):
+        be = B()
+        vt = be.head_transpose(v, nseq, H, L, D)
+        o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale)
+        ctx.save_for_backward(q, k, v, o, lse, keymask if keymask is not None else q.new_empty(0))
+        ctx.dims = (nseq, L, H, D, scale, keymask is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        be = B()
+        q, k, v, o, lse, keymask = ctx.saved_tensors
+        nseq, L, H, D, scale, has_mask = ctx.dims
+        do = do.contiguous()
+        qt = be.head_transpose(q, nseq, H, L, D)
+        kt = be.head_transpose(k, nseq, H, L, D)
+        dot = be.head_transpose(do, nseq, H, L, D)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, keymask if has_mask else None, dq, dk, dv, None,
+                    nseq, H, L, D, scale)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ small ops
+
+class GegluFn(Function):
+    @staticmethod
+    def forward(ctx, u):
+        ctx.save_for_backward(u)
+        return B().geglu_fwd(u)
+
+    @staticmethod
+    def backward(ctx, dg):
+        (u,) = ctx.saved_tensors
+        return B().geglu_bwd(dg.contiguous(), u)
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, u):
+        ctx.save_for_backward(u)
+        return B().gelu_fwd(u)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (u,) = ctx.saved_tensors
+        return B().gelu_bwd(dh.contiguous(), u)
+
+
+class LeakyFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return B().leaky_relu_fwd(x, slope)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return B().leaky_relu_bwd(dy.contiguous(), x, ctx.slope), None
+
+
+class Permute0213Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return B().permute0213(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return B().permute0213(dy.contiguous())
+
+
+class PoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.t = x.shape[1]
+        return B().pool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return B().pool_bwd(dy.contiguous(), ctx.t)
+
+
+class CpbExpandFn(Function):
+    @staticmethod
+    def forward(ctx, tab, gh, gw):
+        ctx.g = (gh, gw)
+        return B().cpb_expand(tab.contiguous(), gh, gw)
+
+    @staticmethod
+    def backward(ctx, dbias):
+        return B().cpb_reduce(dbias.contiguous(), *ctx.g), None, None
+
+
+class VqFn(Function):
+    """vector_quantize_pytorch 1.1.2 cosine codebook (ctvit.py:403): argmax of cosine similarity, gather, straight-through,
+    EMA buffer update in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, embed, cluster_size, training, decay):
+        be = B()
+        xn, _ = be.l2norm_rows(x, x.dtype)
+        en, _ = be.l2norm_rows(embed, x.dtype)
+        idx, _ = be.gemm_argmax(xn, en)
+        q = be.vq_gather(embed, idx, x.dtype)   # raw (pre-update) codebook rows
+        if training:
+            bins, esum = be.vq_ema(idx, xn, cluster_size, embed, decay)
+            hook = getattr(VqFn, "stat_sync", None)
+            if hook is not None:
+                hook(bins, esum)            # data-parallel: all-reduce(SUM) the statistics
+            be.vq_ema_update(cluster_size, embed, bins, esum, decay)
+        ctx.training = training
+        ctx.mark_non_differentiable(idx)
+        return q, idx
+
+    @staticmethod
+    def backward(ctx, dq, _didx):
+        return (dq if ctx.training else None), None, None, None, None
+
+
+class VisualLatentFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, wsh):
+        y = B().visual_latent_fwd(x, wsh)
+        ctx.save_for_backward(x, wsh)
+        ctx.weight = weight
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wsh = ctx.saved_tensors
+        w = ctx.weight
+        sink = sink_of(w)
+        dw = None
+        if w.requires_grad:
+            dw = sink if sink is not None else torch.empty(w.shape, dtype=torch.float32, device=dy.device)
+        dx = B().visual_latent_bwd(dy.contiguous(), x, wsh, dw, accumulate=sink is not None, want_dx=ctx.needs_input_grad[0])
+        return dx, (None if sink is not None else dw), None
+
+
+def visual_latent(x, weight):
+    return VisualLatentFn.apply(x, weight, plain_shadow(weight, x.dtype))
+
+
+class ClipLossFn(Function):
+    """ct_clip.py:771,796,845-901: l2norm, logits * exp(temperature), symmetric InfoNCE.  Forward and backward in one launch."""
+
+    @staticmethod
+    def forward(ctx, tl, il, temperature):
+        out, _, dtl, dil, dtemp = B().clip_loss(tl.contiguous(), il.contiguous(), temperature.detach().reshape(1))
+        ctx.save_for_backward(dtl, dil, dtemp)
+        ctx.temperature = temperature
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dtl, dil, dtemp = ctx.saved_tensors
+        be = B()
+        s = dloss.reshape(1).to(torch.float32).contiguous()
+        be.scale_by_scalar(dtl, s)
+        be.scale_by_scalar(dil, s)
+        be.scale_by_scalar(dtemp, s)
+        t = ctx.temperature
+        sink = sink_of(t)
+        if sink is not None:
+            sink.add_(dtemp.view_as(sink))
+            return dtl, dil, None
+        return dtl, dil, dtemp.view_as(t)
+
+
+class BertEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, dtype):
+        x = B().bert_embed_fwd(ids, word.detach(), pos.detach(), typ.detach()[0].contiguous(), dtype)
+        ctx.save_for_backward(ids)
+        ctx.params = (word, pos, typ)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        word, pos, typ = ctx.params
+        ws, ps, ts = sink_of(word), sink_of(pos), sink_of(typ)
+        dw = ws if ws is not None else torch.zeros_like(word)
+        dp = ps if ps is not None else torch.zeros_like(pos)
+        dt = ts if ts is not None else torch.zeros_like(typ)
+        B().bert_embed_bwd(ids, dx.contiguous(), dw, dp, dt)   # dt row 0 only (token_type_ids are all zero)
+        return None, (None if ws is not None else dw), (None if ps is not None else dp), (None if ts is not None else dt), None
+
+
+def l2norm_f32(x):
+    y, _ = B().l2norm_rows(x.contiguous(), torch.float32)
+    return y

@@ -1,0 +1,247 @@
+"""CTClipTrainer (drop-in for scripts/CTCLIPTrainer.py:113-348) for one-process-per-GPU training on MI355X.
+
+Same constructor keywords and methods (``train``, ``train_step``, ``save``, ``load``, ``print``, ``is_main``,
+buffer ``steps``).  Differences, all additive and documented in INTEGRATION.md:
+  * no Accelerate: the process group is ``torch.distributed`` (RCCL) initialised from RANK/WORLD_SIZE when present;
+  * ``train_dataset`` / ``valid_dataset`` / ``evaluate`` / ``checkpoint`` keywords let a caller inject data and switch off
+    the every-step evaluation + 1.75 GB checkpoint that dominate the reference loop (CTCLIPTrainer.py:266-337);
+  * the optimiser is the fused HIP Adam over one flat f32 buffer (grad-norm clip 0.5 + Adam(0.9, 0.99), optimizer.py:24).
+"""
+import os
+from pathlib import Path
+from shutil import rmtree
+
+import torch
+from torch import nn
+from torch.utils.data import DataLoader
+
+from . import backend as _be
+from . import distributed as _dist
+from . import functional as Fn
+
+UNUSED_PARAM_MARKERS = ("_extra.", "to_pixels", "to_patch_emb_first_frame", ".pooler.", "context_norm.", "null_kv")
+
+
+def exists(v):
+    return v is not None
+
+
+def noop(*a, **k):
+    pass
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+def hot_path_parameters(model):
+    """Parameters that receive gradients on the CT-CLIP path (the rest never do: SURVEY.md section 2 collective table)."""
+    return [(n, p) for n, p in model.named_parameters()
+            if p.requires_grad and not any(m in n for m in UNUSED_PARAM_MARKERS)]
+
+
+class FusedAdam:
+    """Flat-buffer Adam/AdamW + global grad-norm clip on HIP kernels; minimal torch.optim-like surface."""
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        dev = self.params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]     # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(self.params, sizes):
+                view = self.flat_param[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                g = self.flat_grad[off:off + p.numel()].view(p.shape)
+                p._ctclip_grad_sink = g
+                p.grad = g
+                self.offsets.append(off)
+                off += sz
+        self.step_count = 0
+        self.last_norm = None
+        Fn.bump_weight_epoch()
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+
+    def step(self, max_grad_norm=None, extra_sq=None):
+        be = _be.get()
+        self.step_count += 1
+        clip = be.grad_norm_clip(self.flat_grad, max_grad_norm or 0.0, extra_sq)
+        self.last_norm = clip
+        be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                     self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None)
+        Fn.bump_weight_epoch()
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names,
+                    lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class CTClipTrainer(nn.Module):
+    def __init__(self, CTClip, *, num_train_steps, batch_size, data_train="train", data_valid="valid",
+                 reports_file_train="data_reports.xslx", reports_file_valid="data_reports.xslx",
+                 train_meta_file="meta_data.csv", valid_meta_file="meta_data.csv", labels="labels.csv", tokenizer=None,
+                 lr=1.25e-6, wd=0.0, max_grad_norm=0.5, save_results_every=1, save_model_every=1,
+                 results_folder="./ctclip/", num_workers=8, accelerate_kwargs: dict = dict(),
+                 train_dataset=None, valid_dataset=None, evaluate=True, checkpoint=True, max_text_len=512,
+                 sync_loss_every=1):
+        super().__init__()
+        if "RANK" in os.environ and "WORLD_SIZE" in os.environ and not _dist.is_on() and int(os.environ["WORLD_SIZE"]) > 1:
+            torch.distributed.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        self.device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        self.CTClip = CTClip.to(self.device)
+        if tokenizer is None:
+            from transformers import BertTokenizer
+            tokenizer = BertTokenizer.from_pretrained("microsoft/BiomedVLP-CXR-BERT-specialized", do_lower_case=True)
+        self.tokenizer = tokenizer
+        self.register_buffer("steps", torch.Tensor([0]))
+        self.num_train_steps = num_train_steps
+        self.batch_size = batch_size
+        self.max_grad_norm = max_grad_norm
+        self.lr = lr
+        self.max_text_len = max_text_len
+        self.sync_loss_every = sync_loss_every
+
+        self.optim = FusedAdam(hot_path_parameters(self.CTClip), lr=lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+        gather = getattr(self.CTClip, "gather_negatives", True)
+        self.reducer = _dist.GradReducer(self.optim.flat_grad, op="sum" if gather else "mean")
+        Fn.VqFn.stat_sync = staticmethod(_dist.sync_vq_stats)
+
+        if train_dataset is None:
+            from data import CTReportDataset  # the reference's scripts/data.py, when run from its scripts directory
+            train_dataset = CTReportDataset(data_folder=data_train, reports_file=reports_file_train, meta_file=train_meta_file)
+        self.ds = train_dataset
+        self.dl = DataLoader(self.ds, num_workers=num_workers, batch_size=self.batch_size, shuffle=True)
+        self.dl_iter = cycle(self.dl)
+        self.evaluate = evaluate
+        if evaluate:
+            if valid_dataset is None:
+                from data_inference_nii import CTReportDatasetinfer
+                valid_dataset = CTReportDatasetinfer(data_folder=data_valid, reports_file=reports_file_valid,
+                                                     meta_file=valid_meta_file, labels=labels)
+            self.valid_ds = valid_dataset
+            self.valid_dl = DataLoader(self.valid_ds, num_workers=num_workers, batch_size=1, shuffle=False)
+            self.valid_dl_iter = cycle(self.valid_dl)
+        self.checkpoint = checkpoint
+        self.save_model_every = save_model_every
+        self.save_results_every = save_results_every
+        self.results_folder = Path(results_folder)
+        # the reference asks interactively before clearing (CTCLIPTrainer.py:200); only do so on an interactive main rank
+        if self.is_main and len([*self.results_folder.glob("**/*")]) > 0 and os.isatty(0):
+            answer = input("do you want to clear previous experiment checkpoints and results? (y/n) ")
+            if answer.lower() in ("yes", "y"):
+                rmtree(str(self.results_folder))
+        self.results_folder.mkdir(parents=True, exist_ok=True)
+
+    # -- reference surface
+    def save(self, path):
+        if not self.is_main:
+            return
+        torch.save(dict(model=self.CTClip.state_dict(), optim=self.optim.state_dict()), path)
+
+    def load(self, path):
+        path = Path(path)
+        assert path.exists()
+        pkg = torch.load(path, weights_only=False)
+        self.CTClip.load_state_dict(pkg["model"])
+        self.optim.load_state_dict(pkg["optim"])
+        Fn.bump_weight_epoch()
+
+    def print(self, msg):
+        if self.is_main:
+            print(msg)
+
+    @property
+    def is_main(self):
+        return _dist.rank() == 0
+
+    def tokenize(self, text):
+        return self.tokenizer(list(text), return_tensors="pt", padding="max_length", truncation=True,
+                              max_length=self.max_text_len).to(self.device)
+
+    def forward_backward(self, video, text_tokens):
+        """fwd + bwd + gradient all-reduce; returns the (device) loss."""
+        loss = self.CTClip(text_tokens, video, return_loss=True, device=self.device)
+        loss.backward()
+        self.reducer.reduce()
+        return loss
+
+    def train_step(self):
+        steps = int(self.steps.item())
+        self.CTClip.train()
+        logs = {}
+        video, text = next(self.dl_iter)
+        video = video.to(self.device, non_blocking=True)
+        text_tokens = text if hasattr(text, "input_ids") else self.tokenize(text)
+        loss = self.forward_backward(video, text_tokens)
+        self.optim.step(self.max_grad_norm)
+        self.optim.zero_grad()
+        if self.sync_loss_every and steps % self.sync_loss_every == 0:
+            logs["loss"] = loss.item()
+            self.print(f"{steps}: loss: {logs['loss']}")
+        if self.evaluate and self.is_main and not (steps % self.save_results_every):
+            self.run_validation(steps)
+        if self.checkpoint and self.is_main and not (steps % self.save_model_every):
+            model_path = str(self.results_folder / f"CTClip.{steps}.pt")
+            torch.save(self.CTClip.state_dict(), model_path)
+            self.print(f"{steps}: saving model to {str(self.results_folder)}")
+        self.steps += 1
+        return logs
+
+    def run_validation(self, steps):
+        """The in-training zero-shot check of CTCLIPTrainer.py:266-326 (10 validation volumes x 18 pathologies)."""
+        import numpy as np
+        pathologies = ['Medical material', 'Arterial wall calcification', 'Cardiomegaly', 'Pericardial effusion',
+                       'Coronary artery wall calcification', 'Hiatal hernia', 'Lymphadenopathy', 'Emphysema', 'Atelectasis',
+                       'Lung nodule', 'Lung opacity', 'Pulmonary fibrotic sequela', 'Pleural effusion',
+                       'Mosaic attenuation pattern', 'Peribronchial thickening', 'Consolidation', 'Bronchiectasis',
+                       'Interlobular septal thickening']
+        model = self.CTClip
+        model.eval()
+        predictedall, realall = [], []
+        with torch.no_grad():
+            for _ in range(10):
+                valid_data, text, onehotlabels, name_acc = next(self.valid_dl_iter)
+                valid_data = valid_data.to(self.device)
+                predicted = []
+                for pathology in pathologies:
+                    tokens = self.tokenize([f"There is {pathology}.", f"There is no {pathology}."])
+                    out = torch.softmax(model(tokens, valid_data, device=self.device), dim=0)
+                    predicted.append(float(out[0]))
+                predictedall.append(predicted)
+                realall.append(onehotlabels.detach().cpu().numpy()[0])
+        model.train()
+        plotdir = str(self.results_folder / f"CTClip_{steps}") + "/"
+        Path(plotdir).mkdir(parents=True, exist_ok=True)
+        try:
+            from eval import evaluate_internal  # the reference's scripts/eval.py
+            evaluate_internal(np.array(predictedall), np.array(realall), pathologies, plotdir)
+        except ImportError:
+            np.save(plotdir + "predicted.npy", np.array(predictedall))
+            np.save(plotdir + "labels.npy", np.array(realall))
+
+    def train(self, log_fn=noop):
+        while self.steps < self.num_train_steps:
+            logs = self.train_step()
+            log_fn(logs)
+        self.print("training complete")

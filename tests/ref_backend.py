@@ -1,0 +1,317 @@
+"""TEST INFRASTRUCTURE ONLY -- pure-torch checker with the interface of ``ct_clip_amd.backend.HipBackend``.
+
+Two uses: (1) CPU tests swap it in (``backend.use(RefBackend())``) to validate the host-side composition and the
+hand-derived backward formulas of ``ct_clip_amd.functional`` against the oracle without a GPU; (2) GPU tests call the
+same method on both backends with the same inputs to check every HIP kernel.  Never used by the product.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _f(t):
+    return t.float()
+
+
+class RefBackend:
+    name = "torch-reference (test only)"
+
+    # ---- GEMM
+    def gemm(self, a, b, *, a_kc=True, b_kc=True, bias=None, residual=None, out=None, out_dtype=None, accumulate=False,
+             alpha=1.0, split_k=1, M=None, N=None, K=None):
+        A = a if a_kc else a.t()
+        Bm = b if b_kc else b.t()
+        M = A.shape[0] if M is None else M
+        N = Bm.shape[0] if N is None else N
+        K = min(A.shape[1], Bm.shape[1]) if K is None else K
+        y = alpha * (_f(A[:M, :K]) @ _f(Bm[:N, :K]).t())
+        if bias is not None:
+            y = y + bias[:N]
+        if residual is not None:
+            y = y + _f(residual[:M, :N])
+        if out is None:
+            return y.to(out_dtype or a.dtype)
+        if accumulate:
+            out[:M, :N] += y.to(out.dtype)
+        else:
+            out[:M, :N] = y.to(out.dtype)
+        return out
+
+    def gemm_argmax(self, a, b):
+        s = _f(a) @ _f(b).t()
+        val, idx = s.max(dim=-1)
+        return idx, val
+
+    # ---- norms
+    def layernorm_fwd(self, x, gamma, beta, eps, want_stats=True):
+        xf = _f(x)
+        mean = xf.mean(-1)
+        var = xf.var(-1, unbiased=False)
+        rstd = torch.rsqrt(var + eps)
+        y = (xf - mean[:, None]) * rstd[:, None]
+        if gamma is not None:
+            y = y * gamma
+        if beta is not None:
+            y = y + beta
+        return y.to(x.dtype), mean, rstd
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None):
+        xh = (_f(x) - mean[:, None]) * rstd[:, None]
+        g = _f(dy) * (gamma if gamma is not None else 1.0)
+        dx = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+        if dgamma is not None:
+            dgamma += (_f(dy) * xh).sum(0)
+        if dbeta is not None:
+            dbeta += _f(dy).sum(0)
+        return dx.to(x.dtype)
+
+    def patch_ln(self, video, pt, p1, p2, kpad, eps, dtype):
+        b, c, f, H, W = video.shape
+        t, h, w = f // pt, H // p1, W // p2
+        x = video.reshape(b, c, t, pt, h, p1, w, p2).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b * t * h * w, -1)
+        x = F.layer_norm(x, x.shape[-1:], None, None, eps)
+        out = torch.zeros((x.shape[0], kpad), dtype=dtype, device=video.device)
+        out[:, :x.shape[1]] = x.to(dtype)
+        return out
+
+    def l2norm_rows(self, x, out_dtype, eps=1e-12):
+        xf = _f(x)
+        inv = 1.0 / xf.norm(dim=-1).clamp(min=eps)
+        return (xf * inv[:, None]).to(out_dtype), inv
+
+    # ---- PEG
+    def peg_fwd(self, x, w, bias):
+        C = x.shape[-1]
+        xc = _f(x).permute(0, 4, 1, 2, 3)
+        y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C)
+        return (y.permute(0, 2, 3, 4, 1) + _f(x)).to(x.dtype).contiguous()
+
+    def peg_bwd(self, dy, x, w, dw=None, db=None):
+        C = x.shape[-1]
+        xx = _f(x).detach().requires_grad_(True)
+        ww = w.detach().clone().requires_grad_(True)
+        bb = torch.zeros(C, device=x.device, requires_grad=True)
+        with torch.enable_grad():
+            xc = xx.permute(0, 4, 1, 2, 3)
+            y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), ww.view(C, 1, 3, 3, 3), bb, groups=C).permute(0, 2, 3, 4, 1) + xx
+            gx, gw, gb = torch.autograd.grad(y, (xx, ww, bb), _f(dy))
+        if dw is not None:
+            dw += gw
+        if db is not None:
+            db += gb
+        return gx.to(x.dtype).contiguous()
+
+    # ---- attention
+    def head_transpose(self, x, nseq, H, L, D):
+        Lp = (L + 7) // 8 * 8
+        xt = torch.zeros((nseq, H, D, Lp), dtype=x.dtype, device=x.device)
+        xt[..., :L] = x[:, :H * D].reshape(nseq, L, H, D).permute(0, 2, 3, 1)
+        return xt
+
+    def qk_norm_fwd(self, x, scale_vec, H, D):
+        M = x.shape[0]
+        xf = _f(x[:, :H * D]).reshape(M, H, D)
+        inv = 1.0 / xf.norm(dim=-1).clamp(min=1e-12)
+        y = xf * inv[..., None] * scale_vec
+        return y.reshape(M, H * D).to(x.dtype), inv
+
+    def qk_norm_bwd(self, dy, x, inv, scale_vec, dx, dscale, H, D):
+        M = x.shape[0]
+        xf = _f(x[:, :H * D]).reshape(M, H, D)
+        u = xf * inv[..., None]
+        g = _f(dy[:, :H * D]).reshape(M, H, D) * scale_vec
+        r = inv[..., None] * (g - u * (u * g).sum(-1, keepdim=True))
+        dx[:, :H * D] = r.reshape(M, H * D).to(dx.dtype)
+        if dscale is not None:
+            dscale += (_f(dy[:, :H * D]).reshape(M, H, D) * u).sum((0, 1))
+        return dx
+
+    def _scores(self, q, k, bias, keymask, nseq, H, L, D, scale):
+        qf = _f(q[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
+        kf = _f(k[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
+        s = torch.einsum("shid,shjd->shij", qf, kf) * scale
+        if bias is not None:
+            s = s + bias[None]
+        if keymask is not None:
+            s = s + keymask[:, None, None, :]
+        return qf, kf, s
+
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True):
+        qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
+        lse = torch.logsumexp(s, dim=-1)
+        p = torch.exp(s - lse[..., None])
+        v = _f(vt[..., :L]).permute(0, 1, 3, 2)  # (nseq, H, L, D)
+        o = torch.einsum("shij,shjd->shid", p, v).permute(0, 2, 1, 3).reshape(nseq * L, H * D)
+        return o.to(q.dtype).contiguous(), lse
+
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale):
+        qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
+        p = torch.exp(s - lse[..., None])
+        vf = _f(v[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
+        dof = _f(dout[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
+        of = _f(o[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
+        delta = (dof * of).sum(-1)
+        dvf = torch.einsum("shij,shid->shjd", p, dof)
+        dp = torch.einsum("shid,shjd->shij", dof, vf)
+        ds = p * (dp - delta[..., None])
+        dqf = torch.einsum("shij,shjd->shid", ds, kf) * scale
+        dkf = torch.einsum("shij,shid->shjd", ds, qf) * scale
+        back = lambda t: t.permute(0, 2, 1, 3).reshape(nseq * L, H * D)
+        dq[:, :H * D] = back(dqf).to(dq.dtype)
+        dk[:, :H * D] = back(dkf).to(dk.dtype)
+        dv[:, :H * D] = back(dvf).to(dv.dtype)
+        if dbias is not None:
+            dbias += ds.sum(0)
+
+    # ---- elementwise
+    def geglu_fwd(self, u):
+        a, g = _f(u).chunk(2, dim=-1)
+        return (a * F.gelu(g)).to(u.dtype)
+
+    def geglu_bwd(self, dg, u):
+        uu = _f(u).detach().requires_grad_(True)
+        with torch.enable_grad():
+            a, g = uu.chunk(2, dim=-1)
+            y = a * F.gelu(g)
+            (gu,) = torch.autograd.grad(y, uu, _f(dg))
+        return gu.to(u.dtype)
+
+    def gelu_fwd(self, u):
+        return F.gelu(_f(u)).to(u.dtype)
+
+    def gelu_bwd(self, dh, u):
+        uu = _f(u).detach().requires_grad_(True)
+        with torch.enable_grad():
+            (gu,) = torch.autograd.grad(F.gelu(uu), uu, _f(dh))
+        return gu.to(u.dtype)
+
+    def leaky_relu_fwd(self, x, slope):
+        return F.leaky_relu(x, slope)
+
+    def leaky_relu_bwd(self, dy, x, slope):
+        return torch.where(x > 0, dy, dy * slope)
+
+    def colsum(self, x, out, N=None):
+        N = x.shape[1] if N is None else N
+        out += _f(x[:, :N]).sum(0)
+        return out
+
+    def permute0213(self, x):
+        return x.permute(0, 2, 1, 3).contiguous()
+
+    def pool_fwd(self, x):
+        return _f(x).mean(1).to(x.dtype)
+
+    def pool_bwd(self, dy, t):
+        return (_f(dy)[:, None, :] / t).expand(-1, t, -1).to(dy.dtype).contiguous()
+
+    def convert_pad(self, src, rows_dst, cols_dst, dtype, colscale=None, out=None):
+        rows, cols = src.shape
+        if out is None:
+            out = torch.empty((rows_dst, cols_dst), dtype=dtype, device=src.device)
+        out.zero_()
+        v = _f(src)
+        if colscale is not None:
+            v = v * colscale
+        out[:rows, :cols] = v.to(out.dtype)
+        return out
+
+    def _cls(self, gh, gw, device):
+        L = gh * gw
+        i = torch.arange(L, device=device)
+        iy, ix = i // gw, i % gw
+        return (iy[:, None] - iy[None, :] + gh - 1) * (2 * gw - 1) + (ix[:, None] - ix[None, :] + gw - 1)
+
+    def cpb_expand(self, tab, gh, gw):
+        cls = self._cls(gh, gw, tab.device)
+        return tab[cls].permute(2, 0, 1).contiguous()
+
+    def cpb_reduce(self, dbias, gh, gw):
+        H = dbias.shape[0]
+        cls = self._cls(gh, gw, dbias.device).reshape(-1)
+        dtab = torch.zeros(((2 * gh - 1) * (2 * gw - 1), H), device=dbias.device)
+        dtab.index_add_(0, cls, dbias.reshape(H, -1).t())
+        return dtab
+
+    def bert_embed_fwd(self, ids, word, pos, type0, dtype):
+        B, T = ids.shape
+        x = word[ids] + pos[:T][None] + type0[None, None]
+        return x.reshape(B * T, -1).to(dtype)
+
+    def bert_embed_bwd(self, ids, dx, dword, dpos, dtype0):
+        B, T = ids.shape
+        g = _f(dx)
+        if dword is not None:
+            dword.index_add_(0, ids.reshape(-1), g)
+        if dpos is not None:
+            dpos[:T] += g.reshape(B, T, -1).sum(0)
+        if dtype0 is not None:
+            dtype0[0] += g.sum(0)
+
+    # ---- VQ
+    def vq_gather(self, embed, idx, dtype):
+        return embed[idx.reshape(-1)].to(dtype)
+
+    def vq_ema(self, idx, xn, cluster_size, embed, decay):
+        C, d = embed.shape
+        bins = torch.bincount(idx.reshape(-1), minlength=C).float()
+        esum = torch.zeros((C, d), device=embed.device).index_add_(0, idx.reshape(-1), _f(xn))
+        return bins, esum
+
+    def vq_ema_update(self, cluster_size, embed, bins, esum, decay):
+        cluster_size.mul_(decay).add_(bins * (1 - decay))
+        enorm = F.normalize(esum / bins.clamp(min=1.0)[:, None], dim=-1)
+        enorm = torch.where((bins == 0)[:, None], F.normalize(embed, dim=-1), enorm)
+        embed.mul_(decay).add_(enorm * (1 - decay))
+
+    # ---- head
+    def visual_latent_fwd(self, x, w):
+        return _f(x) @ _f(w).t()
+
+    def visual_latent_bwd(self, dy, x, w, dw=None, accumulate=False, want_dx=True):
+        if dw is not None:
+            g = dy.t() @ _f(x)
+            if accumulate:
+                dw += g
+            else:
+                dw.copy_(g)
+        return (dy @ _f(w)).to(x.dtype) if want_dx else None
+
+    def clip_loss(self, tl, il, temperature, want_grads=True, want_logits=False):
+        a = tl.detach().clone().requires_grad_(True)
+        b = il.detach().clone().requires_grad_(True)
+        th = temperature.detach().clone().reshape(1).requires_grad_(True)
+        with torch.enable_grad():
+            s = F.normalize(a, dim=-1) @ F.normalize(b, dim=-1).t() * th.exp()
+            e1, e2 = s.exp(), s.t().exp()
+            l1 = (-torch.log(e1.diagonal() + 1e-20) + torch.log(e1.sum(-1) + 1e-20)).mean()
+            l2 = (-torch.log(e2.diagonal() + 1e-20) + torch.log(e2.sum(-1) + 1e-20)).mean()
+            loss = (l1 + l2) / 2
+            if want_grads:
+                ga, gb, gt = torch.autograd.grad(loss, (a, b, th))
+            else:
+                ga = gb = gt = None
+        out = torch.stack([loss.detach(), th.detach().exp()[0]])
+        return out, (s.detach() if want_logits else None), ga, gb, gt
+
+    def scale_by_scalar(self, x, scalar):
+        x.mul_(scalar)
+        return x
+
+    # ---- optimiser
+    def grad_norm_clip(self, g, max_norm, extra_sq=None):
+        sq = (g.double() ** 2).sum()
+        if extra_sq is not None:
+            sq = sq + extra_sq.double()[0]
+        norm = sq.sqrt().float()
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) if max_norm else torch.ones_like(norm)
+        return torch.stack([norm, coef])
+
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None):
+        gg = g * (clip[1] if clip is not None else 1.0)
+        if weight_decay:
+            p.mul_(1 - lr * weight_decay)
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2 = 1 - beta2 ** step
+        p.addcdiv_(m, v.sqrt() / (bc2 ** 0.5) + eps, value=-lr / bc1)
