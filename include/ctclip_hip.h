@@ -1,0 +1,158 @@
+/* ctclip_hip.h -- C ABI of libctclip_hip.so: the MI355X (gfx950) kernels of the CT-CLIP training hot path.
+ *
+ * The reference (ibrahimethemhamamci/CT-CLIP) is pure Python on PyTorch: its "FFI" for this path is the set of
+ * torch / HuggingFace / vector-quantize-pytorch calls listed in SURVEY.md section 8(a).  Each entry point below
+ * replaces one of those calls; the comment cites the reference line it stands in for (paths relative to the
+ * reference repository: attention.py and ctvit.py live in transformer_maskgit/transformer_maskgit/, ct_clip.py in
+ * CT_CLIP/ct_clip/, CTCLIPTrainer.py in scripts/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous (or row-strided, where an ld* argument exists) buffer;
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit);  statistics, biases, gradients of parameters are float32;
+ *   - the library never allocates, never synchronises and only uses the stream it is handed;
+ *   - return value 0 = success; -1 bad argument, -2 unsupported shape/dtype, -3 workspace too small,
+ *     -(1000 + hipError_t) launch failure; ctclip_last_error() gives the text (thread-local);
+ *   - "ACCUMULATED" outputs are += (zero them first if a plain result is wanted).
+ * The ctypes binding used by the Python host is ct_clip_amd/_lib.py; INTEGRATION.md shows the reference-side stub.
+ */
+#ifndef CTCLIP_HIP_H
+#define CTCLIP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct ihipStream_t* hipStream_t;
+
+/* per-(sequence, head) transposed copy [seq][h][d][Lp] used as MFMA A-operands by the attention kernels. */
+int ctclip_head_transpose(const void* x, void* xt, int nseq, int H, int L, int Lp, int D, int64_t ldx, int dtype, hipStream_t stream);
+
+/* l2norm(q)*q_scale / l2norm(k)*k_scale per head (attention.py:152-154). */
+int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y, float* inv, int64_t M, int H, int D, int64_t ldx, int64_t ldy, int dtype, hipStream_t stream);
+
+/* backward of the above; dscale (D) ACCUMULATED. */
+int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, hipStream_t stream);
+
+/* softmax(scale*q k^T + bias[h] + keymask[seq]) v (attention.py:156-178; HF BertSelfAttention). */
+int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int dtype, hipStream_t stream);
+
+/* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). */
+int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, hipStream_t stream);
+
+/* thread-local message of the last failing call. */
+const char* ctclip_last_error(void);
+
+/* ABI version (1). */
+int ctclip_abi_version(void);
+
+/* "gfx950". */
+const char* ctclip_target_arch(void);
+
+/* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
+int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
+
+/* backward of the above; dw (C,27) / db (C) ACCUMULATED, may be NULL. */
+int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
+
+/* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
+int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha, hipStream_t stream);
+
+/* bytes of workspace ctclip_gemm_argmax needs. */
+int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
+
+/* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
+int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767). */
+int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, hipStream_t s);
+
+/* backward of the above (dX and dW). */
+int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K, int accumulate, int dtype, hipStream_t s);
+
+/* l2norm + logits*exp(temperature) + symmetric InfoNCE, forward and backward (ct_clip.py:771,796,845-901). */
+int ctclip_clip_loss(const float* text_latents, const float* image_latents, const float* temperature, float* out, float* logits, float* d_text, float* d_image, float* d_temperature, int G, int Dl, hipStream_t s);
+
+/* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). */
+int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s);
+
+/* GEGLU: gelu(gate) * x (attention.py:39-42) on the padded [x | gate] layout. */
+int ctclip_geglu_fwd(const void* u, void* g, int64_t M, int Hp, int dtype, hipStream_t s);
+
+/* backward of GEGLU. */
+int ctclip_geglu_bwd(const void* dg, const void* u, void* du, int64_t M, int Hp, int dtype, hipStream_t s);
+
+/* erf-GELU (HF BertIntermediate). */
+int ctclip_gelu_fwd(const void* u, void* h, int64_t n, int dtype, hipStream_t s);
+
+/* backward of erf-GELU. */
+int ctclip_gelu_bwd(const void* dh, const void* u, void* du, int64_t n, int dtype, hipStream_t s);
+
+/* nn.LeakyReLU(0.1) of ContinuousPositionBias (attention.py:19-20,247-250). */
+int ctclip_leaky_relu_fwd(const float* x, float* y, int64_t n, float slope, hipStream_t s);
+
+/* backward of LeakyReLU. */
+int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, float slope, hipStream_t s);
+
+/* bias gradients: out[n] += sum_m x[m][n]. */
+int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, hipStream_t s);
+
+/* rearrange '(b t)(h w) d <-> (b h w) t d' between the spatial and temporal phases (ctvit.py:297-305). */
+int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s);
+
+/* torch.mean(enc_image, dim=1) (ct_clip.py:724). */
+int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
+
+/* backward of the depth mean-pool. */
+int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
+
+/* f32 master weight -> padded compute-dtype shadow (optionally scaled per column). */
+int ctclip_convert_pad(const void* src, void* dst, const float* colscale, int64_t rows, int64_t cols, int64_t lds_, int64_t rows_dst, int64_t cols_dst, int64_t ldd, int src_dtype, int dst_dtype, hipStream_t s);
+
+/* ContinuousPositionBias: gather the per-offset MLP table to (heads, hw, hw) (attention.py:261-276). */
+int ctclip_cpb_expand(const float* tab, float* bias, int H, int gh, int gw, hipStream_t s);
+
+/* backward of the gather (deterministic segmented sum). */
+int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
+
+/* HF BertEmbeddings: word + position + token_type(0) lookup. */
+int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows, int Tlen, int Hd, int dtype, hipStream_t s);
+
+/* scatter-add of the embedding gradients (f32 atomics). */
+int ctclip_bert_embed_bwd(const int64_t* ids, const void* dx, float* dword, float* dpos, float* dtype0, int64_t rows, int Tlen, int Hd, int dtype, hipStream_t s);
+
+/* quantize = embed[ind] (vector_quantize_pytorch, ctvit.py:403). */
+int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t M, int d, int dtype, hipStream_t s);
+
+/* VQ EMA statistics: bins (histogram) and embed_sum (segmented sum of normalised inputs). */
+int ctclip_vq_ema_accum(const int64_t* idx, const void* xn, float* bins, float* esum, int64_t M, int d, int dtype, hipStream_t s);
+
+/* VQ EMA buffer update (decay 0.8) of cluster_size and embed. */
+int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s);
+
+/* F.layer_norm (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm). gamma/beta may be NULL. */
+int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps, int dtype, hipStream_t stream);
+
+/* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. */
+int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols);
+
+/* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. */
+int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* CTViT.to_patch_emb[0:2]: Rearrange 'b c (t pt)(h p1)(w p2) -> b t h w (c pt p1 p2)' + LayerNorm statistics (ctvit.py:171-172). */
+int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, int W, int pt, int p1, int p2, int kpad, float eps, int out_dtype, hipStream_t stream);
+
+/* F.normalize(x, dim=-1) (attention.py:22-23; ct_clip.py:49-50; VQ l2norm). */
+int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int out_dtype, hipStream_t stream);
+
+/* bytes of workspace ctclip_grad_norm_clip needs. */
+int64_t ctclip_grad_norm_workspace(void);
+
+/* accelerator.clip_grad_norm_(params, 0.5) (CTCLIPTrainer.py:259-260): out = [norm, clip coefficient]. */
+int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, float max_norm, float* out, void* workspace, int64_t workspace_bytes, hipStream_t s);
+
+/* torch.optim.Adam(lr, betas=(0.9,0.99), eps=1e-8).step() over a flat buffer (optimizer.py:24; CTCLIPTrainer.py:262). */
+int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, hipStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

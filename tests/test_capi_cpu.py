@@ -1,0 +1,38 @@
+"""The C-ABI library must build, load, and export every symbol include/ctclip_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ctclip_hip.h")).read()
+    return sorted(set(re.findall(r"\b(ctclip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ct_clip_amd import build, _lib
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), f"missing symbol {s}"
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+
+
+def test_loader_binds_and_reports_version():
+    from ct_clip_amd import _lib
+    lib = _lib.load()
+    assert lib.ctclip_abi_version() == 1
+    assert lib.ctclip_target_arch() == b"gfx950"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ct_clip_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(ImportError, match="no PyTorch/CPU fallback"):
+        _lib.load()

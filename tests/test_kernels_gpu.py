@@ -1,0 +1,313 @@
+"""Per-kernel parity on a real MI355X: every primitive of the HIP backend (C-ABI) against the pure-torch checker on the same
+seeded inputs.  f32 mode is the parity mode (tight tolerances; MFMA f32 is an exact fmaf chain); bf16 is the performance mode
+(tolerances scaled to bf16 rounding of the inputs/outputs)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.ref_backend import RefBackend  # noqa: E402
+
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ct_clip_amd import backend
+    return backend.HipBackend()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return RefBackend()
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def tol(dtype, f32=(1e-4, 1e-5), bf16=(3e-2, 3e-2)):
+    return dict(rtol=f32[0], atol=f32[1]) if dtype == torch.float32 else dict(rtol=bf16[0], atol=bf16[1])
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a.float(), b.float(), **kw)
+
+
+# ---------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 72), (64, 2816, 512), (300, 512, 1408), (8, 8, 8)])
+def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
+    a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)   # asymmetric operands (transpose-detecting)
+    bias, res = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    y = hip.gemm(a, b, bias=bias, residual=res)
+    yr = ref.gemm(a, b, bias=bias, residual=res)
+    s = K ** 0.5
+    close(y, yr, **tol(dtype, (1e-4, 1e-4 * s), (2e-2, 2e-2 * s)))
+    y32 = hip.gemm(a, b, out_dtype=torch.float32, alpha=0.5)
+    close(y32, ref.gemm(a, b, out_dtype=torch.float32, alpha=0.5), **tol(dtype, (1e-4, 1e-4 * s), (1e-2, 1e-2 * s)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512)])
+def test_gemm_nn_grad_input(hip, ref, dtype, M, N, K):
+    # dx (M,N) = dy (M,K) @ W (K,N):  b is stored (K, N) and used with b_kc=False
+    dy, w = rnd(M, K, dtype=dtype, seed=5), rnd(K, N, dtype=dtype, seed=6)
+    y = hip.gemm(dy, w, a_kc=True, b_kc=False)
+    close(y, ref.gemm(dy, w, a_kc=True, b_kc=False), **tol(dtype, (1e-4, 1e-4 * K ** 0.5), (2e-2, 2e-2 * K ** 0.5)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("T,N,K,split", [(512, 128, 256, 1), (1000, 70, 130, 4), (4096, 1365, 512, 8), (640, 512, 4000, 3)])
+def test_gemm_tn_grad_weight_splitk_accumulate(hip, ref, dtype, T, N, K, split):
+    # dW (N,K) += dy (T,N)^T @ x (T,K): both operands stored token-major, contraction over rows; odd N exercises pair loads
+    Np = N + (N % 2) + 2
+    dyp, x = rnd(T, Np, dtype=dtype, seed=7), rnd(T, K + 8, dtype=dtype, seed=8)
+    dy = dyp[:, :N]
+    out = rnd(N, K, seed=9)
+    out_ref = out.clone()
+    hip.gemm(dy, x[:, :K], a_kc=False, b_kc=False, out=out, accumulate=True, split_k=split, M=N, N=K, K=T)
+    ref.gemm(dy, x[:, :K], a_kc=False, b_kc=False, out=out_ref, accumulate=True, M=N, N=K, K=T)
+    close(out, out_ref, **tol(dtype, (1e-4, 2e-4 * T ** 0.5), (2e-2, 2e-2 * T ** 0.5)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_argmax(hip, ref, dtype):
+    xn = torch.nn.functional.normalize(rnd(700, 128, seed=10), dim=-1).to(dtype)
+    en = torch.nn.functional.normalize(rnd(1000, 128, seed=11), dim=-1).to(dtype)
+    idx, val = hip.gemm_argmax(xn, en)
+    ridx, rval = ref.gemm_argmax(xn, en)
+    close(val, rval, **tol(dtype, (1e-5, 1e-5), (1e-2, 1e-2)))
+    agree = (idx == ridx).float().mean().item()
+    assert agree >= (0.999 if dtype == torch.float32 else 0.97), agree
+    # ties -> lowest index
+    e2 = en.clone(); e2[5] = e2[900]
+    idx2, _ = hip.gemm_argmax(xn, e2)
+    assert not (idx2 == 900).any()
+
+
+# ---------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols", [(37, 512), (1000, 768), (5, 64), (130, 2048)])
+def test_layernorm_fwd_bwd(hip, ref, dtype, rows, cols):
+    x, dy = rnd(rows, cols, dtype=dtype, seed=1), rnd(rows, cols, dtype=dtype, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(cols, seed=3), 0.1 * rnd(cols, seed=4)
+    y, mean, rstd = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+    yr, mr, rr = ref.layernorm_fwd(x, gamma, beta, 1e-5)
+    close(y, yr, **tol(dtype)); close(mean, mr, rtol=1e-4, atol=1e-5); close(rstd, rr, rtol=1e-4, atol=1e-5)
+    dg, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    dgr, dbr = dg.clone(), db.clone()
+    dx = hip.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+    dxr = ref.layernorm_bwd(dy, x, gamma, mr, rr, dgr, dbr)
+    close(dx, dxr, **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
+    close(dg, dgr, rtol=1e-3, atol=1e-3 * rows ** 0.5); close(db, dbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
+    y2, _, _ = hip.layernorm_fwd(x, gamma, None, 1e-5)   # gamma-only LayerNorm (attention.py:28-35)
+    close(y2, ref.layernorm_fwd(x, gamma, None, 1e-5)[0], **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(2, 32, 64, 64, 16, 16, 16), (1, 20, 40, 60, 10, 20, 20), (1, 6, 9, 6, 3, 3, 3)])
+def test_patch_ln(hip, ref, dtype, geom):
+    B, Fr, H, W, pt, p1, p2 = geom
+    K = pt * p1 * p2
+    kpad = (K + 63) // 64 * 64
+    video = rnd(B, 1, Fr, H, W, seed=5)
+    out = hip.patch_ln(video, pt, p1, p2, kpad, 1e-5, dtype)
+    close(out, ref.patch_ln(video, pt, p1, p2, kpad, 1e-5, dtype), **tol(dtype, (1e-4, 1e-5), (1e-2, 1e-2)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_l2norm_rows(hip, ref, dtype):
+    x = rnd(300, 512, dtype=dtype, seed=6)
+    y, inv = hip.l2norm_rows(x, dtype)
+    yr, ir = ref.l2norm_rows(x, dtype)
+    close(y, yr, **tol(dtype, (1e-5, 1e-6), (1e-2, 1e-2))); close(inv, ir, rtol=1e-4, atol=1e-6)
+    y32, _ = hip.l2norm_rows(rnd(16, 64, seed=7), torch.float32)
+    close(y32, ref.l2norm_rows(rnd(16, 64, seed=7), torch.float32)[0], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- PEG
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 2, 4, 4, 128), (1, 5, 3, 7, 64), (2, 24, 6, 6, 512)])
+def test_peg_fwd_bwd(hip, ref, dtype, shape):
+    C = shape[-1]
+    x, dy = rnd(*shape, dtype=dtype, seed=1), rnd(*shape, dtype=dtype, seed=2)
+    w, b = rnd(C, 27, seed=3, scale=0.2), rnd(C, seed=4, scale=0.2)
+    close(hip.peg_fwd(x, w, b), ref.peg_fwd(x, w, b), **tol(dtype, (1e-4, 1e-4), (3e-2, 3e-2)))
+    dw, db = torch.zeros(C, 27, device=DEV), torch.zeros(C, device=DEV)
+    dwr, dbr = dw.clone(), db.clone()
+    dx = hip.peg_bwd(dy, x, w, dw, db)
+    dxr = ref.peg_bwd(dy, x, w, dwr, dbr)
+    n = (x.numel() / C) ** 0.5
+    close(dx, dxr, **tol(dtype, (1e-4, 1e-4), (3e-2, 3e-2)))
+    close(dw, dwr, rtol=1e-3, atol=2e-3 * n); close(db, dbr, rtol=1e-3, atol=2e-3 * n)
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nseq,H,L,D,use_bias,use_mask", [(2, 4, 16, 32, True, False), (3, 2, 9, 32, True, False),
+                                                          (4, 8, 24, 32, False, False), (2, 8, 576, 32, True, False),
+                                                          (2, 12, 128, 64, False, True), (3, 4, 50, 64, False, True),
+                                                          (64, 2, 2, 32, False, False)])
+def test_attention_fwd_bwd(hip, ref, dtype, nseq, H, L, D, use_bias, use_mask):
+    M, HD = nseq * L, H * D
+    kv = rnd(M, 2 * HD, dtype=dtype, seed=1, scale=0.5)
+    q = rnd(M, HD, dtype=dtype, seed=2, scale=0.5)
+    k, v = kv[:, :HD], kv[:, HD:]
+    bias = rnd(H, L, L, seed=3) if use_bias else None
+    mask = None
+    if use_mask:
+        lens = torch.randint(L // 2, L + 1, (nseq,))
+        mask = ((torch.arange(L)[None] >= lens[:, None]).float() * torch.finfo(torch.float32).min).to(DEV)
+    scale = 8.0 if D == 32 else 0.125
+    if D == 32:   # cosine attention operates on unit vectors
+        q = torch.nn.functional.normalize(q.float().view(M, H, D), dim=-1).view(M, HD).to(dtype)
+        kv = torch.cat([torch.nn.functional.normalize(k.float().reshape(M, H, D), dim=-1).view(M, HD).to(dtype), v], 1).contiguous()
+        k, v = kv[:, :HD], kv[:, HD:]
+    vt = hip.head_transpose(v, nseq, H, L, D)
+    close(vt, ref.head_transpose(v, nseq, H, L, D), rtol=0, atol=0)
+    o, lse = hip.attn_fwd(q, k, vt, bias, mask, nseq, H, L, D, scale)
+    orf, lser = ref.attn_fwd(q, k, vt, bias, mask, nseq, H, L, D, scale)
+    close(o, orf, **tol(dtype, (1e-4, 1e-5), (2e-2, 2e-2))); close(lse, lser, **tol(dtype, (1e-4, 1e-4), (1e-2, 3e-2)))
+    do = rnd(M, HD, dtype=dtype, seed=4)
+    qt, kt, dot = (hip.head_transpose(t, nseq, H, L, D) for t in (q, k, do))
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dk = torch.empty_like(q)
+    dbias = torch.zeros_like(bias) if use_bias else None
+    hip.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, bias, mask, dq, dk, dkv[:, HD:], dbias, nseq, H, L, D, scale)
+    dqr, dkr, dvr = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    dbr = torch.zeros_like(bias) if use_bias else None
+    ref.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, bias, mask, dqr, dkr, dvr, dbr, nseq, H, L, D, scale)
+    t = tol(dtype, (1e-3, 1e-4), (3e-2, 3e-2))
+    close(dq, dqr, **t); close(dk, dkr, **t); close(dkv[:, HD:], dvr, **t)
+    if use_bias:
+        close(dbias, dbr, rtol=t["rtol"], atol=t["atol"] * nseq ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("H,D", [(4, 32), (12, 64)])
+def test_qk_norm(hip, ref, dtype, H, D):
+    M, HD = 200, H * D
+    kv = rnd(M, 2 * HD, dtype=dtype, seed=1)
+    sv = 1 + 0.1 * rnd(D, seed=2)
+    x = kv[:, :HD]
+    y, inv = hip.qk_norm_fwd(x, sv, H, D)
+    yr, ir = ref.qk_norm_fwd(x, sv, H, D)
+    close(y, yr, **tol(dtype, (1e-5, 1e-6), (1e-2, 1e-2))); close(inv, ir, rtol=1e-4, atol=1e-6)
+    dy = rnd(M, HD, dtype=dtype, seed=3)
+    dkv, dkvr = torch.zeros_like(kv), torch.zeros_like(kv)
+    ds, dsr = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    hip.qk_norm_bwd(dy, x, inv, sv, dkv[:, :HD], ds, H, D)
+    ref.qk_norm_bwd(dy, x, ir, sv, dkvr[:, :HD], dsr, H, D)
+    close(dkv, dkvr, **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2))); close(ds, dsr, rtol=1e-3, atol=1e-2)
+
+
+# ---------------------------------------------------------------- streaming kernels
+@pytest.mark.parametrize("dtype", DT)
+def test_geglu_gelu_leaky(hip, ref, dtype):
+    u, dg = rnd(100, 2 * 384, dtype=dtype, seed=1), rnd(100, 384, dtype=dtype, seed=2)
+    close(hip.geglu_fwd(u), ref.geglu_fwd(u), **tol(dtype, (1e-5, 1e-6), (2e-2, 2e-2)))
+    close(hip.geglu_bwd(dg, u), ref.geglu_bwd(dg, u), **tol(dtype, (1e-4, 1e-5), (2e-2, 2e-2)))
+    close(hip.gelu_fwd(u), ref.gelu_fwd(u), **tol(dtype, (1e-5, 1e-6), (2e-2, 2e-2)))
+    du = rnd(100, 768, dtype=dtype, seed=3)
+    close(hip.gelu_bwd(du, u), ref.gelu_bwd(du, u), **tol(dtype, (1e-4, 1e-5), (2e-2, 2e-2)))
+    x, dy = rnd(50, 77, seed=4), rnd(50, 77, seed=5)
+    close(hip.leaky_relu_fwd(x, 0.1), ref.leaky_relu_fwd(x, 0.1), rtol=0, atol=0)
+    close(hip.leaky_relu_bwd(dy, x, 0.1), ref.leaky_relu_bwd(dy, x, 0.1), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_colsum_permute_pool_convert(hip, ref, dtype):
+    x = rnd(1300, 776, dtype=dtype, seed=1)
+    out, outr = torch.ones(768, device=DEV), torch.ones(768, device=DEV)
+    hip.colsum(x, out, N=768); ref.colsum(x, outr, N=768)
+    close(out, outr, rtol=1e-3, atol=5e-2)
+    t4 = rnd(3, 5, 7, 64, dtype=dtype, seed=2)
+    close(hip.permute0213(t4), ref.permute0213(t4), rtol=0, atol=0)
+    t3 = rnd(3, 6, 256, dtype=dtype, seed=3)
+    close(hip.pool_fwd(t3), ref.pool_fwd(t3), **tol(dtype, (1e-5, 1e-6), (1e-2, 1e-2)))
+    close(hip.pool_bwd(t3[:, 0].contiguous(), 6), ref.pool_bwd(t3[:, 0].contiguous(), 6), **tol(dtype, (1e-6, 1e-7), (1e-2, 1e-2)))
+    w, cs = rnd(37, 50, seed=4), rnd(50, seed=5)
+    close(hip.convert_pad(w, 40, 64, dtype, colscale=cs), ref.convert_pad(w, 40, 64, dtype, colscale=cs), **tol(dtype, (1e-6, 1e-7), (1e-2, 1e-2)))
+
+
+def test_cpb_expand_reduce(hip, ref):
+    for gh, gw in [(4, 4), (3, 5), (24, 24)]:
+        ncls = (2 * gh - 1) * (2 * gw - 1)
+        tab = rnd(ncls, 8, seed=gh)
+        close(hip.cpb_expand(tab, gh, gw), ref.cpb_expand(tab, gh, gw), rtol=0, atol=0)
+        db = rnd(8, gh * gw, gh * gw, seed=gw)
+        close(hip.cpb_reduce(db, gh, gw), ref.cpb_reduce(db, gh, gw), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bert_embed(hip, ref, dtype):
+    V, T, Hd, Bz = 200, 16, 128, 3
+    word, pos, typ = rnd(V, Hd, seed=1), rnd(32, Hd, seed=2), rnd(2, Hd, seed=3)
+    ids = torch.randint(0, V, (Bz, T)).to(DEV)
+    close(hip.bert_embed_fwd(ids, word, pos, typ[0].contiguous(), dtype), ref.bert_embed_fwd(ids, word, pos, typ[0], dtype),
+          **tol(dtype, (1e-6, 1e-6), (1e-2, 1e-2)))
+    dx = rnd(Bz * T, Hd, dtype=dtype, seed=4)
+    outs = [torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)]
+    outr = [o.clone() for o in outs]
+    hip.bert_embed_bwd(ids, dx, *outs); ref.bert_embed_bwd(ids, dx, *outr)
+    for a, b in zip(outs, outr):
+        close(a, b, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vq_kernels(hip, ref, dtype):
+    C, d, M = 512, 128, 1000
+    embed = torch.nn.functional.normalize(rnd(C, d, seed=1), dim=-1)
+    idx = torch.randint(0, C // 2, (M,)).to(DEV)      # upper half of the codebook unused -> bins == 0 branch
+    xn = torch.nn.functional.normalize(rnd(M, d, seed=2), dim=-1).to(dtype)
+    close(hip.vq_gather(embed, idx, dtype), ref.vq_gather(embed, idx, dtype), **tol(dtype, (0, 0), (1e-2, 1e-2)))
+    bins, esum = hip.vq_ema(idx, xn, None, embed, 0.8)
+    br, er = ref.vq_ema(idx, xn, None, embed, 0.8)
+    close(bins, br, rtol=0, atol=0); close(esum, er, rtol=1e-4, atol=1e-4)
+    cl, em = torch.rand(C, device=DEV), embed.clone()
+    clr, emr = cl.clone(), em.clone()
+    hip.vq_ema_update(cl, em, bins, esum, 0.8); ref.vq_ema_update(clr, emr, br, er, 0.8)
+    close(cl, clr, rtol=1e-5, atol=1e-6); close(em, emr, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- CLIP head
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Bm,N,K", [(2, 64, 2048), (8, 512, 4096 + 1024), (11, 32, 1024)])
+def test_visual_latent(hip, ref, dtype, Bm, N, K):
+    x, w = rnd(Bm, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05)
+    close(hip.visual_latent_fwd(x, w), ref.visual_latent_fwd(x, w), **tol(dtype, (1e-4, 1e-3), (1e-2, 5e-2)))
+    dy = rnd(Bm, N, seed=3)
+    dw, dwr = torch.ones(N, K, device=DEV), torch.ones(N, K, device=DEV)
+    dx = hip.visual_latent_bwd(dy, x, w, dw, accumulate=True)
+    dxr = ref.visual_latent_bwd(dy, x, w, dwr, accumulate=True)
+    close(dx, dxr, **tol(dtype, (1e-4, 1e-4), (3e-2, 3e-2))); close(dw, dwr, rtol=1e-3, atol=1e-3)
+    dw2 = torch.full((N, K), 7.0, device=DEV)
+    hip.visual_latent_bwd(dy, x, w, dw2, accumulate=False, want_dx=False)
+    close(dw2, dwr - 1.0, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("G,Dl", [(2, 64), (8, 512), (64, 512), (3, 32)])
+def test_clip_loss(hip, ref, G, Dl):
+    tl, il = rnd(G, Dl, seed=1), rnd(G, Dl, seed=2)
+    temp = torch.tensor([1.0], device=DEV)
+    out, logits, dtl, dil, dtemp = hip.clip_loss(tl, il, temp, want_logits=True)
+    outr, lr, dtlr, dilr, dtr = ref.clip_loss(tl, il, temp, want_logits=True)
+    close(out, outr, rtol=1e-5, atol=1e-5); close(logits, lr, rtol=1e-4, atol=1e-5)
+    close(dtl, dtlr, rtol=1e-3, atol=1e-6); close(dil, dilr, rtol=1e-3, atol=1e-6); close(dtemp, dtr, rtol=1e-3, atol=1e-6)
+
+
+def test_grad_norm_and_adam(hip, ref):
+    n = 1_000_003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.01)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    for step in (1, 2, 3):
+        clip = hip.grad_norm_clip(g, 0.5)
+        clipr = ref.grad_norm_clip(g, 0.5)
+        close(clip, clipr, rtol=1e-5, atol=1e-7)
+        hip.adam_step(p, g, m, v, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clip)
+        ref.adam_step(pr, g, mr, vr, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clipr)
+    close(p, pr, rtol=1e-6, atol=1e-7); close(m, mr, rtol=1e-4, atol=1e-9); close(v, vr, rtol=1e-4, atol=1e-12)
