@@ -57,7 +57,24 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ base, int64_t l
       const int idx = t + NTHREADS * j, row = idx >> 3, chunk = idx & 7;
       const int64_t gr = row0 + row, gk = k0 + chunk * CE;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (gr < nrows && gk < kend) v = *reinterpret_cast<const u32x4*>(base + gr * ld + gk);
+      if (gr < nrows && gk < kend) {
+        if (gk + CE <= kend) {
+          v = *reinterpret_cast<const u32x4*>(base + gr * ld + gk);
+        } else {  // K tail inside a 16-byte chunk: element-wise, zero filled
+          const T* src = base + gr * ld + gk;
+          const int nrem = (int)(kend - gk);
+          if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = e < nrem ? __float_as_uint(reinterpret_cast<const float*>(src)[e]) : 0u;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t h = e < nrem ? (uint32_t)reinterpret_cast<const uint16_t*>(src)[e] : 0u;
+              v[e >> 1] |= h << ((e & 1) * 16);
+            }
+          }
+        }
+      }
       r[4 * j + 0] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
     }
   } else if constexpr (sizeof(T) == 4) {
@@ -291,8 +308,8 @@ int check_operands(const void* A, const void* B, int64_t lda, int64_t ldb, int64
   // non-k-contiguous bf16 operands are read as dwords (2 adjacent rows): the pitch must be even and cover the
   // row count rounded up to even (an odd last row reads one in-bounds element past it and discards the result)
   auto bad4 = [&](const void* ptr, int64_t ld, int64_t rows) { return ((uintptr_t)ptr % 4) != 0 || (es == 2 && ((ld % 2) || (ld < rows + (rows & 1)))); };
-  if (a_kc ? (bad16(A, lda) || (K % ce)) : bad4(A, lda, M)) { ctclip_set_error("gemm: A alignment (k-contiguous needs 16-B rows and K%chunk==0; else even lda/M)"); return CTCLIP_EBADARG; }
-  if (b_kc ? (bad16(B, ldb) || (K % ce)) : bad4(B, ldb, N)) { ctclip_set_error("gemm: B alignment"); return CTCLIP_EBADARG; }
+  if (a_kc ? bad16(A, lda) : bad4(A, lda, M)) { ctclip_set_error("gemm: A alignment (k-contiguous operands need 16-byte aligned rows; others an even pitch)"); return CTCLIP_EBADARG; }
+  if (b_kc ? bad16(B, ldb) : bad4(B, ldb, N)) { ctclip_set_error("gemm: B alignment (k-contiguous operands need 16-byte aligned rows; others an even pitch)"); return CTCLIP_EBADARG; }
   return CTCLIP_OK;
 }
 

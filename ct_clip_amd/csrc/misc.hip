@@ -98,6 +98,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   }
 }
 
+// generic fallback (any N / pitch): one thread per column, 64 rows per block row-lane
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ld) {
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  if (col >= N) return;
+  float acc = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * 1024;
+  for (int64_t r = r0 + rl; r < r0 + 1024 && r < M; r += 4) acc += Elem<T>::ld(x + r * ld + col);
+  atomicAdd(out + col, acc);
+}
+
 // ---- (A, B, C, D) -> (A, C, B, D)   (ctvit.py:297-305 rearranges between the spatial and temporal phases)
 template <typename T>
 __global__ void permute0213_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t A, int B, int C, int D) {
@@ -303,7 +314,12 @@ extern "C" int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx,
 }
 // out (f32, N) += column sums of x (M, N)
 extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, hipStream_t s) {
-  if (!x || !out || N % 8 || ld % 8) { ctclip_set_error("colsum: N and ld must be multiples of 8"); return CTCLIP_EBADARG; }
+  if (!x || !out) { ctclip_set_error("colsum: null argument"); return CTCLIP_EBADARG; }
+  if (N % 8 || ld % 8 || ((uintptr_t)x % 16)) {
+    dim3 gridg((unsigned)cdiv(M, 1024), (unsigned)cdiv(N, 64));
+    BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_generic_kernel<T>, gridg, dim3(256), 0, s, (const T*)x, out, M, N, ld));
+    return ctclip_check_launch("colsum");
+  }
   dim3 grid((unsigned)cdiv(M, 512), (unsigned)cdiv(N, 256));
   BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, out, M, N, ld));
   return ctclip_check_launch("colsum");

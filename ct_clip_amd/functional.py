@@ -118,7 +118,13 @@ class LinearFn(Function):
         dres = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
-        dyc = dy if dy.dtype == x.dtype else B().convert_pad(dy, dy.shape[0], dy.shape[1], x.dtype)
+        ce = 4 if x.dtype == torch.float32 else 8
+        nout = dy.shape[1]
+        if dy.dtype != x.dtype or nout % ce:
+            # (tiny layers only, e.g. the position-bias MLP's heads-wide output) 16-byte aligned rows for the kernels
+            dyc = B().convert_pad(dy, dy.shape[0], round_up(nout, 8), x.dtype)[:, :nout]
+        else:
+            dyc = dy
         dx = None
         if ctx.needs_input_grad[0]:
             dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)

@@ -116,6 +116,8 @@ def test_one_training_step_matches_oracle(golden, tmp_path):
             continue
         delta_ref = v - g["state_dict"][k]
         delta = sd[k].cpu() - g["state_dict"][k]
-        torch.testing.assert_close(delta, delta_ref, rtol=2e-2, atol=2e-2 * float(delta_ref.abs().max()) + 1e-9)
+        # gradients that are mathematically zero (a bias in front of a LayerNorm) are rounding noise ~1e-11; Adam turns noise/eps
+        # into updates of up to ~1e-2*lr, hence the absolute floor
+        torch.testing.assert_close(delta, delta_ref, rtol=2e-2, atol=2e-2 * float(delta_ref.abs().max()) + 2e-2 * lr)
         checked += 1
     assert checked > 40

@@ -51,10 +51,10 @@ def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512), (49, 64, 2)])
 def test_gemm_nn_grad_input(hip, ref, dtype, M, N, K):
-    # dx (M,N) = dy (M,K) @ W (K,N):  b is stored (K, N) and used with b_kc=False
-    dy, w = rnd(M, K, dtype=dtype, seed=5), rnd(K, N, dtype=dtype, seed=6)
+    # dx (M,N) = dy (M,K) @ W (K,N):  b is stored (K, N) and used with b_kc=False; K tails inside a 16-byte chunk are legal
+    dy, w = rnd(M, (K + 7) // 8 * 8, dtype=dtype, seed=5)[:, :K], rnd(K, N, dtype=dtype, seed=6)
     y = hip.gemm(dy, w, a_kc=True, b_kc=False)
     close(y, ref.gemm(dy, w, a_kc=True, b_kc=False), **tol(dtype, (1e-4, 1e-4 * K ** 0.5), (2e-2, 2e-2 * K ** 0.5)))
 
@@ -223,6 +223,9 @@ def test_colsum_permute_pool_convert(hip, ref, dtype):
     x = rnd(1300, 776, dtype=dtype, seed=1)
     out, outr = torch.ones(768, device=DEV), torch.ones(768, device=DEV)
     hip.colsum(x, out, N=768); ref.colsum(x, outr, N=768)
+    close(out, outr, rtol=1e-3, atol=5e-2)
+    out, outr = torch.ones(5, device=DEV), torch.ones(5, device=DEV)     # generic path (N not a multiple of 8)
+    hip.colsum(x[:, 3:], out, N=5); ref.colsum(x[:, 3:], outr, N=5)
     close(out, outr, rtol=1e-3, atol=5e-2)
     t4 = rnd(3, 5, 7, 64, dtype=dtype, seed=2)
     close(hip.permute0213(t4), ref.permute0213(t4), rtol=0, atol=0)
