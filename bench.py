@@ -1,0 +1,240 @@
+"""bench.py -- CT-CLIP training-step throughput on MI355X (BASELINE.json metric: CT volumes/s/node at 480x480x240, bs=8/GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one full optimisation step of the hot path (scripts/CTCLIPTrainer.py:233-264): text tower + image tower forward,
+gathered-negatives CLIP loss, backward, gradient all-reduce (N > 1), global grad-norm clip, Adam -- on synthetic inputs that are
+already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- the dominant kernel (bf16 MFMA GEMM, FeedForward in-projection shape): algorithmic FLOPs per launch / mean
+                  launch duration measured with events on the launch stream inside the timed steps, vs the 2.5 PFLOP/s dense peak.
+  cpu_baseline -- the CPU oracle (a restatement of the reference, kind "port") timed on the host cores on a bounded sample
+                  (one volume of the same configuration, one training step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FULL = dict(image=480, frames=240, patch=20, tpatch=10, dim=512, heads=8, dim_head=32, codebook=8192, dim_latent=512)
+
+
+def synth_text(B, T, gen, device, vocab=30522):
+    ids = torch.randint(1000, vocab, (B, T), generator=gen)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=gen)
+    ids[:, 0] = 101
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    for b in range(B):
+        ids[b, lens[b] - 1] = 102
+    ids = ids * mask
+    return ids.to(device), mask.long().to(device)
+
+
+class Text:
+    def __init__(self, ids, mask):
+        self.input_ids, self.attention_mask = ids, mask
+
+
+def build(args, device, dtype):
+    from transformers import BertConfig, BertModel
+    import ct_clip_amd
+    torch.manual_seed(0)
+    enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                            temporal_patch_size=FULL["tpatch"], spatial_depth=args.spatial_depth,
+                            temporal_depth=args.temporal_depth, dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=dtype)
+    bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))   # BERT-base, random init
+    hw = args.image // FULL["patch"]
+    clip = ct_clip_amd.CTCLIP(image_encoder=enc, text_encoder=bert, dim_text=768, dim_image=hw * hw * FULL["dim"],
+                              dim_latent=FULL["dim_latent"], compute_dtype=dtype)
+    # the two never-used *_extra projections (151 M parameters) stay on the host: they receive no gradient
+    clip.to(device)
+    trainer = ct_clip_amd.CTClipTrainer(clip, num_train_steps=10 ** 9, batch_size=args.batch, tokenizer=object(), lr=1.25e-6,
+                                        train_dataset=[0], evaluate=False, checkpoint=False, num_workers=0,
+                                        results_folder=os.path.join(ROOT, "gpurun_out", "bench_results"), sync_loss_every=0)
+    return clip, trainer
+
+
+def algorithmic_flops_per_volume(args, T):
+    """SURVEY.md section 8(d) accounting (2*M*N*K per GEMM, backward = 2x forward for differentiable GEMMs)."""
+    d, H = FULL["dim"], int(4 * (2 / 3) * FULL["dim"])
+    hw = args.image // FULL["patch"]
+    t = args.frames // FULL["tpatch"]
+    n = t * hw * hw
+    K = FULL["patch"] ** 2 * FULL["tpatch"]
+    inner = FULL["heads"] * FULL["dim_head"]
+    patch = 2 * n * K * d
+    proj = 2 * n * d * (inner + 2 * inner) + 2 * n * inner * d
+    ff = 2 * n * d * 2 * H + 2 * n * H * d
+    peg = 2 * 27 * n * d
+    attn_s = 4 * n * (hw * hw) * inner
+    attn_t = 4 * n * t * inner
+    layers = args.spatial_depth * (proj + ff + peg + attn_s) + args.temporal_depth * (proj + ff + peg + attn_t)
+    vq = 2 * n * FULL["codebook"] * d
+    vis = 2 * hw * hw * d * FULL["dim_latent"]
+    img_fwd = patch + layers + vq + vis
+    img_train = img_fwd + 2 * (patch + layers + vis)
+    hb, fb, Lb = 768, 3072, 12
+    bert_fwd = Lb * (2 * T * hb * 3 * hb + 4 * T * T * hb + 2 * T * hb * hb + 4 * T * hb * fb)
+    return img_train + 3 * bert_fwd, img_fwd + bert_fwd
+
+
+def cpu_baseline(args, T):
+    """Time the CPU oracle (oracle/ctclip_oracle.py, a restatement of the reference path) on ONE volume of the same configuration."""
+    from oracle import ctclip_oracle as O
+    from transformers import BertConfig, BertModel
+    import ct_clip_amd
+    torch.manual_seed(0)
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    sd_small = args.cpu_spatial_depth
+    enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                            temporal_patch_size=FULL["tpatch"], spatial_depth=sd_small, temporal_depth=args.cpu_temporal_depth,
+                            dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=torch.float32)
+    bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    hw = args.image // FULL["patch"]
+    sd = {"temperature": torch.tensor(1.0)}
+    sd.update({"visual_transformer." + k: v for k, v in enc.state_dict().items()})
+    sd.update({"text_transformer." + k: v for k, v in bert.state_dict().items()})
+    sd["to_text_latent.weight"] = torch.randn(FULL["dim_latent"], 768) * 0.02
+    sd["to_visual_latent.weight"] = torch.randn(FULL["dim_latent"], hw * hw * FULL["dim"]) * 0.002
+    cfg = O.OracleConfig(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                         temporal_patch_size=FULL["tpatch"], spatial_depth=sd_small, temporal_depth=args.cpu_temporal_depth,
+                         dim_head=FULL["dim_head"], heads=FULL["heads"], bert_layers=12, bert_heads=12, dim_latent=FULL["dim_latent"])
+    g = torch.Generator().manual_seed(1234)
+    nb = args.cpu_batch
+    video = torch.rand(nb, 1, args.frames, args.image, args.image, generator=g) * 2 - 1
+    ids, mask = synth_text(nb, T, g, "cpu")
+    t0 = time.time()
+    loss, *_ = O.train_step_reference(sd, cfg, ids, mask, video)
+    dt = time.time() - t0
+    layers_ratio = (args.spatial_depth + args.temporal_depth) / (sd_small + args.cpu_temporal_depth)
+    return dict(value=nb / dt, unit="volumes/s", cores=cores, kind="port",
+                sample=f"oracle/ctclip_oracle.train_step_reference (fwd+bwd+clip+Adam, f32), {nb} volume(s) {args.image}x{args.image}x{args.frames}, "
+                       f"{sd_small}+{args.cpu_temporal_depth} layers, T={T}, {dt:.1f} s wall; the benchmarked model has {layers_ratio:.1f}x the "
+                       f"transformer layers", loss=float(loss))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="volumes per GPU")
+    ap.add_argument("--text-len", type=int, default=128)
+    ap.add_argument("--spatial-depth", type=int, default=12, help="12+12 = the '24 layers' BASELINE.json names; reference scripts use 4+4")
+    ap.add_argument("--temporal-depth", type=int, default=12)
+    ap.add_argument("--image", type=int, default=FULL["image"])
+    ap.add_argument("--frames", type=int, default=FULL["frames"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-spatial-depth", type=int, default=1)
+    ap.add_argument("--cpu-temporal-depth", type=int, default=1)
+    ap.add_argument("--also-reference-depth", action="store_true", help="additionally time the reference-true 4+4-layer model")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    from ct_clip_amd import backend
+    be = backend.get()
+
+    def run_config(sdepth, tdepth, steps, warmup, profile_gemm):
+        args.spatial_depth, args.temporal_depth = sdepth, tdepth
+        clip, trainer = build(args, device, dtype)
+        clip.train()
+        g = torch.Generator().manual_seed(1234 + rank)
+        gd = torch.Generator(device=device).manual_seed(1234 + rank)
+        video = torch.rand(args.batch, 1, args.frames, args.image, args.image, generator=gd, device=device) * 2 - 1
+        ids, mask = synth_text(args.batch, args.text_len, g, device)
+        text = Text(ids, mask)
+
+        def step():
+            loss = trainer.forward_backward(video, text)
+            trainer.optim.step(trainer.max_grad_norm)
+            trainer.optim.zero_grad()
+            return loss
+
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile_gemm:
+            be.start_gemm_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing = be.stop_gemm_timing() if profile_gemm else None
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lossv = float(loss)
+        peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+        del clip, trainer, video
+        torch.cuda.empty_cache()
+        return float(t[0]), lossv, timing, peak_mem
+
+    dt, lossv, timing, peak_mem = run_config(args.spatial_depth, args.temporal_depth, args.steps, args.warmup, True)
+    sdepth, tdepth = args.spatial_depth, args.temporal_depth
+    ms = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+    train_flops, _ = algorithmic_flops_per_volume(args, args.text_len)
+
+    out = {
+        "metric": "CT volumes/sec/node (480x480x240, bs=8/GPU), full training step",
+        "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (uniform [-1,1] volumes generated on device, random token ids; random-init weights)",
+        "config": {"workload": f"CT-CLIP train step: CTViT {args.image}x{args.image}x{args.frames} patch 20x20x10 dim 512 "
+                               f"{sdepth}+{tdepth} layers + BERT-base T={args.text_len}, batch {args.batch}/GPU, global batch {world * args.batch}, "
+                               "gathered-negatives InfoNCE, grad clip 0.5, Adam",
+                   "global_batch": world * args.batch, "text_len": args.text_len, "parallelism": f"dp{world}",
+                   "layers": f"{sdepth}+{tdepth}"},
+        "loss": round(lossv, 5),
+        "model_tflops_per_step_per_gpu": round(train_flops * args.batch / 1e12, 2),
+        "model_tflops_per_s_per_gpu": round(train_flops * args.batch / 1e12 / (ms / 1e3), 1),
+        "mfma_fraction_whole_step": round(train_flops * args.batch / (ms / 1e3) / 2.5e15, 4),
+        "peak_mem_gib": round(peak_mem, 1),
+    }
+    if timing:
+        out["roofline"] = timing
+    if args.also_reference_depth:
+        dt2, loss2, _, _ = run_config(4, 4, args.steps, max(1, args.warmup), False)
+        out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps / dt2, 3), "unit": "volumes/s",
+                                      "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5)}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            args.spatial_depth, args.temporal_depth = sdepth, tdepth
+            out["cpu_baseline"] = cpu_baseline(args, args.text_len)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,34 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        self._gemm_events = None
+
+    # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
+    def start_gemm_timing(self):
+        """Record an event pair on the launch stream around every ctclip_gemm launch until stop_gemm_timing()."""
+        self._gemm_events = {}
+
+    def stop_gemm_timing(self, peak_tflops=2500.0):
+        ev, self._gemm_events = self._gemm_events, None
+        torch.cuda.synchronize()
+        groups = []
+        for key, pairs in ev.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            layout, dt, M, N, K = key
+            flops = 2.0 * M * N * K
+            groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}", launches=len(ms),
+                               avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops))
+        groups.sort(key=lambda g: -g["total_ms"])
+        top = groups[0]
+        ach = top["flops_per_launch"] / (top["avg_us"] * 1e-6) / 1e12
+        bf = "bf16" in top["kernel"]
+        peak = peak_tflops if bf else 157.3
+        return dict(bound="mfma", kernel=top["kernel"], achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
+                    frac=round(ach / peak, 4), traffic=None, launches=top["launches"], avg_us=round(top["avg_us"], 1),
+                    algorithmic_flops_per_launch=top["flops_per_launch"],
+                    gemm_total_ms=round(sum(g["total_ms"] for g in groups), 2),
+                    top5=[dict(kernel=g["kernel"], launches=g["launches"], avg_us=round(g["avg_us"], 1),
+                               tflops=round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)) for g in groups[:5]])
 
     # ------------------------------------------------------------------ helpers
     def workspace(self, device, nbytes):
@@ -69,10 +97,18 @@ class HipBackend:
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= N
         ldr = _rowmajor(residual, "gemm residual") if residual is not None else 0
+        timing = self._gemm_events
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = self.lib.ctclip_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr,
                                   int(a_kc), int(b_kc), dcode(a.dtype), dcode(out.dtype),
                                   dcode(residual.dtype) if residual is not None else 0, int(accumulate), int(split_k),
                                   float(alpha), _stream())
+        if timing is not None:
+            e1.record()
+            key = ("NT" if a_kc and b_kc else "NN" if a_kc else "TN", "bf16" if a.dtype == torch.bfloat16 else "f32", M, N, K)
+            timing.setdefault(key, []).append((e0, e1))
         _lib.check(rc, "ctclip_gemm")
         return out
 
