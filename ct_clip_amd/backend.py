@@ -221,11 +221,14 @@ class HipBackend:
     def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale):
         Lp = qt.shape[-1]
         delta = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device)
+        ws = None
+        if dbias is not None:
+            ws = self.workspace(q.device, self.lib.ctclip_attn_bwd_workspace(nseq, H, L))
         rc = self.lib.ctclip_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(o), _p(dout), _p(dot), _p(lse), _p(bias),
                                       _p(keymask), _p(delta), _p(dq), _p(dk), _p(dv), _p(dbias), nseq, H, L, Lp, D,
                                       _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(o, "o"),
                                       _rowmajor(dout, "dout"), _rowmajor(dq, "dq"), _rowmajor(dk, "dk"), _rowmajor(dv, "dv"),
-                                      float(scale), dcode(q.dtype), _stream())
+                                      float(scale), dcode(q.dtype), _p(ws), ws.numel() if ws is not None else 0, _stream())
         _lib.check(rc, "ctclip_attn_bwd")
 
     # ------------------------------------------------------------------ elementwise / streaming

@@ -262,6 +262,127 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   }
 }
 
+
+// dQ + dBias without atomics (used when a (H,L,L) bias gradient is requested, i.e. CTViT's spatial attention).
+// Block = 4 waves sharing ONE (query block, head); the block walks a strided subset of the sequences.  Within a sequence
+// wave w owns key tiles kb = w, w+4, ...: its dS tiles are accumulated over sequences in REGISTERS (dBias partial sums,
+// <= ATT_MAXT tiles), the four partial dQ tiles are combined through LDS.  Per-split partial dBias slabs are written
+// with plain stores and summed by dbias_reduce_kernel: deterministic, no global atomics.
+constexpr int ATT_MAXT = 5;   // key tiles per wave: L <= 4 * 5 * 32 = 640
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
+  __shared__ float red[4][D / 32][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qb = blockIdx.x, h = blockIdx.y, split = blockIdx.z;
+  const int L = p.L, Lp = p.Lp;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  const T* Kt = reinterpret_cast<const T*>(p.kt);
+  const T* dO = reinterpret_cast<const T*>(p.dout);
+  const int nkb = (L + 31) / 32;
+
+  float accb[ATT_MAXT][16];
+#pragma unroll
+  for (int t = 0; t < ATT_MAXT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[t][r] = 0.f;
+
+  for (int seq = split; seq < p.nseq; seq += nsplit) {
+    Frag<T, D> qf, dof;
+    float lse = 0.f, delta = 0.f;
+    if (qi < L) {
+      frag_load(qf, Q + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D);
+      frag_load(dof, dO + ((int64_t)seq * L + qi) * p.lddo + h * D, half, D);
+      lse = p.lse[((int64_t)seq * p.H + h) * L + qi];
+      delta = p.delta[((int64_t)seq * p.H + h) * L + qi];
+    } else { frag_zero(qf); frag_zero(dof); }
+    f32x16 dqacc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < ATT_MAXT; ++t) {
+      const int kb = wave + 4 * t;
+      if (kb < nkb) {
+        const int krow = kb * 32 + ar;
+        Frag<T, D> kf, vf;
+        if (krow < L) {
+          frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
+          frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
+        } else { frag_zero(kf); frag_zero(vf); }
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        s = mma(s, kf, qf);
+        dp = mma(dp, vf, dof);
+        float val[16], ds[16];
+        tile_logits<true>(val, s, p, seq, h, qi, kb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = kb * 32 + slot_index(r, half);
+          const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
+          ds[r] = pr * (dp[r] - delta);
+          accb[t][r] += ds[r];
+        }
+        Frag<T, 32> dsf;
+        frag_from_regs(dsf, ds);
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+          Frag<T, 32> ktf;
+          frag_load(ktf, Kt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
+          dqacc[i] = mma(dqacc[i], ktf, dsf);
+        }
+      }
+    }
+    // combine the four partial dQ tiles
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][i][r][lane] = dqacc[i][r];
+    __syncthreads();
+    if (wave < 2 * (D / 32) && qi < L) {
+      const int i = wave >> 1, g = wave & 1;
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * g + e;
+        o8[e] = (red[0][i][r][lane] + red[1][i][r][lane] + red[2][i][r][lane] + red[3][i][r][lane]) * p.scale;
+      }
+      T* dQ = reinterpret_cast<T*>(p.dq) + ((int64_t)seq * L + qi) * p.lddq + h * D;
+      store8(dQ + i * 32 + 16 * g + 8 * half, o8);
+    }
+    __syncthreads();
+  }
+  // partial dBias slab of this split
+  if (qi < L) {
+    float* dst = dbias_part + (((int64_t)split * p.H + h) * L + qi) * L;
+#pragma unroll
+    for (int t = 0; t < ATT_MAXT; ++t) {
+      const int kb = wave + 4 * t;
+      if (kb < nkb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = kb * 32 + slot_index(r, half);
+          if (kj < L) dst[kj] = accb[t][r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nsplit, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + i];
+    dbias[i] += t;
+  }
+}
+
 // dK, dV: one wave per 32-key block, loop over query tiles.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
@@ -573,13 +694,24 @@ extern "C" int ctclip_attn_fwd(const void* q, const void* k, const void* vt, con
   return dispatch_attn(0, p, D, dtype, stream);
 }
 
+static int dbias_nsplit(int nseq, int H, int L) {
+  const int blocks = ((L + 31) / 32) * H;
+  int ns = (1536 + blocks - 1) / blocks;
+  if (ns > nseq) ns = nseq;
+  if (ns > 16) ns = 16;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+// bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs)
+extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)dbias_nsplit(nseq, H, L) * H * L * L * 4; }
+
 // Backward.  Needs the transposed copies qt, kt (of q, k) and dot (of dout) and delta = rowsum(dO*O) (computed here
 // into `delta`, (nseq,H,L) f32 scratch).  dbias (H,L,L) f32 is ACCUMULATED with atomics when non-null.
 extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o,
                                const void* dout, const void* dot, const float* lse, const float* bias, const float* keymask,
                                float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk,
-                               int64_t lddv, float scale, int dtype, hipStream_t stream) {
+                               int64_t lddv, float scale, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!q || !k || !v || !qt || !kt || !o || !dout || !dot || !lse || !delta || !dq || !dk || !dv) { ctclip_set_error("attn_bwd: null arg"); return CTCLIP_EBADARG; }
   if (bad_ld(ldq) || bad_ld(ldk) || bad_ld(ldv) || bad_ld(ldo) || bad_ld(lddo) || bad_ld(lddq) || bad_ld(lddk) || bad_ld(lddv) || Lp % 8 || Lp < L) { ctclip_set_error("attn_bwd: strides must be multiples of 8"); return CTCLIP_EBADARG; }
   const int64_t M = (int64_t)nseq * L;
@@ -599,7 +731,25 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
   p.bias = bias; p.keymask = keymask; p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias;
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo;
   p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.scale = scale;
-  int rc = dispatch_attn(1, p, D, dtype, stream);
+  int rc;
+  if (dbias && D == 32 && (L + 31) / 32 <= 4 * ATT_MAXT) {
+    // deterministic dBias path: registers + per-split slabs, no atomics
+    const int ns = dbias_nsplit(nseq, H, L);
+    if (!workspace || workspace_bytes < ctclip_attn_bwd_workspace(nseq, H, L)) { ctclip_set_error("attn_bwd: workspace too small for the dBias slabs"); return CTCLIP_EWORKSPACE; }
+    p.dbias = nullptr;
+    dim3 grid((unsigned)((L + 31) / 32), H, ns);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((attn_bwd_dq_bias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, (float*)workspace, ns);
+    else if (dtype == DT_F32) hipLaunchKernelGGL((attn_bwd_dq_bias_kernel<float, 32>), grid, dim3(256), 0, stream, p, (float*)workspace, ns);
+    else return CTCLIP_EUNSUPPORTED;
+    rc = ctclip_check_launch("attn_bwd_dq_bias");
+    if (rc) return rc;
+    const int64_t n = (int64_t)H * L * L;
+    int64_t nb = cdiv(n, 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, dbias, ns, n);
+    rc = ctclip_check_launch("dbias_reduce");
+  } else {
+    rc = dispatch_attn(1, p, D, dtype, stream);   // dBias (if any) via f32 atomics
+  }
   if (rc) return rc;
   return dispatch_attn(2, p, D, dtype, stream);
 }
