@@ -101,10 +101,15 @@ class HipBackend:
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        ws, wsn = None, 0
+        if split_k != 1 and out.dtype == torch.float32:
+            wsn = self.lib.ctclip_gemm_workspace(M, N, K, dcode(a.dtype), int(split_k))
+            if wsn:
+                ws = self.workspace(a.device, wsn)
         rc = self.lib.ctclip_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr,
                                   int(a_kc), int(b_kc), dcode(a.dtype), dcode(out.dtype),
                                   dcode(residual.dtype) if residual is not None else 0, int(accumulate), int(split_k),
-                                  float(alpha), _stream())
+                                  float(alpha), _p(ws), ws.numel() if ws is not None else 0, _stream())
         if timing is not None:
             e1.record()
             key = ("NT" if a_kc and b_kc else "NN" if a_kc else "TN", "bf16" if a.dtype == torch.bfloat16 else "f32", M, N, K)

@@ -21,6 +21,11 @@
 // f32 uses 8 x mfma_f32_16x16x4f32 (exact f32 FMA chain -- the parity mode).
 #include "common.h"
 
+int ctclip_gemm256_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype,
+                       int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t ctclip_gemm256_workspace(int64_t M, int64_t N, int64_t K, int split_k);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
@@ -321,10 +326,15 @@ int check_operands(const void* A, const void* B, int64_t lda, int64_t ldb, int64
 extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M,
                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc,
                            int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha,
-                           hipStream_t stream) {
+                           void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   int rc = check_operands(A, B, lda, ldb, M, N, K, a_kc, b_kc, in_dtype);
   if (rc) return rc;
   if (!C) { ctclip_set_error("gemm: null C"); return CTCLIP_EBADARG; }
+  if (in_dtype == DT_BF16) {   // large-tile fast path (gemm256.hip) when the shape fills the chip
+    rc = ctclip_gemm256_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_kc, b_kc, out_dtype, res_dtype, accumulate,
+                            split_k, alpha, workspace, workspace_bytes, stream);
+    if (rc != 1) return rc;
+  }
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -332,6 +342,11 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   p.ntm = (int)cdiv(M, BM); p.ntn = (int)cdiv(N, BN);
   const int bk = in_dtype == DT_F32 ? 32 : 64;
   int64_t ktiles = cdiv(K, bk);
+  if (split_k <= 0) {   // auto: ~2 resident 128^2 blocks per CU
+    const int64_t tiles = (int64_t)p.ntm * p.ntn;
+    split_k = (out_dtype == DT_F32 && tiles < 256) ? (int)(512 / tiles) : 1;
+    if (split_k > ktiles / 4) split_k = (int)(ktiles / 4);
+  }
   if (split_k < 1) split_k = 1;
   if (split_k > ktiles) split_k = (int)ktiles;
   if (split_k > 1 && out_dtype != DT_F32) { ctclip_set_error("gemm: split-K needs f32 output"); return CTCLIP_EUNSUPPORTED; }
@@ -344,6 +359,11 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   dim3 grid(p.ntm * p.ntn, split_k);
   if (in_dtype == DT_F32) return launch_layout<float, EPI_STD>(p, a_kc, b_kc, grid, stream);
   return launch_layout<bf16_t, EPI_STD>(p, a_kc, b_kc, grid, stream);
+}
+
+// bytes of optional workspace for ctclip_gemm (split-K partial slabs of the large-tile bf16 path); split_k <= 0 means "auto"
+extern "C" int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k) {
+  return in_dtype == DT_BF16 ? ctclip_gemm256_workspace(M, N, K, split_k) : 0;
 }
 
 // Row-wise arg-max of A B^T without materialising the product (vector-quantiser code assignment:

@@ -84,7 +84,7 @@ def weight_grad(dy, x, weight, segments, K):
     dst2 = dst.view(weight.shape[0], -1)
     for (r0, n, c0) in segments:
         B().gemm(dy[:, c0:c0 + n], x[:, :K], a_kc=False, b_kc=False, out=dst2[r0:r0 + n, :K], accumulate=True,
-                 split_k=_split_k_for(n, K, dy.shape[0], dy.dtype), M=n, N=K, K=dy.shape[0])
+                 split_k=0, M=n, N=K, K=dy.shape[0])
     return None if sink is not None else dst
 
 
@@ -243,7 +243,7 @@ class PatchEmbedFn(Function):
         be.colsum(dz, dbp)
         G = torch.zeros((N, K), dtype=torch.float32, device=dz.device)
         be.gemm(dz, xhat[:, :K], a_kc=False, b_kc=False, out=G, accumulate=True,
-                split_k=_split_k_for(N, K, dz.shape[0], dz.dtype), M=N, N=K, K=dz.shape[0])
+                split_k=0, M=N, N=K, K=dz.shape[0])
         # parameter-space epilogue (N x K elementwise, tiny next to the token stream)
         Wd, g1d, b1d = W.detach(), g1.detach(), b1.detach()
         dW = G * g1d[None, :] + dbp[:, None] * b1d[None, :]

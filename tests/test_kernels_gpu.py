@@ -38,7 +38,8 @@ def close(a, b, **kw):
 
 # ---------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 72), (64, 2816, 512), (300, 512, 1408), (8, 8, 8)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 72), (64, 2816, 512), (300, 512, 1408), (8, 8, 8),
+                                   (4096, 2816, 256), (4000, 2900, 192)])   # the last two take the 256^2-tile path
 def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
     a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)   # asymmetric operands (transpose-detecting)
     bias, res = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
@@ -51,7 +52,7 @@ def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512), (49, 64, 2)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512), (49, 64, 2), (4096, 2560, 512), (4100, 2568, 448)])
 def test_gemm_nn_grad_input(hip, ref, dtype, M, N, K):
     # dx (M,N) = dy (M,K) @ W (K,N):  b is stored (K, N) and used with b_kc=False; K tails inside a 16-byte chunk are legal
     dy, w = rnd(M, (K + 7) // 8 * 8, dtype=dtype, seed=5)[:, :K], rnd(K, N, dtype=dtype, seed=6)
@@ -60,11 +61,12 @@ def test_gemm_nn_grad_input(hip, ref, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("T,N,K,split", [(512, 128, 256, 1), (1000, 70, 130, 4), (4096, 1365, 512, 8), (640, 512, 4000, 3)])
+@pytest.mark.parametrize("T,N,K,split", [(512, 128, 256, 1), (1000, 70, 130, 4), (4096, 1365, 512, 8), (640, 512, 4000, 3),
+                                         (8192, 1365, 512, 0), (16384, 512, 1365, 0), (8192, 256, 512, 0)])
 def test_gemm_tn_grad_weight_splitk_accumulate(hip, ref, dtype, T, N, K, split):
     # dW (N,K) += dy (T,N)^T @ x (T,K): both operands stored token-major, contraction over rows; odd N exercises pair loads
     Np = N + (N % 2) + 2
-    dyp, x = rnd(T, Np, dtype=dtype, seed=7), rnd(T, K + 8, dtype=dtype, seed=8)
+    dyp, x = rnd(T, Np, dtype=dtype, seed=7), rnd(T, (K + 7) // 8 * 8 + 8, dtype=dtype, seed=8)
     dy = dyp[:, :N]
     out = rnd(N, K, seed=9)
     out_ref = out.clone()
