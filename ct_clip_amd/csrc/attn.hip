@@ -37,22 +37,26 @@ __device__ __forceinline__ void frag_zero(Frag<float, KD>& f) {
 #pragma unroll
   for (int e = 0; e < KD / 2; ++e) f.v[e] = 0.f;
 }
-// p points at contraction index 0 of this lane's row; groups of 8 at 16g + 8*half; indices >= limit read as 0
+// p points at contraction index 0 of this lane's row; groups of 8 at 16g + 8*half.  Loads are UNCONDITIONAL (a branch
+// around a load makes hipcc serialise the round trips): groups at or past `limit` (a multiple of 8, >= 8) are clamped to the
+// last valid group.  Every caller multiplies such slots by an exact zero (masked probability / dS) or never stores them, and
+// the clamped data is real, finite tensor data.
 template <int KD>
 __device__ __forceinline__ void frag_load(Frag<bf16_t, KD>& f, const bf16_t* p, int half, int limit) {
 #pragma unroll
   for (int g = 0; g < KD / 16; ++g) {
-    const int off = 16 * g + 8 * half;
-    f.v[g] = off < limit ? *reinterpret_cast<const bf16x8*>(p + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    int off = 16 * g + 8 * half;
+    off = off < limit ? off : limit - 8;
+    f.v[g] = *reinterpret_cast<const bf16x8*>(p + off);
   }
 }
 template <int KD>
 __device__ __forceinline__ void frag_load(Frag<float, KD>& f, const float* p, int half, int limit) {
 #pragma unroll
   for (int g = 0; g < KD / 16; ++g) {
-    const int off = 16 * g + 8 * half;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    if (off < limit) { a = *reinterpret_cast<const f32x4*>(p + off); b = *reinterpret_cast<const f32x4*>(p + off + 4); }
+    int off = 16 * g + 8 * half;
+    off = off < limit ? off : limit - 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + off), b = *reinterpret_cast<const f32x4*>(p + off + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f.v[8 * g + e] = a[e]; f.v[8 * g + 4 + e] = b[e]; }
   }
@@ -99,18 +103,44 @@ __device__ __forceinline__ void tile_logits(float (&val)[16], const f32x16& s, c
                                             int row_base, int half) {
   // ROWS_ARE_KEYS: column = query (col_idx), rows = keys.  else: column = key, rows = queries.
   const int L = p.L;
+  float add[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) add[r] = 0.f;
+  if (p.bias) {   // wave-uniform branch; the loads inside are unconditional (indices clamped)
+    if (ROWS_ARE_KEYS && (L & 7) == 0) {
+      const int qc = col_idx < L ? col_idx : L - 1;
+      const float* brow = p.bias + ((int64_t)h * L + qc) * L;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int k0 = row_base + 16 * g + 8 * half;
+        k0 = k0 < L ? k0 : L - 8;               // runs are 8-aligned: wholly valid or wholly past L (masked below)
+        const f32x4 a = *reinterpret_cast<const f32x4*>(brow + k0), b = *reinterpret_cast<const f32x4*>(brow + k0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { add[8 * g + e] = a[e]; add[8 * g + 4 + e] = b[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = row_base + slot_index(r, half);
+        int qi = ROWS_ARE_KEYS ? col_idx : ri, kj = ROWS_ARE_KEYS ? ri : col_idx;
+        qi = qi < L ? qi : L - 1; kj = kj < L ? kj : L - 1;
+        add[r] = p.bias[((int64_t)h * L + qi) * L + kj];
+      }
+    }
+  }
+  if (p.keymask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int kj = ROWS_ARE_KEYS ? row_base + slot_index(r, half) : col_idx;
+      kj = kj < L ? kj : L - 1;
+      add[r] += p.keymask[(int64_t)seq * L + kj];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ri = row_base + slot_index(r, half);
     const int qi = ROWS_ARE_KEYS ? col_idx : ri, kj = ROWS_ARE_KEYS ? ri : col_idx;
-    float t = s[r] * p.scale;
-    if (qi < L && kj < L) {
-      if (p.bias) t += p.bias[((int64_t)h * L + qi) * L + kj];
-      if (p.keymask) t += p.keymask[(int64_t)seq * L + kj];
-    } else {
-      t = -INFINITY;
-    }
-    val[r] = t;
+    val[r] = (qi < L && kj < L) ? s[r] * p.scale + add[r] : -INFINITY;
   }
 }
 
@@ -126,8 +156,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* Vt = reinterpret_cast<const T*>(p.vt);
 
+  const int qic = qi < L ? qi : L - 1;   // clamped: loads stay unconditional, invalid lanes are never stored
   Frag<T, D> qf;
-  if (qi < L) frag_load(qf, Q + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D); else frag_zero(qf);
+  frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
 
   float m = -INFINITY, lsum = 0.f;
   f32x16 oacc[D / 32];
@@ -138,9 +169,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
   const int nkb = (L + 31) / 32;
   for (int kb = 0; kb < nkb; ++kb) {
-    const int krow = kb * 32 + ar;
+    int krow = kb * 32 + ar;
+    krow = krow < L ? krow : L - 1;       // keys past L are masked to -inf in tile_logits
     Frag<T, D> kf;
-    if (krow < L) frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D); else frag_zero(kf);
+    frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -202,14 +234,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const T* Kt = reinterpret_cast<const T*>(p.kt);
   const T* dO = reinterpret_cast<const T*>(p.dout);
 
+  const int qic = qi < L ? qi : L - 1;
   Frag<T, D> qf, dof;
-  float lse = 0.f, delta = 0.f;
-  if (qi < L) {
-    frag_load(qf, Q + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D);
-    frag_load(dof, dO + ((int64_t)seq * L + qi) * p.lddo + h * D, half, D);
-    lse = p.lse[((int64_t)seq * p.H + h) * L + qi];
-    delta = p.delta[((int64_t)seq * p.H + h) * L + qi];
-  } else { frag_zero(qf); frag_zero(dof); }
+  frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
+  frag_load(dof, dO + ((int64_t)seq * L + qic) * p.lddo + h * D, half, D);
+  const float lse = p.lse[((int64_t)seq * p.H + h) * L + qic];
+  const float delta = p.delta[((int64_t)seq * p.H + h) * L + qic];
 
   f32x16 dqacc[D / 32];
 #pragma unroll
@@ -219,12 +249,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
   const int nkb = (L + 31) / 32;
   for (int kb = 0; kb < nkb; ++kb) {
-    const int krow = kb * 32 + ar;
+    int krow = kb * 32 + ar;
+    krow = krow < L ? krow : L - 1;
     Frag<T, D> kf, vf;
-    if (krow < L) {
-      frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
-      frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
-    } else { frag_zero(kf); frag_zero(vf); }
+    frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
+    frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -292,14 +321,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bias_kernel(AttnParams p, flo
     for (int r = 0; r < 16; ++r) accb[t][r] = 0.f;
 
   for (int seq = split; seq < p.nseq; seq += nsplit) {
+    const int qic = qi < L ? qi : L - 1;
     Frag<T, D> qf, dof;
-    float lse = 0.f, delta = 0.f;
-    if (qi < L) {
-      frag_load(qf, Q + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D);
-      frag_load(dof, dO + ((int64_t)seq * L + qi) * p.lddo + h * D, half, D);
-      lse = p.lse[((int64_t)seq * p.H + h) * L + qi];
-      delta = p.delta[((int64_t)seq * p.H + h) * L + qi];
-    } else { frag_zero(qf); frag_zero(dof); }
+    frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
+    frag_load(dof, dO + ((int64_t)seq * L + qic) * p.lddo + h * D, half, D);
+    const float lse = p.lse[((int64_t)seq * p.H + h) * L + qic];
+    const float delta = p.delta[((int64_t)seq * p.H + h) * L + qic];
     f32x16 dqacc[D / 32];
 #pragma unroll
     for (int i = 0; i < D / 32; ++i)
@@ -309,12 +336,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bias_kernel(AttnParams p, flo
     for (int t = 0; t < ATT_MAXT; ++t) {
       const int kb = wave + 4 * t;
       if (kb < nkb) {
-        const int krow = kb * 32 + ar;
+        int krow = kb * 32 + ar;
+        krow = krow < L ? krow : L - 1;
         Frag<T, D> kf, vf;
-        if (krow < L) {
-          frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
-          frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
-        } else { frag_zero(kf); frag_zero(vf); }
+        frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
+        frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -399,11 +425,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const T* dO = reinterpret_cast<const T*>(p.dout);
   const T* dOt = reinterpret_cast<const T*>(p.dot);
 
+  const int kjc = kj < L ? kj : L - 1;
   Frag<T, D> kf, vf;
-  if (kj < L) {
-    frag_load(kf, K + ((int64_t)seq * L + kj) * p.ldk + h * D, half, D);
-    frag_load(vf, V + ((int64_t)seq * L + kj) * p.ldv + h * D, half, D);
-  } else { frag_zero(kf); frag_zero(vf); }
+  frag_load(kf, K + ((int64_t)seq * L + kjc) * p.ldk + h * D, half, D);
+  frag_load(vf, V + ((int64_t)seq * L + kjc) * p.ldv + h * D, half, D);
 
   f32x16 dkacc[D / 32], dvacc[D / 32];
 #pragma unroll
@@ -414,12 +439,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int64_t statbase = ((int64_t)seq * p.H + h) * L;
   const int nqb = (L + 31) / 32;
   for (int qb = 0; qb < nqb; ++qb) {
-    const int qrow = qb * 32 + ar;
+    int qrow = qb * 32 + ar;
+    qrow = qrow < L ? qrow : L - 1;
     Frag<T, D> qf, dof;
-    if (qrow < L) {
-      frag_load(qf, Q + ((int64_t)seq * L + qrow) * p.ldq + h * D, half, D);
-      frag_load(dof, dO + ((int64_t)seq * L + qrow) * p.lddo + h * D, half, D);
-    } else { frag_zero(qf); frag_zero(dof); }
+    frag_load(qf, Q + ((int64_t)seq * L + qrow) * p.ldq + h * D, half, D);
+    frag_load(dof, dO + ((int64_t)seq * L + qrow) * p.lddo + h * D, half, D);
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -430,8 +454,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = qb * 32 + slot_index(r, half);
-      float lse = 0.f, delta = 0.f;
-      if (qi < L) { lse = p.lse[statbase + qi]; delta = p.delta[statbase + qi]; }
+      const int qc = qi < L ? qi : L - 1;
+      const float lse = p.lse[statbase + qc], delta = p.delta[statbase + qc];
       pr[r] = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
       ds[r] = pr[r] * (dp[r] - delta);
     }

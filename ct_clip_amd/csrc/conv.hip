@@ -30,21 +30,30 @@ __global__ __launch_bounds__(256) void peg_kernel(const T* __restrict__ x, const
   load8(x + pos * C + ch, xin);
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = xin[e] + ((dir > 0 && bias) ? bias[ch + e] : 0.f);
+  // all 27 neighbour loads are UNCONDITIONAL (coordinates clamped, out-of-range taps weighted by 0): branches around the
+  // loads would make the compiler wait for each one in turn.  Only the innermost 3 taps are unrolled: 27 loads in flight
+  // cost 216 VGPRs and the occupancy that hides the latency.
+#pragma unroll 1
   for (int d1 = 0; d1 < 3; ++d1) {
     const int aa = a + dir * (d1 - 2);
-    if (aa < 0 || aa >= D1) continue;
+    const bool ok1 = aa >= 0 && aa < D1;
+    const int aac = aa < 0 ? 0 : (aa >= D1 ? D1 - 1 : aa);
+#pragma unroll 1
     for (int d2 = 0; d2 < 3; ++d2) {
       const int b2 = bb + dir * (d2 - 1);
-      if (b2 < 0 || b2 >= D2) continue;
+      const bool ok2 = ok1 && b2 >= 0 && b2 < D2;
+      const int b2c = b2 < 0 ? 0 : (b2 >= D2 ? D2 - 1 : b2);
 #pragma unroll
       for (int d3 = 0; d3 < 3; ++d3) {
         const int g2 = g + dir * (d3 - 1);
-        if (g2 < 0 || g2 >= D3) continue;
+        const bool ok = ok2 && g2 >= 0 && g2 < D3;
+        const int g2c = g2 < 0 ? 0 : (g2 >= D3 ? D3 - 1 : g2);
         float v[8];
-        load8(x + ((((batch * D1 + aa) * D2 + b2) * D3) + g2) * C + ch, v);
+        load8(x + ((((batch * D1 + aac) * D2 + b2c) * D3) + g2c) * C + ch, v);
         const int tap = (d1 * 3 + d2) * 3 + d3;
+        const float m = ok ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += ws[tap][cg * 8 + e] * v[e];
+        for (int e = 0; e < 8; ++e) acc[e] += (ws[tap][cg * 8 + e] * m) * v[e];
       }
     }
   }
@@ -79,19 +88,23 @@ __global__ __launch_bounds__(256) void peg_wgrad_kernel(const T* __restrict__ dy
         for (int e = 0; e < 8; ++e) accb[e] += gy[e];
       }
       const int aa = a + d1 - 2;
-      if (aa < 0) continue;
+      const bool ok1 = aa >= 0;
+      const int aac = aa < 0 ? 0 : aa;
 #pragma unroll
       for (int d2 = 0; d2 < 3; ++d2) {
         const int b2 = bb + d2 - 1;
-        if (b2 < 0 || b2 >= D2) continue;
+        const bool ok2 = ok1 && b2 >= 0 && b2 < D2;
+        const int b2c = b2 < 0 ? 0 : (b2 >= D2 ? D2 - 1 : b2);
 #pragma unroll
         for (int d3 = 0; d3 < 3; ++d3) {
           const int g2 = g + d3 - 1;
-          if (g2 < 0 || g2 >= D3) continue;
+          const bool ok = ok2 && g2 >= 0 && g2 < D3;
+          const int g2c = g2 < 0 ? 0 : (g2 >= D3 ? D3 - 1 : g2);
           float v[8];
-          load8(x + ((((batch * D1 + aa) * D2 + b2) * D3) + g2) * C + ch, v);
+          load8(x + ((((batch * D1 + aac) * D2 + b2c) * D3) + g2c) * C + ch, v);   // unconditional, masked below
+          const float m = ok ? 1.f : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[d2 * 3 + d3][e] += gy[e] * v[e];
+          for (int e = 0; e < 8; ++e) acc[d2 * 3 + d3][e] += (gy[e] * m) * v[e];
         }
       }
     }
