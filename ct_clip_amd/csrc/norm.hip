@@ -7,115 +7,105 @@ namespace {
 
 constexpr int LN_MAXV = 4;  // up to 64 lanes * 8 * 4 = 2048 columns per row
 
-template <typename T>
+// One wave64 per row, several rows per wave (grid-stride).  NV = ceil(cols / 512) is a compile-time constant so that the
+// row's loads are unconditional and issued together (columns past `cols` are clamped and masked).
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int64_t rows, int cols, float eps) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const T* xr = x + row * cols;
-  float v[LN_MAXV][8];
-  float s = 0.f;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int cc[NV]; bool ok[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 8;
-    if (c < cols) {
-      load8(xr + c, v[i]);
+  for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * 8; ok[i] = c < cols; cc[i] = ok[i] ? c : cols - 8; }
+  float gm[NV][8], bt[NV][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[i][e] = gamma ? gamma[cc[i] + e] : 1.f; bt[i][e] = beta ? beta[cc[i] + e] : 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const T* xr = x + row * cols;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) load8(xr + cc[i], v[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += ok[i] ? v[i][e] : 0.f;
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += ok[i] ? d * d : 0.f; }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
     }
-  }
-  const float mean = wave_sum(s) / cols;
-  float q = 0.f;
+    T* yr = y + row * cols;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 8;
-    if (c < cols) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / cols + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
-  }
-  T* yr = y + row * cols;
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 8;
-    if (c < cols) {
+    for (int i = 0; i < NV; ++i) {
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (v[i][e] - mean) * rstd;
-        if (gamma) t *= gamma[c + e];
-        if (beta) t += beta[c + e];
-        o[e] = t;
-      }
-      store8(yr + c, o);
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+      if (ok[i]) store8(yr + cc[i], o);
     }
   }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
 // Per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy are written to part[block][2][cols].
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[LN_MAXV][8], db[LN_MAXV][8];
+  int cc[NV]; bool ok[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * 8; ok[i] = c < cols; cc[i] = ok[i] ? c : cols - 8; }
+  float gm[NV][8], dg[NV][8], db[NV][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[i][e] = gamma ? gamma[cc[i] + e] : 1.f; dg[i][e] = 0.f; db[i][e] = 0.f; }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    float g[LN_MAXV][8], xh[LN_MAXV][8];
+    float a[NV][8], b[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { load8(dy + row * cols + cc[i], a[i]); load8(x + row * cols + cc[i], b[i]); }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < cols) {
-        float a[8], b[8];
-        load8(dy + row * cols + c, a);
-        load8(x + row * cols + c, b);
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (b[e] - mu) * rs;
-          g[i][e] = gamma ? a[e] * gamma[c + e] : a[e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
-          dg[i][e] += a[e] * xh[i][e];
-          db[i][e] += a[e];
-        }
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (b[i][e] - mu) * rs;
+        const float dyv = ok[i] ? a[i][e] : 0.f;
+        const float g = dyv * gm[i][e];
+        b[i][e] = xh; a[i][e] = g;
+        s1 += g; s2 += g * xh;
+        dg[i][e] += dyv * xh; db[i][e] += dyv;
       }
-    }
     s1 = wave_sum(s1) / cols;
     s2 = wave_sum(s2) / cols;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < cols) {
-        float o[8];
+    for (int i = 0; i < NV; ++i) {
+      float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
-        store8(dx + row * cols + c, o);
-      }
+      for (int e = 0; e < 8; ++e) o[e] = rs * (a[i][e] - s1 - b[i][e] * s2);
+      if (ok[i]) store8(dx + row * cols + cc[i], o);
     }
   }
   if (!part) return;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 8;
-    if (c < cols) {
+  for (int i = 0; i < NV; ++i) {
+    if (ok[i]) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { sm[(wave * 2 + 0) * cols + c + e] = dg[i][e]; sm[(wave * 2 + 1) * cols + c + e] = db[i][e]; }
+      for (int e = 0; e < 8; ++e) { sm[(wave * 2 + 0) * cols + cc[i] + e] = dg[i][e]; sm[(wave * 2 + 1) * cols + cc[i] + e] = db[i][e]; }
     }
   }
   __syncthreads();
@@ -127,17 +117,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] += sum_b part[b][which][c]
-__global__ void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                         int nblocks, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * cols) return;
-  const int which = c / cols, col = c % cols;
-  float* dst = which == 0 ? dgamma : dbeta;
-  if (!dst) return;
+// out[c] += sum_b part[b][which][c]; block = 64 columns x 4 partial-lanes
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int nblocks, int cols) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += part[((int64_t)b * 2 + which) * cols + col];
-  dst[col] += t;
+  if (c < 2 * cols) {
+    const int which = c / cols, col = c % cols;
+    for (int b = pl; b < nblocks; b += 4) t += part[((int64_t)b * 2 + which) * cols + col];
+  }
+  red[pl][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (pl == 0 && c < 2 * cols) {
+    const int which = c / cols, col = c % cols;
+    float* dst = which == 0 ? dgamma : dbeta;
+    if (dst) dst[col] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
 }
 
 // CTViT patch embedding front-end (ctvit.py:171-172): gather the (pt, p1, p2) patch of one token from the
@@ -235,34 +231,43 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const TI* __restrict__
 extern "C" int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                     int64_t rows, int cols, float eps, int dtype, hipStream_t stream) {
   if (!x || !y || rows <= 0 || cols <= 0 || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_fwd: cols must be a multiple of 8 and <= 2048"); return CTCLIP_EBADARG; }
-  dim3 grid((unsigned)cdiv(rows, 4));
-  if (dtype == DT_F32) hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps);
+  int64_t nb = cdiv(rows, 8); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+  dim3 grid((unsigned)nb);
+  const int nv = (cols + 511) / 512;
+#define LNF(T, NVV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NVV>), grid, dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, cols, eps)
+#define LNF_NV(T) do { if (nv == 1) LNF(T, 1); else if (nv == 2) LNF(T, 2); else if (nv == 3) LNF(T, 3); else LNF(T, 4); } while (0)
+  if (dtype == DT_F32) LNF_NV(float);
+  else if (dtype == DT_BF16) LNF_NV(bf16_t);
   else return CTCLIP_EUNSUPPORTED;
+#undef LNF
+#undef LNF_NV
   return ctclip_check_launch("layernorm_fwd");
 }
 
-extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) {
-  int64_t nb = cdiv(rows, 4); if (nb > 512) nb = 512;
-  return nb * 2 * cols * 4;
-}
+static int64_t ln_bwd_blocks(int64_t rows) { int64_t nb = cdiv(rows, 8); if (nb > 1024) nb = 1024; return nb < 1 ? 1 : nb; }
+extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) { return ln_bwd_blocks(rows) * 2 * cols * 4; }
 
 // LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
 extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                     void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype, void* workspace,
                                     int64_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !dx || !mean || !rstd || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_bwd: bad args"); return CTCLIP_EBADARG; }
-  int64_t nb = cdiv(rows, 4); if (nb > 512) nb = 512;
+  const int64_t nb = ln_bwd_blocks(rows);
   const bool want = dgamma || dbeta;
   if (want && (!workspace || workspace_bytes < ctclip_layernorm_bwd_workspace(rows, cols))) { ctclip_set_error("layernorm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
   float* part = want ? (float*)workspace : nullptr;
   const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
-  if (dtype == DT_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), shm, stream, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, part, rows, cols);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), shm, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, part, rows, cols);
+  const int nv = (cols + 511) / 512;
+#define LNB(T, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols)
+#define LNB_NV(T) do { if (nv == 1) LNB(T, 1); else if (nv == 2) LNB(T, 2); else if (nv == 3) LNB(T, 3); else LNB(T, 4); } while (0)
+  if (dtype == DT_F32) LNB_NV(float);
+  else if (dtype == DT_BF16) LNB_NV(bf16_t);
   else return CTCLIP_EUNSUPPORTED;
+#undef LNB
+#undef LNB_NV
   int rc = ctclip_check_launch("layernorm_bwd");
   if (rc || !want) return rc;
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 256)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
   return ctclip_check_launch("ln_partial_reduce");
 }
 
