@@ -104,6 +104,8 @@ class CTCLIP(nn.Module):
             tl, il = Fn.l2norm_f32(text_lat), Fn.l2norm_f32(image_lat)
             return (tl * il).sum(-1) * self.temperature.exp()
         assert Bt == Bi, "contrastive loss needs as many texts as volumes"
+        replicas = 1
         if self.gather_negatives and _dist.world_size() > 1:
             text_lat, image_lat = _dist.all_gather_latents(text_lat, image_lat)
-        return Fn.ClipLossFn.apply(text_lat, image_lat, self.temperature)
+            replicas = _dist.world_size()
+        return Fn.ClipLossFn.apply(text_lat, image_lat, self.temperature, replicas)

@@ -486,10 +486,14 @@ class ClipLossFn(Function):
     """ct_clip.py:771,796,845-901: l2norm, logits * exp(temperature), symmetric InfoNCE.  Forward and backward in one launch."""
 
     @staticmethod
-    def forward(ctx, tl, il, temperature):
+    def forward(ctx, tl, il, temperature, replicas=1):
+        """replicas: number of data-parallel ranks that evaluate this SAME (gathered) loss.  The latent gradients reach the
+        parameters through each rank's local slice only, but the temperature gradient is complete on every rank: it is
+        divided by `replicas` so that the all-reduce(SUM) of parameter gradients yields it once."""
         out, _, dtl, dil, dtemp = B().clip_loss(tl.contiguous(), il.contiguous(), temperature.detach().reshape(1))
         ctx.save_for_backward(dtl, dil, dtemp)
         ctx.temperature = temperature
+        ctx.replicas = replicas
         return out[0]
 
     @staticmethod
@@ -499,13 +503,13 @@ class ClipLossFn(Function):
         s = dloss.reshape(1).to(torch.float32).contiguous()
         be.scale_by_scalar(dtl, s)
         be.scale_by_scalar(dil, s)
-        be.scale_by_scalar(dtemp, s)
+        be.scale_by_scalar(dtemp, s / ctx.replicas if ctx.replicas != 1 else s)
         t = ctx.temperature
         sink = sink_of(t)
         if sink is not None:
             sink.add_(dtemp.view_as(sink))
-            return dtl, dil, None
-        return dtl, dil, dtemp.view_as(t)
+            return dtl, dil, None, None
+        return dtl, dil, dtemp.view_as(t), None
 
 
 class BertEmbedFn(Function):
