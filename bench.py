@@ -94,8 +94,8 @@ def cpu_baseline(args, T):
     from transformers import BertConfig, BertModel
     import ct_clip_amd
     torch.manual_seed(0)
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
+    cores = min(args.cpu_threads, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+    torch.set_num_threads(cores)     # more threads than ~32 only adds synchronisation overhead to torch's CPU kernels
     sd_small = args.cpu_spatial_depth
     enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
                             temporal_patch_size=FULL["tpatch"], spatial_depth=sd_small, temporal_depth=args.cpu_temporal_depth,
@@ -130,6 +130,30 @@ def cpu_baseline(args, T):
                              "FLOPs per volume; value_scaled_to_bench_config divides the measured rate by that ratio")
 
 
+def run_cpu_baseline_bounded(args, sdepth, tdepth):
+    """The oracle runs in a child process with a wall-clock bound so that the default bench always finishes in minutes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--spatial-depth", str(sdepth), "--temporal-depth", str(tdepth),
+           "--cpu-spatial-depth", str(args.cpu_spatial_depth), "--cpu-temporal-depth", str(args.cpu_temporal_depth),
+           "--cpu-batch", str(args.cpu_batch), "--cpu-threads", str(args.cpu_threads), "--text-len", str(args.text_len),
+           "--image", str(args.image), "--frames", str(args.frames)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        for line in res.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return dict(value=None, unit="volumes/s", kind="port", sample="CPU baseline failed: " + res.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        dt = time.time() - t0
+        return dict(value=None, unit="volumes/s", kind="port", cores=args.cpu_threads, upper_bound=round(args.cpu_batch / dt, 5),
+                    sample=f"oracle train step on {args.cpu_batch} volume(s), {args.cpu_spatial_depth}+{args.cpu_temporal_depth} layers did not finish "
+                           f"within the {args.cpu_timeout:.0f} s bound: rate < upper_bound")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,8 +170,15 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-spatial-depth", type=int, default=4, help="the CPU sample uses the reference's own 4+4 layers to stay bounded")
     ap.add_argument("--cpu-temporal-depth", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-timeout", type=float, default=150.0, help="wall-clock bound (s) for the CPU baseline subprocess")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help="additionally time the reference-true 4+4-layer model")
     args = ap.parse_args()
+
+    if args.cpu_baseline_worker:      # child process: time the oracle and print its JSON
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args, args.text_len)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -234,8 +265,7 @@ def main():
                                       "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            args.spatial_depth, args.temporal_depth = sdepth, tdepth
-            out["cpu_baseline"] = cpu_baseline(args, args.text_len)
+            out["cpu_baseline"] = run_cpu_baseline_bounded(args, sdepth, tdepth)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
