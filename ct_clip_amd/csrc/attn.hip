@@ -168,11 +168,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
 
   const int nkb = (L + 31) / 32;
-  for (int kb = 0; kb < nkb; ++kb) {
+  // register double-buffering: the next tile's K and V^T fragments are in flight while the current tile is computed
+  auto load_k = [&](int kb, Frag<T, D>& kf) {
     int krow = kb * 32 + ar;
     krow = krow < L ? krow : L - 1;       // keys past L are masked to -inf in tile_logits
-    Frag<T, D> kf;
     frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
+  };
+  auto load_v = [&](int kb, Frag<T, 32> (&vf)[D / 32]) {
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+      frag_load(vf[i], Vt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
+  };
+  Frag<T, D> kf;
+  Frag<T, 32> vf[D / 32];
+  load_k(0, kf);
+  load_v(0, vf);
+  for (int kb = 0; kb < nkb; ++kb) {
+    Frag<T, D> kn;
+    Frag<T, 32> vn[D / 32];
+    const int kbn = kb + 1 < nkb ? kb + 1 : kb;
+    load_k(kbn, kn);
+    load_v(kbn, vn);
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -197,10 +213,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < D / 32; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      Frag<T, 32> vf;
-      frag_load(vf, Vt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
-      oacc[i] = mma(oacc[i], vf, pf);
+      oacc[i] = mma(oacc[i], vf[i], pf);
     }
+    kf = kn;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) vf[i] = vn[i];
   }
   const float l = lsum + __shfl_xor(lsum, 32, 64);
   if (qi < L) {
@@ -248,12 +265,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
   const int nkb = (L + 31) / 32;
-  for (int kb = 0; kb < nkb; ++kb) {
+  auto load = [&](int kb, Frag<T, D>& kf, Frag<T, D>& vf, Frag<T, 32> (&ktf)[D / 32]) {
     int krow = kb * 32 + ar;
     krow = krow < L ? krow : L - 1;
-    Frag<T, D> kf, vf;
     frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
     frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+      frag_load(ktf[i], Kt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
+  };
+  Frag<T, D> kf, vf;
+  Frag<T, 32> ktf[D / 32];
+  load(0, kf, vf, ktf);
+  for (int kb = 0; kb < nkb; ++kb) {
+    Frag<T, D> kn, vn;
+    Frag<T, 32> ktn[D / 32];
+    load(kb + 1 < nkb ? kb + 1 : kb, kn, vn, ktn);   // next key tile in flight under this tile's math
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -271,11 +298,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     Frag<T, 32> dsf;
     frag_from_regs(dsf, ds);
 #pragma unroll
-    for (int i = 0; i < D / 32; ++i) {
-      Frag<T, 32> ktf;
-      frag_load(ktf, Kt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
-      dqacc[i] = mma(dqacc[i], ktf, dsf);
-    }
+    for (int i = 0; i < D / 32; ++i) dqacc[i] = mma(dqacc[i], ktf[i], dsf);
+    kf = kn; vf = vn;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) ktf[i] = ktn[i];
   }
   if (qi < L) {
     T* dQ = reinterpret_cast<T*>(p.dq) + ((int64_t)seq * L + qi) * p.lddq + h * D;
@@ -291,112 +317,80 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   }
 }
 
-
-// dQ + dBias without atomics (used when a (H,L,L) bias gradient is requested, i.e. CTViT's spatial attention).
-// Block = 4 waves sharing ONE (query block, head); the block walks a strided subset of the sequences.  Within a sequence
-// wave w owns key tiles kb = w, w+4, ...: its dS tiles are accumulated over sequences in REGISTERS (dBias partial sums,
-// <= ATT_MAXT tiles), the four partial dQ tiles are combined through LDS.  Per-split partial dBias slabs are written
-// with plain stores and summed by dbias_reduce_kernel: deterministic, no global atomics.
-constexpr int ATT_MAXT = 5;   // key tiles per wave: L <= 4 * 5 * 32 = 640
-
+// dBias without atomics: one wave owns ONE (query tile, key tile) pair of one head and walks a strided subset of the
+// sequences, recomputing S and dP and accumulating dS in 16 registers; the bias tile is loop invariant (registers).
+// Per-split partial slabs are written with plain stores and summed by dbias_reduce_kernel (deterministic).  The first
+// version of this path used f32 atomics from the dQ kernel: 510 M atomics per layer cost 11 ms.
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
-  __shared__ float red[4][D / 32][16][64];
+__global__ __launch_bounds__(256) void attn_bwd_dbias_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qb = blockIdx.x, h = blockIdx.y, split = blockIdx.z;
-  const int L = p.L, Lp = p.Lp;
+  const int L = p.L;
+  const int nkb = (L + 31) / 32;
+  const int pair = blockIdx.x * 4 + wave, h = blockIdx.y, split = blockIdx.z;
+  if (pair >= nkb * nkb) return;
+  const int qb = pair / nkb, kb = pair % nkb;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
+  const int qic = qi < L ? qi : L - 1;
+  int krow = kb * 32 + ar;
+  krow = krow < L ? krow : L - 1;
   const T* Q = reinterpret_cast<const T*>(p.q);
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* V = reinterpret_cast<const T*>(p.v);
-  const T* Kt = reinterpret_cast<const T*>(p.kt);
   const T* dO = reinterpret_cast<const T*>(p.dout);
-  const int nkb = (L + 31) / 32;
 
-  float accb[ATT_MAXT][16];
+  // loop-invariant additive logits (bias tile) and validity
+  float add[16];
+  bool ok[16];
 #pragma unroll
-  for (int t = 0; t < ATT_MAXT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[t][r] = 0.f;
-
-  for (int seq = split; seq < p.nseq; seq += nsplit) {
-    const int qic = qi < L ? qi : L - 1;
-    Frag<T, D> qf, dof;
-    frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
-    frag_load(dof, dO + ((int64_t)seq * L + qic) * p.lddo + h * D, half, D);
-    const float lse = p.lse[((int64_t)seq * p.H + h) * L + qic];
-    const float delta = p.delta[((int64_t)seq * p.H + h) * L + qic];
-    f32x16 dqacc[D / 32];
-#pragma unroll
-    for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < ATT_MAXT; ++t) {
-      const int kb = wave + 4 * t;
-      if (kb < nkb) {
-        int krow = kb * 32 + ar;
-        krow = krow < L ? krow : L - 1;
-        Frag<T, D> kf, vf;
-        frag_load(kf, K + ((int64_t)seq * L + krow) * p.ldk + h * D, half, D);
-        frag_load(vf, V + ((int64_t)seq * L + krow) * p.ldv + h * D, half, D);
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        s = mma(s, kf, qf);
-        dp = mma(dp, vf, dof);
-        float val[16], ds[16];
-        tile_logits<true>(val, s, p, seq, h, qi, kb * 32, half);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kj = kb * 32 + slot_index(r, half);
-          const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
-          ds[r] = pr * (dp[r] - delta);
-          accb[t][r] += ds[r];
-        }
-        Frag<T, 32> dsf;
-        frag_from_regs(dsf, ds);
-#pragma unroll
-        for (int i = 0; i < D / 32; ++i) {
-          Frag<T, 32> ktf;
-          frag_load(ktf, Kt + (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + kb * 32, half, Lp - kb * 32);
-          dqacc[i] = mma(dqacc[i], ktf, dsf);
-        }
-      }
-    }
-    // combine the four partial dQ tiles
-#pragma unroll
-    for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave][i][r][lane] = dqacc[i][r];
-    __syncthreads();
-    if (wave < 2 * (D / 32) && qi < L) {
-      const int i = wave >> 1, g = wave & 1;
-      float o8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int r = 8 * g + e;
-        o8[e] = (red[0][i][r][lane] + red[1][i][r][lane] + red[2][i][r][lane] + red[3][i][r][lane]) * p.scale;
-      }
-      T* dQ = reinterpret_cast<T*>(p.dq) + ((int64_t)seq * L + qi) * p.lddq + h * D;
-      store8(dQ + i * 32 + 16 * g + 8 * half, o8);
-    }
-    __syncthreads();
+  for (int r = 0; r < 16; ++r) {
+    const int kj = kb * 32 + slot_index(r, half);
+    ok[r] = qi < L && kj < L;
+    const int kc = kj < L ? kj : L - 1;
+    add[r] = p.bias ? p.bias[((int64_t)h * L + qic) * L + kc] : 0.f;
   }
-  // partial dBias slab of this split
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  auto load = [&](int seq, Frag<T, D>& qf, Frag<T, D>& dof, Frag<T, D>& kf, Frag<T, D>& vf, float& lse, float& delta) {
+    const int64_t srow = (int64_t)seq * L;
+    frag_load(qf, Q + (srow + qic) * p.ldq + h * D, half, D);
+    frag_load(dof, dO + (srow + qic) * p.lddo + h * D, half, D);
+    frag_load(kf, K + (srow + krow) * p.ldk + h * D, half, D);
+    frag_load(vf, V + (srow + krow) * p.ldv + h * D, half, D);
+    lse = p.lse[((int64_t)seq * p.H + h) * L + qic];
+    delta = p.delta[((int64_t)seq * p.H + h) * L + qic];
+  };
+  Frag<T, D> qf, dof, kf, vf;
+  float lse, delta;
+  int seq = split;
+  if (seq < p.nseq) load(seq, qf, dof, kf, vf, lse, delta);
+  for (; seq < p.nseq; seq += nsplit) {
+    Frag<T, D> qn, don, kn, vn;
+    float lsen, deltan;
+    const int sn = seq + nsplit < p.nseq ? seq + nsplit : seq;
+    load(sn, qn, don, kn, vn, lsen, deltan);     // next sequence in flight
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, kf, qf);
+    dp = mma(dp, vf, dof);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float t = s[r] * p.scale + add[r];
+      if (p.keymask) { const int kj = kb * 32 + slot_index(r, half); t += p.keymask[(int64_t)seq * L + (kj < L ? kj : L - 1)]; }
+      const float pr = ok[r] ? __expf(t - lse) : 0.f;
+      acc[r] += pr * (dp[r] - delta);
+    }
+    qf = qn; dof = don; kf = kn; vf = vn; lse = lsen; delta = deltan;
+  }
   if (qi < L) {
     float* dst = dbias_part + (((int64_t)split * p.H + h) * L + qi) * L;
 #pragma unroll
-    for (int t = 0; t < ATT_MAXT; ++t) {
-      const int kb = wave + 4 * t;
-      if (kb < nkb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kj = kb * 32 + slot_index(r, half);
-          if (kj < L) dst[kj] = accb[t][r];
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int kj = kb * 32 + slot_index(r, half);
+      if (kj < L) dst[kj] = acc[r];
     }
   }
 }
@@ -438,12 +432,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 
   const int64_t statbase = ((int64_t)seq * p.H + h) * L;
   const int nqb = (L + 31) / 32;
-  for (int qb = 0; qb < nqb; ++qb) {
+  auto load_q = [&](int qb, Frag<T, D>& qf, Frag<T, D>& dof, Frag<T, 32> (&dotf)[D / 32], Frag<T, 32> (&qtf)[D / 32]) {
     int qrow = qb * 32 + ar;
     qrow = qrow < L ? qrow : L - 1;
-    Frag<T, D> qf, dof;
     frag_load(qf, Q + ((int64_t)seq * L + qrow) * p.ldq + h * D, half, D);
     frag_load(dof, dO + ((int64_t)seq * L + qrow) * p.lddo + h * D, half, D);
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) {
+      const int64_t trow = (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + qb * 32;
+      frag_load(dotf[i], dOt + trow, half, Lp - qb * 32);
+      frag_load(qtf[i], Qt + trow, half, Lp - qb * 32);
+    }
+  };
+  Frag<T, D> qf, dof;
+  Frag<T, 32> dotf[D / 32], qtf[D / 32];
+  load_q(0, qf, dof, dotf, qtf);
+  for (int qb = 0; qb < nqb; ++qb) {
+    Frag<T, D> qn, don;
+    Frag<T, 32> dotn[D / 32], qtn[D / 32];
+    load_q(qb + 1 < nqb ? qb + 1 : qb, qn, don, dotn, qtn);   // next tile in flight under this tile's math
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -464,13 +471,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     frag_from_regs(dsf, ds);
 #pragma unroll
     for (int i = 0; i < D / 32; ++i) {
-      Frag<T, 32> dotf, qtf;
-      const int64_t trow = (((int64_t)seq * p.H + h) * D + i * 32 + ar) * Lp + qb * 32;
-      frag_load(dotf, dOt + trow, half, Lp - qb * 32);
-      frag_load(qtf, Qt + trow, half, Lp - qb * 32);
-      dvacc[i] = mma(dvacc[i], dotf, pf);
-      dkacc[i] = mma(dkacc[i], qtf, dsf);
+      dvacc[i] = mma(dvacc[i], dotf[i], pf);
+      dkacc[i] = mma(dkacc[i], qtf[i], dsf);
     }
+    qf = qn; dof = don;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) { dotf[i] = dotn[i]; qtf[i] = qtn[i]; }
   }
   if (kj < L) {
     T* dK = reinterpret_cast<T*>(p.dk) + ((int64_t)seq * L + kj) * p.lddk + h * D;
@@ -719,10 +725,11 @@ extern "C" int ctclip_attn_fwd(const void* q, const void* k, const void* vt, con
 }
 
 static int dbias_nsplit(int nseq, int H, int L) {
-  const int blocks = ((L + 31) / 32) * H;
-  int ns = (1536 + blocks - 1) / blocks;
+  const int nkb = (L + 31) / 32;
+  const int blocks = ((nkb * nkb + 3) / 4) * H;     // 4 tile pairs per block
+  int ns = (2048 + blocks - 1) / blocks;
   if (ns > nseq) ns = nseq;
-  if (ns > 16) ns = 16;
+  if (ns > 8) ns = 8;
   if (ns < 1) ns = 1;
   return ns;
 }
@@ -756,24 +763,28 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo;
   p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.scale = scale;
   int rc;
-  if (dbias && D == 32 && (L + 31) / 32 <= 4 * ATT_MAXT) {
-    // deterministic dBias path: registers + per-split slabs, no atomics
+  if (dbias) {
+    // deterministic dBias: dedicated kernel (registers + per-split slabs), then the plain dQ kernel
     const int ns = dbias_nsplit(nseq, H, L);
     if (!workspace || workspace_bytes < ctclip_attn_bwd_workspace(nseq, H, L)) { ctclip_set_error("attn_bwd: workspace too small for the dBias slabs"); return CTCLIP_EWORKSPACE; }
-    p.dbias = nullptr;
-    dim3 grid((unsigned)((L + 31) / 32), H, ns);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((attn_bwd_dq_bias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, (float*)workspace, ns);
-    else if (dtype == DT_F32) hipLaunchKernelGGL((attn_bwd_dq_bias_kernel<float, 32>), grid, dim3(256), 0, stream, p, (float*)workspace, ns);
+    const int nkb = (L + 31) / 32;
+    dim3 grid((unsigned)((nkb * nkb + 3) / 4), H, ns);
+    float* ws = (float*)workspace;
+    if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, ws, ns);
+    else if (dtype == DT_BF16 && D == 64) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 64>), grid, dim3(256), 0, stream, p, ws, ns);
+    else if (dtype == DT_F32 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<float, 32>), grid, dim3(256), 0, stream, p, ws, ns);
+    else if (dtype == DT_F32 && D == 64) hipLaunchKernelGGL((attn_bwd_dbias_kernel<float, 64>), grid, dim3(256), 0, stream, p, ws, ns);
     else return CTCLIP_EUNSUPPORTED;
-    rc = ctclip_check_launch("attn_bwd_dq_bias");
+    rc = ctclip_check_launch("attn_bwd_dbias");
     if (rc) return rc;
     const int64_t n = (int64_t)H * L * L;
     int64_t nb = cdiv(n, 256); if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, dbias, ns, n);
     rc = ctclip_check_launch("dbias_reduce");
-  } else {
-    rc = dispatch_attn(1, p, D, dtype, stream);   // dBias (if any) via f32 atomics
+    if (rc) return rc;
+    p.dbias = nullptr;
   }
+  rc = dispatch_attn(1, p, D, dtype, stream);
   if (rc) return rc;
   return dispatch_attn(2, p, D, dtype, stream);
 }

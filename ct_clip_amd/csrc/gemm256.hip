@@ -194,16 +194,18 @@ __global__ __launch_bounds__(NT256) void gemm256_kernel(Gemm256Params p) {
   float* wbuf = reinterpret_cast<float*>(lds) + wave * (32 * 65);
   const bool vec_ok = ((p.ldc % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.C) % 16) == 0) &&
                       (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
+  // (the main loop ended with a block barrier: nobody reads the stage buffers any more.  From here on every wave works in
+  //  its PRIVATE wbuf region, so only wave-local ordering of LDS writes -> reads is needed, no block barriers.)
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) {
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wbuf[(a * 16 + lg * 4 + r) * 65 + b * 16 + li] = acc[hh * 2 + a][b][r] * p.alpha;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // 32 rows x 64 cols: a lane handles 8 consecutive columns of one row; 8 lanes per row, 8 rows per pass, 4 passes
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {

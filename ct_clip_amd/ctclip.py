@@ -73,6 +73,16 @@ class CTCLIP(nn.Module):
         assert path.exists()
         self.load_state_dict(torch.load(str(path)))
 
+    def _text_stream(self, device):
+        import os
+        if device.type != "cuda" or os.environ.get("CTCLIP_TEXT_STREAM", "1") == "0":
+            return None
+        st = self.__dict__.get("_side_stream")
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self.__dict__["_side_stream"] = st
+        return st
+
     def tokenize(self, prompt):
         if self.tokenizer is None:
             from transformers import BertTokenizer
@@ -88,8 +98,20 @@ class CTCLIP(nn.Module):
         dt = self.compute_dtype
         ids, mask = text.input_ids, text.attention_mask
         Bt, T = ids.shape
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)          # (Bt*T, dim_text)
+        # The text tower (M = B*T rows: far too small to fill 256 CUs) runs on a side stream underneath the image tower;
+        # autograd replays each tower's backward on the stream its forward used.
+        side = self._text_stream(ids.device if ids.is_cuda else self.temperature.device)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)   # (Bt*T, dim_text)
+        else:
+            enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)
         enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)                 # (Bi, t, h, w, d)
+        if side is not None:
+            main.wait_stream(side)
+            enc_text.record_stream(main)
         Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
         enc_image = Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1))                               # ct_clip.py:724,740
         if return_encodings:
