@@ -42,6 +42,7 @@ SIGNATURES = {
     "ctclip_leaky_relu_bwd": (_I, [_P, _P, _P, _L, _F, _P]),
     "ctclip_colsum": (_I, [_P, _P, _L, _I, _L, _I, _P]),
     "ctclip_permute0213": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "ctclip_transpose2d": (_I, [_P, _P, _I, _I, _L, _L, _I, _P]),
     "ctclip_pool_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),
     "ctclip_pool_bwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),
     "ctclip_convert_pad": (_I, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _P]),

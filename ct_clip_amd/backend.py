@@ -284,6 +284,13 @@ class HipBackend:
         _lib.check(self.lib.ctclip_permute0213(_p(x), _p(y), A, B, C, D, dcode(x.dtype), _stream()), "ctclip_permute0213")
         return y
 
+    def transpose2d(self, x):
+        R, C = x.shape
+        y = torch.empty((C, R), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.ctclip_transpose2d(_p(x), _p(y), R, C, _rowmajor(x, "transpose x"), R, dcode(x.dtype), _stream()),
+                   "ctclip_transpose2d")
+        return y
+
     def pool_fwd(self, x):
         B, t, R = x.shape
         assert x.is_contiguous()

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT256) void gemm256_kernel(Gemm256Params p) {
     p.ldc = p.slab_ld; p.out_dtype = DT_F32; p.accumulate = 0; p.bias = nullptr; p.residual = nullptr;
   }
   // stage the wave's 128 x 64 f32 tile through LDS in four quarters of 32 rows (row pitch 65 floats, 8320 B per wave)
-  float* wbuf = reinterpret_cast<float*>(lds) + wave * (32 * 65);
+  float* wbuf = reinterpret_cast<float*>(lds) + wave * (32 * 68);   // pitch 68 floats: conflict-free column writes, 16-B aligned rows
   const bool vec_ok = ((p.ldc % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.C) % 16) == 0) &&
                       (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
   // (the main loop ended with a block barrier: nobody reads the stage buffers any more.  From here on every wave works in
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NT256) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wbuf[(a * 16 + lg * 4 + r) * 65 + b * 16 + li] = acc[hh * 2 + a][b][r] * p.alpha;
+        for (int r = 0; r < 4; ++r) wbuf[(a * 16 + lg * 4 + r) * 68 + b * 16 + li] = acc[hh * 2 + a][b][r] * p.alpha;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // 32 rows x 64 cols: a lane handles 8 consecutive columns of one row; 8 lanes per row, 8 rows per pass, 4 passes
 #pragma unroll
@@ -213,8 +213,7 @@ __global__ __launch_bounds__(NT256) void gemm256_kernel(Gemm256Params p) {
       const int64_t row = m0 + wm * 128 + hh * 32 + rr, col = n0 + wn * 64 + cc;
       if (row >= p.M || col >= p.N) continue;
       float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = wbuf[rr * 65 + cc + e];
+      load8(wbuf + rr * 68 + cc, v);
       const bool full = vec_ok && (col + 8 <= p.N);
       if (p.bias) {
 #pragma unroll

@@ -124,6 +124,23 @@ __global__ void permute0213_kernel(const T* __restrict__ x, T* __restrict__ y, i
   }
 }
 
+// ---- y (C, R) = x (R, C)^T  (weight-shadow transposes for the grad-input GEMMs), 32 x 32 LDS tiles
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int C, int64_t ldx, int64_t ldy) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? Elem<T>::ld(x + (int64_t)r * ldx + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) Elem<T>::st(y + (int64_t)c * ldy + r, tile[tx][i]);
+  }
+}
+
 // ---- mean over the depth-token axis (ct_clip.py:724): x (B, t, R) -> y (B, R); backward broadcasts dy / t
 template <typename T>
 __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t B, int t, int64_t R) {
@@ -328,6 +345,12 @@ extern "C" int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int 
   if (!x || !y || D % 8) { ctclip_set_error("permute0213: D must be a multiple of 8"); return CTCLIP_EBADARG; }
   BY_DTYPE(dtype, hipLaunchKernelGGL(permute0213_kernel<T>, grid_for(A * B * C * D / 8), dim3(256), 0, s, (const T*)x, (T*)y, A, B, C, D));
   return ctclip_check_launch("permute0213");
+}
+extern "C" int ctclip_transpose2d(const void* x, void* y, int R, int C, int64_t ldx, int64_t ldy, int dtype, hipStream_t s) {
+  if (!x || !y) return CTCLIP_EBADARG;
+  dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
+  BY_DTYPE(dtype, hipLaunchKernelGGL(transpose2d_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (T*)y, R, C, ldx, ldy));
+  return ctclip_check_launch("transpose2d");
 }
 extern "C" int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s) {
   if (!x || !y || R % 8) { ctclip_set_error("pool_fwd: R must be a multiple of 8"); return CTCLIP_EBADARG; }

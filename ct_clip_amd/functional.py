@@ -106,6 +106,7 @@ class LinearFn(Function):
         y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
                      out_dtype=out_dtype or x.dtype)
         ctx.save_for_backward(x, wsh)
+        ctx.wkey = (weight, tuple(wsh.shape))
         ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
         ctx.has_res = residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
@@ -127,7 +128,13 @@ class LinearFn(Function):
             dyc = dy
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
+            if dyc.dtype == torch.bfloat16 and dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0:
+                # big grad-input GEMM: use the transposed weight shadow so that both operands are k-contiguous (global_load_lds path)
+                w, shp = ctx.wkey
+                wt = shadow(w, ("T",) + shp, dyc.dtype, lambda: B().transpose2d(wsh))
+                dx = B().gemm(dyc, wt)
+            else:
+                dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
             if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
                 dx = dx[:, :x.shape[1]]
         dw = None

@@ -104,6 +104,9 @@ int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int d
 /* rearrange '(b t)(h w) d <-> (b h w) t d' between the spatial and temporal phases (ctvit.py:297-305). */
 int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s);
 
+/* y (C,R) = x (R,C)^T: transposed weight shadows for the grad-input GEMMs. */
+int ctclip_transpose2d(const void* x, void* y, int R, int C, int64_t ldx, int64_t ldy, int dtype, hipStream_t s);
+
 /* torch.mean(enc_image, dim=1) (ct_clip.py:724). */
 int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
 

@@ -198,6 +198,9 @@ class RefBackend:
     def permute0213(self, x):
         return x.permute(0, 2, 1, 3).contiguous()
 
+    def transpose2d(self, x):
+        return x.t().contiguous()
+
     def pool_fwd(self, x):
         return _f(x).mean(1).to(x.dtype)
 

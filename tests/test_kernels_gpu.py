@@ -39,7 +39,7 @@ def close(a, b, **kw):
 # ---------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (130, 70, 72), (64, 2816, 512), (300, 512, 1408), (8, 8, 8),
-                                   (4096, 2816, 256), (4000, 2900, 192)])   # the last two take the 256^2-tile path
+                                   (4096, 2816, 256), (4000, 2900, 192), (4096, 2560, 64), (8200, 1408, 2816)])   # large-tile paths
 def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
     a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)   # asymmetric operands (transpose-detecting)
     bias, res = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
@@ -236,6 +236,14 @@ def test_colsum_permute_pool_convert(hip, ref, dtype):
     close(hip.pool_bwd(t3[:, 0].contiguous(), 6), ref.pool_bwd(t3[:, 0].contiguous(), 6), **tol(dtype, (1e-6, 1e-7), (1e-2, 1e-2)))
     w, cs = rnd(37, 50, seed=4), rnd(50, seed=5)
     close(hip.convert_pad(w, 40, 64, dtype, colscale=cs), ref.convert_pad(w, 40, 64, dtype, colscale=cs), **tol(dtype, (1e-6, 1e-7), (1e-2, 1e-2)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose2d(hip, ref, dtype):
+    x = rnd(300, 1416, dtype=dtype, seed=9)[:, :1408]
+    close(hip.transpose2d(x), ref.transpose2d(x), rtol=0, atol=0)
+    x = rnd(37, 50, dtype=dtype, seed=10)
+    close(hip.transpose2d(x), ref.transpose2d(x), rtol=0, atol=0)
 
 
 def test_cpb_expand_reduce(hip, ref):
