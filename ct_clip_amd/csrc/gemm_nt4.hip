@@ -60,49 +60,61 @@ __device__ __forceinline__ void stage_glds(char* lds, const bf16_t* __restrict__
 
 template <int WM_>
 __global__ __launch_bounds__(Geo<WM_>::NTH) void gemm_nt4_kernel(Nt4Params p) {
-  using G = Geo<WM_>;
-  constexpr int TM = G::TM, NSTAGE = G::NSTAGE, STAGE_BYTES = G::STAGE_BYTES;
+  using G_ = Geo<WM_>;
+  constexpr int TM = G_::TM, NSTAGE = G_::NSTAGE, STAGE_BYTES = G_::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int ntiles = p.ntm * p.ntn;
-  int bid = blockIdx.x;
-  {  // XCD-aware tile order: consecutive tile ids (sharing an A row panel) stay on one XCD / L2
-    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, within = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
-  const int tm = bid / p.ntn, tn = bid % p.ntn;
-  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
   const int nk = (int)(p.K / TK);
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // wm is 0 when WM_ == 1
   const int li = lane & 15, lg = lane >> 4;
 
+  // PERSISTENT: one workgroup per CU walks the tile list (no per-tile launch / retire).  Measured phase split of the FF
+  // in-projection (M=110592, N=2816, K=512; CTCLIP_NT4_DEBUG ablations): MFMA+LDS-reads only 287 us, loads only 221 us, epilogue
+  // 233 us (the 623 MB of output at ~2.7 TB/s), total 568 us -- the phases overlap only partially because all eight waves of
+  // the workgroup are in the same phase, and the next tile's counted waits still cover this tile's stores (vmcnt counts both).
+  // Tile order: in round i the workgroups of XCD x (blockIdx % 8, 32 CUs) take 32 CONSECUTIVE tile ids, which share A row
+  // panels through that XCD's L2.
+  const int G = gridDim.x;
+  const int slotb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);     // G is a multiple of 8
+  auto tile_of = [&](int it, int64_t& m0, int64_t& n0) -> bool {
+    const int id = it * G + slotb;
+    if (id >= ntiles) return false;
+    m0 = (int64_t)(id / p.ntn) * TM; n0 = (int64_t)(id % p.ntn) * TN;
+    return true;
+  };
+  int64_t m0, n0;
+  if (!tile_of(0, m0, n0)) return;
+  int gs = 0;   // global stage counter: stage t of the current tile lives in ring slot (gs + t) % NSTAGE
+
+  auto issue = [&](int t) {
+    char* s = lds + ((gs + t) % NSTAGE) * STAGE_BYTES;
+    stage_glds<G_::A_PIECES>(s, p.A, p.lda, m0, p.M, (int64_t)t * TK, wave, lane);
+    stage_glds<G_::B_PIECES>(s + TM * ROWB, p.B, p.ldb, n0, p.N, (int64_t)t * TK, wave, lane);
+  };
+  // prologue of the first tile: NSTAGE-1 stages in flight (G_::GLDS glds per wave per stage)
+  issue(0);
+  if (nk > 1) issue(1);
+  if (NSTAGE > 3 && nk > 2) issue(2);
+
+  for (int it = 0;; ++it) {
   f32x4 acc[8][4];
 #pragma unroll
   for (int a = 0; a < 8; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int t) {
-    char* s = lds + (t % NSTAGE) * STAGE_BYTES;
-    stage_glds<G::A_PIECES>(s, p.A, p.lda, m0, p.M, (int64_t)t * TK, wave, lane);
-    stage_glds<G::B_PIECES>(s + TM * ROWB, p.B, p.ldb, n0, p.N, (int64_t)t * TK, wave, lane);
-  };
-  // prologue: NSTAGE-1 stages in flight (G::GLDS glds per wave per stage)
-  issue(0);
-  if (nk > 1) issue(1);
-  if (NSTAGE > 3 && nk > 2) issue(2);
-
   for (int t = 0; t < nk; ++t) {
-    // stage t must have landed: allow only the glds of the (up to two) younger stages to remain outstanding
+    // stage t must have landed: allow only the glds of the (up to two) younger stages to remain outstanding.  (Epilogue
+    // stores of the previous tile may still be counted by vmcnt: the bound is on the TOTAL, so it stays safe, merely conservative.)
     const int younger = nk - 1 - t;
-    if (younger >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * G::GLDS) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::GLDS) : "memory");
+    if (younger >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * G_::GLDS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G_::GLDS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // every wave's part of stage t is in LDS; every wave is done reading stage t-1
     if (t + NSTAGE - 1 < nk && !(p.dbg & 1)) issue(t + NSTAGE - 1);       // refills the slot stage t-1 occupied
-    const char* sA = lds + (t % NSTAGE) * STAGE_BYTES;
+    const char* sA = lds + ((gs + t) % NSTAGE) * STAGE_BYTES;
     const char* sB = sA + TM * ROWB;
     u32x4 bfr[4];
 #pragma unroll
@@ -117,8 +129,10 @@ __global__ __launch_bounds__(Geo<WM_>::NTH) void gemm_nt4_kernel(Nt4Params p) {
                                                             acc[a][b], 0, 0, 0);
     }
   }
-  __syncthreads();   // all fragment reads done before the LDS is reused by the epilogue
-  if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = 1.f; return; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // all fragment reads done before the LDS is reused by the epilogue (raw barrier: a
+                                  // __syncthreads would also drain vmcnt, i.e. wait for the previous tile's stores)
+  const bool skip_epi = (p.dbg & 4) && acc[0][0][0] != 12345.678f;
 
   // ---------------- epilogue: acc[a][b][r] = C[m0 + wm*128 + a*16 + lg*4 + r][n0 + wn*64 + b*16 + li]
   // each wave stages its tile through a PRIVATE LDS region in four quarters of 32 rows (only wave-local ordering needed)
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(Geo<WM_>::NTH) void gemm_nt4_kernel(Nt4Params p) {
                       (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) {
+    if (skip_epi) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -187,7 +202,17 @@ __global__ __launch_bounds__(Geo<WM_>::NTH) void gemm_nt4_kernel(Nt4Params p) {
       }
     }
   }
+  // next tile: all waves must be done with the epilogue's LDS region before the ring is refilled
+  gs = (gs + nk) % NSTAGE;
+  if (!tile_of(it + 1, m0, n0)) break;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // raw: do NOT wait for this tile's stores, they drain under the next tile
+  issue(0);
+  if (nk > 1) issue(1);
+  if (NSTAGE > 3 && nk > 2) issue(2);
+  }   // persistent tile loop
 }
+
 
 }  // namespace
 
@@ -213,6 +238,8 @@ int ctclip_gemm_nt4_try(const void* A, const void* B, void* C, const float* bias
   // (A 128 x 256 / 4-wave / 72 KiB geometry meant to keep two workgroups per CU was measured 2x SLOWER -- 1160 vs 570 us on the
   //  FF in-projection -- and is not dispatched; Geo<1> stays only as the documented record of that experiment.)
   p.dbg &= 7;
-  hipLaunchKernelGGL(gemm_nt4_kernel<2>, dim3((unsigned)(p.ntm * p.ntn)), dim3(Geo<2>::NTH), Geo<2>::NSTAGE * Geo<2>::STAGE_BYTES, stream, p);
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? (prop.multiProcessorCount & ~7) : 256; }
+  hipLaunchKernelGGL(gemm_nt4_kernel<2>, dim3((unsigned)ncu), dim3(Geo<2>::NTH), Geo<2>::NSTAGE * Geo<2>::STAGE_BYTES, stream, p);
   return ctclip_check_launch("gemm_nt4");
 }
