@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctclip_hip.so")
+LIB_PATH = os.environ.get("CTCLIP_LIB") or os.path.join(_HERE, "libctclip_hip.so")   # CTCLIP_LIB: profiling builds only
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 

@@ -20,14 +20,15 @@
 // valid as long as A and B use the same one; bf16 uses 2 x mfma_f32_16x16x32_bf16 per fragment pair,
 // f32 uses 8 x mfma_f32_16x16x4f32 (exact f32 FMA chain -- the parity mode).
 #include "common.h"
+#include <stdlib.h>
 
 int ctclip_gemm256_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype,
                        int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t ctclip_gemm256_workspace(int64_t M, int64_t N, int64_t K, int split_k);
-int ctclip_gemm_nt4_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
-                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
-                        hipStream_t stream);
+int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
+                       hipStream_t stream);
 
 namespace {
 
@@ -333,8 +334,8 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   int rc = check_operands(A, B, lda, ldb, M, N, K, a_kc, b_kc, in_dtype);
   if (rc) return rc;
   if (!C) { ctclip_set_error("gemm: null C"); return CTCLIP_EBADARG; }
-  if (in_dtype == DT_BF16 && a_kc && b_kc && split_k <= 1) {   // 4-stage counted-vmcnt kernel for the big forward / grad-input GEMMs
-    rc = ctclip_gemm_nt4_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_dtype, res_dtype, accumulate, alpha, stream);
+  if (in_dtype == DT_BF16 && a_kc && b_kc && split_k <= 1) {   // persistent LDS-DMA ring kernel (gemm_nt.hip) for the big forward / grad-input GEMMs
+    rc = ctclip_gemm_nt_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_dtype, res_dtype, accumulate, alpha, stream);
     if (rc != 1) return rc;
   }
   if (in_dtype == DT_BF16) {   // large-tile fast path (gemm256.hip) when the shape fills the chip

@@ -51,6 +51,23 @@ def test_gemm_nt_bias_residual(hip, ref, dtype, M, N, K):
     close(y32, ref.gemm(a, b, out_dtype=torch.float32, alpha=0.5), **tol(dtype, (1e-4, 1e-4 * s), (1e-2, 1e-2 * s)))
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2816, 512), (20000, 1408, 192), (12300, 2100, 128), (16384, 4096, 64)])
+def test_gemm_nt_persistent_multi_tile(hip, ref, M, N, K):
+    """More tiles than CUs: the persistent NT kernel's panel stream runs across tile boundaries and the counted vmcnt waits have
+    to account for the epilogue stores of the previous tile (fast path) or drain them (ragged tiles, residual, accumulate)."""
+    dtype = torch.bfloat16
+    a, b = rnd(M, K, dtype=dtype, seed=5), rnd(N, K, dtype=dtype, seed=6)
+    bias, res = rnd(N, seed=7), rnd(M, N, dtype=dtype, seed=8)
+    s = K ** 0.5
+    for kw in (dict(), dict(bias=bias), dict(out_dtype=torch.float32, alpha=0.25), dict(bias=bias, out_dtype=torch.float32),
+               dict(residual=res), dict(bias=bias, residual=res)):
+        close(hip.gemm(a, b, **kw), ref.gemm(a, b, **kw), rtol=2e-2, atol=2e-2 * s)
+    acc = rnd(M, N, seed=9)
+    out = acc.clone()
+    hip.gemm(a, b, out=out, accumulate=True)
+    close(out, acc + ref.gemm(a, b, out_dtype=torch.float32), rtol=2e-2, atol=2e-2 * s)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (130, 72, 70), (512, 1408, 512), (49, 64, 2), (4096, 2560, 512), (4100, 2568, 448)])
 def test_gemm_nn_grad_input(hip, ref, dtype, M, N, K):

@@ -25,7 +25,10 @@ cases = {
                                                          M=1365, N=d, K=M), 2.0 * M * 1365 * d, (M * 1365 + M * d) * 2 + 1365 * d * 8),
 }
 out = {}
+only = os.environ.get("GEMM_CASES")   # e.g. GEMM_CASES=NT
 for name, (fn, flops, bytes_) in cases.items():
+    if only and not name.startswith(only):
+        continue
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
