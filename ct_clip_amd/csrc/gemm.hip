@@ -26,6 +26,10 @@ int ctclip_gemm256_try(const void* A, const void* B, void* C, const float* bias,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype,
                        int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t ctclip_gemm256_workspace(int64_t M, int64_t N, int64_t K, int split_k);
+int ctclip_gemm_tn_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int accumulate, int split_k, float alpha, void* workspace,
+                       int64_t workspace_bytes, hipStream_t stream);
+int64_t ctclip_gemm_tn_workspace(int64_t M, int64_t N, int64_t K, int split_k);
 int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
                        hipStream_t stream);
@@ -338,6 +342,13 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
     rc = ctclip_gemm_nt_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_dtype, res_dtype, accumulate, alpha, stream);
     if (rc != 1) return rc;
   }
+  static int use_tn = -1;
+  if (use_tn < 0) { const char* e = getenv("CTCLIP_GEMM_TN"); use_tn = (e && e[0] == '0') ? 0 : 1; }
+  if (use_tn && in_dtype == DT_BF16 && !a_kc && !b_kc) {       // weight gradients: split-K kernel with transposing LDS reads (gemm_tn.hip)
+    rc = ctclip_gemm_tn_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, out_dtype, accumulate, split_k, alpha, workspace,
+                            workspace_bytes, stream);
+    if (rc != 1) return rc;
+  }
   if (in_dtype == DT_BF16) {   // large-tile fast path (gemm256.hip) when the shape fills the chip
     rc = ctclip_gemm256_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_kc, b_kc, out_dtype, res_dtype, accumulate,
                             split_k, alpha, workspace, workspace_bytes, stream);
@@ -371,7 +382,9 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
 
 // bytes of optional workspace for ctclip_gemm (split-K partial slabs of the large-tile bf16 path); split_k <= 0 means "auto"
 extern "C" int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k) {
-  return in_dtype == DT_BF16 ? ctclip_gemm256_workspace(M, N, K, split_k) : 0;
+  if (in_dtype != DT_BF16) return 0;
+  const int64_t w256 = ctclip_gemm256_workspace(M, N, K, split_k), wtn = ctclip_gemm_tn_workspace(M, N, K, split_k);
+  return w256 > wtn ? w256 : wtn;   // (layout-agnostic entry point: enough for whichever kernel the dispatcher picks)
 }
 
 // Row-wise arg-max of A B^T without materialising the product (vector-quantiser code assignment:
