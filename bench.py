@@ -258,6 +258,18 @@ def main():
         "peak_mem_gib": round(peak_mem, 1),
     }
     if timing:
+        # HBM traffic of the same kernel at the same shape from the committed PMC passes (collected off-line: --pmc cannot be combined
+        # with the timed run); None when that shape was not profiled
+        try:
+            table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+            m = __import__("re").match(r"gemm_kernel<\w+,(\w+)> (M=\d+ N=\d+ K=\d+)", timing["kernel"])
+            ent = table.get(f"{m.group(1)} {m.group(2)}") if m else None
+            if ent:
+                timing["traffic"] = ent["fetch_bytes"] + ent["write_bytes"]
+                timing["traffic_source"] = "profiles/r01_pmc_gemm_nt_tn.md (FETCH_SIZE x2-corrected + WRITE_SIZE, bytes per launch)"
+                timing["device_kernel"] = ent["kernel"]
+        except Exception:
+            pass
         out["roofline"] = timing
     if args.also_reference_depth:
         dt2, loss2, _, _ = run_config(4, 4, args.steps, max(1, args.warmup), False)

@@ -56,8 +56,10 @@ class HipBackend:
             ms = [a.elapsed_time(b) for a, b in pairs]
             layout, dt, M, N, K = key
             flops = 2.0 * M * N * K
+            esz = 2 if dt == "bf16" else 4
             groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}", launches=len(ms),
-                               avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops))
+                               avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops,
+                               bytes_per_launch=float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))))
         groups.sort(key=lambda g: -g["total_ms"])
         top = groups[0]
         ach = top["flops_per_launch"] / (top["avg_us"] * 1e-6) / 1e12
@@ -65,7 +67,7 @@ class HipBackend:
         peak = peak_tflops if bf else 157.3
         return dict(bound="mfma", kernel=top["kernel"], achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
                     frac=round(ach / peak, 4), traffic=None, launches=top["launches"], avg_us=round(top["avg_us"], 1),
-                    algorithmic_flops_per_launch=top["flops_per_launch"],
+                    algorithmic_flops_per_launch=top["flops_per_launch"], algorithmic_bytes_per_launch=top["bytes_per_launch"],
                     gemm_total_ms=round(sum(g["total_ms"] for g in groups), 2),
                     top5=[dict(kernel=g["kernel"], launches=g["launches"], avg_us=round(g["avg_us"], 1),
                                tflops=round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)) for g in groups[:5]])

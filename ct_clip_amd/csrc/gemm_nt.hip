@@ -71,6 +71,17 @@ __device__ __forceinline__ const char* to_sgpr(const char* ptr) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// Fragment reads go through inline asm with the kernel's own counted lgkmcnt waits (LDS returns in order): left to the compiler
+// every half sub-step began with s_waitcnt lgkmcnt(0) right after two fresh reads were issued, i.e. exposed their latency.
+// (gemm_tn.hip needs the asm form for a harder reason: see there.)  The waits carry the fragments as operands to pin the order.
+template <int OFF> __device__ __forceinline__ u32x4 lds_read16(uint32_t vaddr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(vaddr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lds(u32x4& x, u32x4& y) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N)); }
+template <int N> __device__ __forceinline__ void wait_lds3(u32x4& x, u32x4& y, u32x4& z) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(x), "+v"(y), "+v"(z) : "n"(N)); }
+
 template <bool NONTEMPORAL>
 __device__ __forceinline__ void store16(void* c, u32x4 d) {
   if (NONTEMPORAL) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(c));
@@ -156,8 +167,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 
   // fragment registers, reloaded IN PLACE as soon as their last MFMA of a sub-step has been issued
   u32x4 fa[4], fb[8];
-  auto read_a = [&](int f, const char* sA, int ks) { fa[f] = *reinterpret_cast<const u32x4*>(sA + swz(wm * 64 + f * 16 + li, ks * 4 + lg)); };
-  auto read_b = [&](int f, const char* sB, int ks) { fb[f] = *reinterpret_cast<const u32x4*>(sB + swz(wn * 128 + f * 16 + li, ks * 4 + lg)); };
+  // lane part of the fragment address for ks = 0, 1 (the swizzle depends on li only; fragment f adds 16 rows = 2048 bytes)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const uint32_t fadr[2] = {(uint32_t)swz(li, lg), (uint32_t)swz(li, 4 + lg)};
+  uint32_t pa[2], pb[2];
+  auto point_a = [&](int slot) { pa[0] = fadr[0] + lds0 + (uint32_t)(slot * PANEL + wm * 8192); pa[1] = fadr[1] + lds0 + (uint32_t)(slot * PANEL + wm * 8192); };
+  auto point_b = [&](int slot) { pb[0] = fadr[0] + lds0 + (uint32_t)(slot * PANEL + wn * 16384); pb[1] = fadr[1] + lds0 + (uint32_t)(slot * PANEL + wn * 16384); };
+#define NT_RA(f, ks) fa[f] = lds_read16<(f) * 2048>(pa[ks]);
+#define NT_RB(f, ks) fb[f] = lds_read16<(f) * 2048>(pb[ks]);
 
   // ---- prologue.  Ring position of A(g) is 2g, of B(g) 2g+1 (g = global k-step across tiles), slot = position % 5.
   enter_a(0); enter_b(0);
@@ -175,9 +192,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
   for (int j = 0; j < GL; ++j) glds(b_base + (int64_t)b_t * (TK * 2), b_off[j], 3, j);        // B(1)
   if (++b_t == nk) enter_b(b_it + 1);
-  read_a(0, lds, 0); read_a(1, lds, 0);
-#pragma unroll
-  for (int f = 0; f < 8; ++f) read_b(f, lds + PANEL, 0);
+  point_a(0); point_b(1);
+  NT_RA(0, 0) NT_RA(1, 0)
+  NT_RB(0, 0) NT_RB(1, 0) NT_RB(2, 0) NT_RB(3, 0) NT_RB(4, 0) NT_RB(5, 0) NT_RB(6, 0) NT_RB(7, 0)
   int cs = 0;             // ring slot of A(g) for the consumer's current step g
 
   for (int it = 0;; ++it) {
@@ -193,65 +210,79 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     acc[a0 + 1][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a0 + 1]), __builtin_bit_cast(bf16x8, fb[b]), \
                                                              acc[a0 + 1][b], 0, 0, 0);
 
+    // Every fragment read and every LDS-DMA piece is issued BETWEEN MFMAs.  A sub-step (32 MFMAs per wave) runs as two halves:
+    // rows a = 0,1 against all eight B fragments, then rows a = 2,3.  While the first half runs, fa[2], fa[3] of the same
+    // sub-step are fetched; in the second half fa[0], fa[1] and, one by one as they die, fb[0..7] are re-loaded with the NEXT
+    // sub-step's fragments.  No second register set is needed and no read phase is exposed.  Issue order of the reads:
+    //   H1: A2 A3 | MFMA(a=0,1 ; b) needs A0 A1 B[b]      H2: A0' A1' | MFMA(a=2,3 ; b) needs A2 A3 ; then B[b]'
+    //   H3: A2' A3' | MFMA(0,1) needs A0' A1' B'[b]       barrier      H4: A0'' A1'' | MFMA(2,3) ; then B[b]''
+    // In H1 / H3 the reads younger than B[b] are B[b+1..7] and the two A fragments just issued: lgkmcnt(2 + 7 - b).
+#define NT_H13(b) wait_lds3<2 + 7 - (b)>(fa[0], fa[1], fb[b]); NT_MFMA2(0, b)
     for (int t = 0; t < nk; ++t) {
-      // Every fragment read and every LDS-DMA piece is issued BETWEEN MFMAs.  A sub-step (32 MFMAs per wave) runs as two halves:
-      // rows a = 0,1 against all eight B fragments, then rows a = 2,3.  While the first half runs, fa[2], fa[3] of the same
-      // sub-step are fetched; in the second half fa[0], fa[1] and, one by one as they die, fb[0..7] are re-loaded with the NEXT
-      // sub-step's fragments.  No second register set is needed and no read phase is exposed.
-      const char* sA = lds + cs * PANEL;
-      const char* sB = lds + wrap(cs + 1) * PANEL;
-      const char* nA = lds + wrap(cs + 2) * PANEL;            // step g+1
-      const char* nB = lds + wrap(cs + 3) * PANEL;
       const int slot_b2 = cs;                                 // B(g+2) replaces A(g) after barrier_g
       const int slot_a2 = wrap(cs + 4);                       // A(g+2): issued during this step's first half-unit (freed by barrier_g-1)
+      const int slot_na = wrap(cs + 2), slot_nb = wrap(cs + 3);
       cs = wrap(cs + 2);
       const char* a_k = a_base + (int64_t)a_t * (TK * 2);     // cursor position of A(g+2)
-      // ---- (t, ks=0), first half; LDS-DMA of A(g+2)
-      read_a(2, sA, 0); read_a(3, sA, 0);
+      // ---- H1: (t, ks=0), rows a = 0,1; LDS-DMA of A(g+2)
+      NT_RA(2, 0) NT_RA(3, 0)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        NT_MFMA2(0, b)
-        if (b & 1) glds(a_k, a_off[b >> 1], slot_a2, b >> 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      NT_H13(0) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(1) glds(a_k, a_off[0], slot_a2, 0); __builtin_amdgcn_sched_barrier(0);
+      NT_H13(2) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(3) glds(a_k, a_off[1], slot_a2, 1); __builtin_amdgcn_sched_barrier(0);
+      NT_H13(4) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(5) glds(a_k, a_off[2], slot_a2, 2); __builtin_amdgcn_sched_barrier(0);
+      NT_H13(6) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(7) glds(a_k, a_off[3], slot_a2, 3); __builtin_amdgcn_sched_barrier(0);
       if (++a_t == nk) enter_a(a_it + 1);
-      // ---- (t, 0), second half; fetch (t, ks=1)
-      read_a(0, sA, 1); read_a(1, sA, 1);
+      // ---- H2: (t, 0), rows a = 2,3; fetch (t, ks=1)
+      NT_RA(0, 1) NT_RA(1, 1)
+      wait_lds<2>(fa[2], fa[3]);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        NT_MFMA2(2, b)
-        read_b(b, sB, 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- (t, 1), first half
-      read_a(2, sA, 1); read_a(3, sA, 1);
+      NT_MFMA2(2, 0) NT_RB(0, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 1) NT_RB(1, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 2) NT_RB(2, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 3) NT_RB(3, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 4) NT_RB(4, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 5) NT_RB(5, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 6) NT_RB(6, 1) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 7) NT_RB(7, 1) __builtin_amdgcn_sched_barrier(0);
+      // ---- H3: (t, 1), rows a = 0,1
+      NT_RA(2, 1) NT_RA(3, 1)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        NT_MFMA2(0, b)
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      NT_H13(0) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(1) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(2) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(3) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(4) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(5) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(6) __builtin_amdgcn_sched_barrier(0);
+      NT_H13(7) __builtin_amdgcn_sched_barrier(0);
       // ---- barrier_g: A(g+1), B(g+1) have landed (outstanding, oldest first: A(g+1), B(g+1), A(g+2) [epilogue stores of the
       // previous tile are older than A(g+2) and are simply waited for]); every wave holds all of step g in registers.
       wait_vm<GL>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_lds<0>(fa[2], fa[3]);
       __builtin_amdgcn_s_barrier();
       const char* b_k = b_base + (int64_t)b_t * (TK * 2);     // cursor position of B(g+2)
-      // ---- (t, 1), second half; fetch (t+1, ks=0) -- of the next tile after the last step; LDS-DMA of B(g+2)
-      read_a(0, nA, 0); read_a(1, nA, 0);
+      // ---- H4: (t, 1), rows a = 2,3; fetch (t+1, ks=0) -- of the next tile after the last step; LDS-DMA of B(g+2)
+      point_a(slot_na); point_b(slot_nb);
+      NT_RA(0, 0) NT_RA(1, 0)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        NT_MFMA2(2, b)
-        read_b(b, nB, 0);
-        if (b & 1) glds(b_k, b_off[b >> 1], slot_b2, b >> 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      NT_MFMA2(2, 0) NT_RB(0, 0) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 1) NT_RB(1, 0) glds(b_k, b_off[0], slot_b2, 0); __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 2) NT_RB(2, 0) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 3) NT_RB(3, 0) glds(b_k, b_off[1], slot_b2, 1); __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 4) NT_RB(4, 0) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 5) NT_RB(5, 0) glds(b_k, b_off[2], slot_b2, 2); __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 6) NT_RB(6, 0) __builtin_amdgcn_sched_barrier(0);
+      NT_MFMA2(2, 7) NT_RB(7, 0) glds(b_k, b_off[3], slot_b2, 3); __builtin_amdgcn_sched_barrier(0);
       if (++b_t == nk) enter_b(b_it + 1);
     }
+#undef NT_H13
 #undef NT_MFMA2
+#undef NT_RA
+#undef NT_RB
 
     // ---------------- epilogue, straight from registers: acc[a][b][r] = C[m0 + wm*64 + a*16 + lg*4 + r][n0 + wn*128 + li*8 + b]:
     // a lane owns 8 consecutive columns, 16 lanes one 256-B (bf16) row segment, one 16-byte store instruction writes 4 full rows

@@ -11,7 +11,7 @@ import sys
 
 root, out = sys.argv[1], sys.argv[2]
 data = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in glob.glob(root + "/*/*counter_collection.csv"):
+for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name).split("(")[0]
@@ -30,6 +30,9 @@ for (name, grid), c in sorted(data.items()):
     bw = (fm + wm) / dur * 1e3 if (fm is not None and wm is not None and dur) else None
     mf, ga = avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("GRBM_GUI_ACTIVE")
     util = 100 * mf / (ga / 8 * 1024) if mf and ga else None
+    if util is None and mf:   # no GRBM_GUI_ACTIVE pass: busy cycles per SIMD over wall time at the nominal 2.4 GHz (a lower bound)
+        dm = avg("_dur_SQ_VALU_MFMA_BUSY_CYCLES")
+        util = 100 * (mf / 1024) / (dm * 1e-6 * 2.4e9) if dm else None
     fmt = lambda v, p=1: "-" if v is None else f"{v:.{p}f}"
     lines.append(f"| `{name}` | {grid} | {len(c.get('FETCH_SIZE', c.get('SQ_VALU_MFMA_BUSY_CYCLES', [])))} | {fmt(dur)} | {fmt(fm)} | {fmt(wm)} | {fmt(bw, 0)} | {fmt(util)} |")
 open(out, "w").write("\n".join(lines) + "\n")
