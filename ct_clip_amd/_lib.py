@@ -31,9 +31,9 @@ SIGNATURES = {
     "ctclip_head_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "ctclip_qk_norm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _I, _P]),
     "ctclip_qk_norm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _P]),
-    "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
+    "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
-    "ctclip_attn_bwd": (_I, [_P] * 15 + [_P] + [_I] * 5 + [_L] * 8 + [_F, _I, _P, _L, _P]),
+    "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _I, _P, _L, _P]),
     "ctclip_geglu_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
     "ctclip_geglu_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ctclip_gelu_fwd": (_I, [_P, _P, _L, _I, _P]),

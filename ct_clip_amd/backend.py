@@ -215,23 +215,26 @@ class HipBackend:
         _lib.check(rc, "ctclip_qk_norm_bwd")
         return dx
 
-    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True):
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None):
+        """bias: (H, L, L) f32, or with bias_grid = (gh, gw) the relative-position table (nclass, H) (ctclip_attn_fwd)."""
+        gh, gw = bias_grid if bias_grid is not None else (0, 0)
         M = nseq * L
         Lp = vt.shape[-1]
         o = torch.empty((M, H * D), dtype=q.dtype, device=q.device)
         lse = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device) if want_lse else None
-        rc = self.lib.ctclip_attn_fwd(_p(q), _p(k), _p(vt), _p(bias), _p(keymask), _p(o), _p(lse), nseq, H, L, Lp, D,
+        rc = self.lib.ctclip_attn_fwd(_p(q), _p(k), _p(vt), _p(bias), gh, gw, _p(keymask), _p(o), _p(lse), nseq, H, L, Lp, D,
                                       _rowmajor(q, "q"), _rowmajor(k, "k"), H * D, float(scale), dcode(q.dtype), _stream())
         _lib.check(rc, "ctclip_attn_fwd")
         return o, lse
 
-    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale):
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None):
         Lp = qt.shape[-1]
+        gh, gw = bias_grid if bias_grid is not None else (0, 0)
         delta = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device)
         ws = None
         if dbias is not None:
             ws = self.workspace(q.device, self.lib.ctclip_attn_bwd_workspace(nseq, H, L))
-        rc = self.lib.ctclip_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(o), _p(dout), _p(dot), _p(lse), _p(bias),
+        rc = self.lib.ctclip_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(o), _p(dout), _p(dot), _p(lse), _p(bias), gh, gw,
                                       _p(keymask), _p(delta), _p(dq), _p(dk), _p(dv), _p(dbias), nseq, H, L, Lp, D,
                                       _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(o, "o"),
                                       _rowmajor(dout, "dout"), _rowmajor(dq, "dq"), _rowmajor(dk, "dk"), _rowmajor(dv, "dv"),

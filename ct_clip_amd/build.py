@@ -7,6 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libctclip_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+# MFMA results that are post-processed by VALU (softmax) stay in VGPRs: the AGPR form costs a copy per register and tile
+FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -31,7 +33,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()

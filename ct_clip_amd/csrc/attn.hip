@@ -17,6 +17,7 @@
 //     of B, so any assignment of contraction indices to slots is valid if A and B agree.)
 //   - O^T = V^T P^T keeps the query as the lane index, so the online-softmax rescale is a per-lane scalar.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -90,6 +91,8 @@ __device__ __forceinline__ void frag_from_regs(Frag<float, 32>& f, const float (
 struct AttnParams {
   const void *q, *k, *v, *qt, *kt, *vt, *o, *dout, *dot;
   const float *bias, *keymask, *lse, *delta;
+  const float* bias_tab;   // relative-position form of the bias: (nclass, H) table, class(i, j) below; replaces `bias`
+  int gh, gw;              // token grid of the sequence (L = gh * gw) when bias_tab is set
   void *out, *dq, *dk, *dv;
   float *lse_out, *dbias;
   int nseq, H, L, Lp;
@@ -97,16 +100,49 @@ struct AttnParams {
   float scale;
 };
 
+// Relative-position bias (attention.py:257-276): bias[h][i][j] = tab[class(i, j)][h] with class(i, j) = (iy - jy + gh - 1) (2 gw - 1)
+// + (ix - jx + gw - 1) = u(i) - u(j) + const for u(t) = (t / gw) (2 gw - 1) + t % gw.  The expanded (H, L, L) f32 matrix was half of
+// all the L2 traffic of the attention kernels (4 KB per 32 x 32 score tile and wave, re-read for every sequence); the table of one
+// head is 8.8 KB at 24 x 24 tokens and lives in LDS, one gather per score.
+constexpr int REL_MAXCLS = 4096, REL_MAXL = 1024;
+struct RelLds {
+  float tab[REL_MAXCLS];
+  __attribute__((aligned(16))) uint16_t u[REL_MAXL + 32];
+};
+// whole workgroup; call before any early return
+__device__ __forceinline__ void rel_stage(RelLds& rel, const AttnParams& p, int h, float mul = 1.f) {
+  if (!p.bias_tab) return;                       // workgroup-uniform
+  const int ncls = (2 * p.gh - 1) * (2 * p.gw - 1);
+  for (int i = threadIdx.x; i < ncls; i += blockDim.x) rel.tab[i] = p.bias_tab[(int64_t)i * p.H + h] * mul;
+  for (int i = threadIdx.x; i < p.L + 32; i += blockDim.x) {
+    const int t = i < p.L ? i : p.L - 1;         // positions past L alias the last token: any valid class (they are masked)
+    rel.u[i] = (uint16_t)((t / p.gw) * (2 * p.gw - 1) + t % p.gw);
+  }
+  __syncthreads();
+}
+
 // scores of one 32x32 tile in "lane = column c, regs = rows slot_index(r, half)" layout -> logits
 template <bool ROWS_ARE_KEYS>
-__device__ __forceinline__ void tile_logits(float (&val)[16], const f32x16& s, const AttnParams& p, int seq, int h, int col_idx,
-                                            int row_base, int half) {
+__device__ __forceinline__ void tile_logits(float (&val)[16], const f32x16& s, const AttnParams& p, const RelLds& rel, int seq, int h,
+                                            int col_idx, int row_base, int half) {
   // ROWS_ARE_KEYS: column = query (col_idx), rows = keys.  else: column = key, rows = queries.
   const int L = p.L;
   float add[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) add[r] = 0.f;
-  if (p.bias) {   // wave-uniform branch; the loads inside are unconditional (indices clamped)
+  if (p.bias_tab) {
+    const int ucol = rel.u[col_idx < L ? col_idx : L - 1];
+    const int c0 = (p.gh - 1) * (2 * p.gw - 1) + (p.gw - 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(rel.u + row_base + 16 * g + 8 * half);   // 8 consecutive rows (broadcast read)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int urow = (int)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        add[8 * g + e] = rel.tab[ROWS_ARE_KEYS ? ucol - urow + c0 : urow - ucol + c0];
+      }
+    }
+  } else if (p.bias) {   // wave-uniform branch; the loads inside are unconditional (indices clamped)
     if (ROWS_ARE_KEYS && (L & 7) == 0) {
       const int qc = col_idx < L ? col_idx : L - 1;
       const float* brow = p.bias + ((int64_t)h * L + qc) * L;
@@ -149,6 +185,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
   const int L = p.L, Lp = p.Lp;
+  __shared__ RelLds rel;
+  rel_stage(rel, p, h);
   if (qb * 32 >= L) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
@@ -194,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     s = mma(s, kf, qf);
     float val[16];
-    tile_logits<true>(val, s, p, seq, h, qi, kb * 32, half);
+    tile_logits<true>(val, s, p, rel, seq, h, qi, kb * 32, half);
     float mx = val[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
@@ -242,6 +280,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
   const int L = p.L, Lp = p.Lp;
+  __shared__ RelLds rel;
+  rel_stage(rel, p, h);
   if (qb * 32 >= L) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     s = mma(s, kf, qf);
     dp = mma(dp, vf, dof);
     float val[16], ds[16];
-    tile_logits<true>(val, s, p, seq, h, qi, kb * 32, half);
+    tile_logits<true>(val, s, p, rel, seq, h, qi, kb * 32, half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kj = kb * 32 + slot_index(r, half);
@@ -347,7 +387,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_kernel(AttnParams p, float
     const int kj = kb * 32 + slot_index(r, half);
     ok[r] = qi < L && kj < L;
     const int kc = kj < L ? kj : L - 1;
-    add[r] = p.bias ? p.bias[((int64_t)h * L + qic) * L + kc] : 0.f;
+    if (p.bias_tab) {
+      const int cls = (qic / p.gw - kc / p.gw + p.gh - 1) * (2 * p.gw - 1) + (qic % p.gw - kc % p.gw + p.gw - 1);
+      add[r] = p.bias_tab[(int64_t)cls * p.H + h];
+    } else add[r] = p.bias ? p.bias[((int64_t)h * L + qic) * L + kc] : 0.f;
   }
   float acc[16];
 #pragma unroll
@@ -395,11 +438,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_kernel(AttnParams p, float
   }
 }
 
-__global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nsplit, int64_t n) {
+__global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nsplit, int64_t n, int accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float t = 0.f;
     for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + i];
-    dbias[i] += t;
+    dbias[i] = accumulate ? dbias[i] + t : t;
   }
 }
 
@@ -409,6 +452,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
   const int L = p.L, Lp = p.Lp;
+  __shared__ RelLds rel;
+  rel_stage(rel, p, h);
   if (jb * 32 >= L) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int kj = jb * 32 + c;
@@ -457,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     s = mma(s, qf, kf);     // D[query rho][key c]
     dp = mma(dp, dof, vf);
     float val[16], pr[16], ds[16];
-    tile_logits<false>(val, s, p, seq, h, kj, qb * 32, half);
+    tile_logits<false>(val, s, p, rel, seq, h, kj, qb * 32, half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = qb * 32 + slot_index(r, half);
@@ -491,6 +536,463 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         store8(dK + i * 32 + 16 * g + 8 * half, a8);
         store8(dV + i * 32 + 16 * g + 8 * half, b8);
       }
+  }
+}
+
+// FAST path of the LDS-shared kernels (decided per launch): L % 32 == 0 (every tile is full: no masks), no key-padding mask, bias
+// absent or a relative-position table with gw % 8 == 0.  PMC showed these kernels VALU-bound (291 VALU instructions per 32 x 32 tile
+// and wave in the forward, ~4 clk each, SQ_ACTIVE_INST_VALU = 64 % of the wall time), so the fast path is a VALU diet:
+//  * logits in the log2 domain (scale and table pre-multiplied by log2 e): exp2 is the hardware instruction, no multiply per element;
+//  * the 8 keys of a fragment run lie in one image row when gw % 8 == 0, so their bias classes are CONSECUTIVE: one index per run
+//    and eight LDS reads with immediate offsets instead of an unpack, a subtract and a shift per element;
+//  * no bounds selects; the accumulator rescale is skipped while no lane's running maximum moved;
+//  * MFMA results stay in VGPRs (-mllvm -amdgpu-mfma-vgpr-form for this file): the AGPR form cost ~96 copies per tile.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+template <bool ROWS_ARE_KEYS>
+__device__ __forceinline__ void tile_logits_fast(float (&val)[16], const f32x16& s, const AttnParams& p, const RelLds& rel, int col_idx,
+                                                 int row_base, int half, float scale2) {
+  if (p.bias_tab) {
+    const int ucol = rel.u[col_idx];
+    const int c0 = (p.gh - 1) * (2 * p.gw - 1) + (p.gw - 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int urow0 = rel.u[row_base + 16 * g + 8 * half];
+      if (ROWS_ARE_KEYS) {
+        const float* b = rel.tab + (ucol - urow0 + c0 - 7);      // class of key e = class of key 0 - e
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[8 * g + e] = fmaf(s[8 * g + e], scale2, b[7 - e]);
+      } else {
+        const float* b = rel.tab + (urow0 - ucol + c0);          // class of query e = class of query 0 + e
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[8 * g + e] = fmaf(s[8 * g + e], scale2, b[e]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) val[r] = s[r] * scale2;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// LDS-shared variants for the CTViT shape (bf16, d_head 32, L >= 128).  The four waves of a workgroup own four neighbouring
+// 32-row blocks of the SAME (sequence, head) and walk the other axis in lockstep, so the operand tiles of a step (32 rows x 64 B
+// each) are fetched ONCE per workgroup -- one 16-byte load per thread -- into a double-buffered LDS ring and read from there by all
+// four waves.  The register-only kernels above re-read every tile per wave: 4-6 KB of L2 traffic and ~200 line lookups per wave
+// and step made them L2 / address-path bound (358 us for the 65-GFLOP spatial forward without bias).
+// LDS rows are 80 B apart (64 B of data): the sixteen rows one ds_read_b128 service group touches then start in sixteen different
+// 16-byte bank groups (20 r mod 64 is a permutation for the row sets of the fragment layout).
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int SROW = 80, STILE = 32 * SROW;
+
+__device__ __forceinline__ void lds_frag(Frag<bf16_t, 32>& f, const char* tile, int ar, int half) {
+  const char* r = tile + ar * SROW + half * 16;
+  f.v[0] = *reinterpret_cast<const bf16x8*>(r);
+  f.v[1] = *reinterpret_cast<const bf16x8*>(r + 32);
+}
+// source of this thread's 16 bytes of a staged tile.  Row-major operand (rows = tokens of the tile): `row0` = first token.
+__device__ __forceinline__ const bf16_t* src_rows(const bf16_t* base, int64_t seq_row0, int tok0, int L, int64_t ld, int hcol, int srow, int schunk) {
+  int t = tok0 + srow;
+  t = t < L ? t : L - 1;                                   // clamped (never branch around a load); masked by the consumer
+  return base + (seq_row0 + t) * ld + hcol + schunk * 8;
+}
+// transposed copy (rows = head dims, columns = tokens): xt[(seq, h)][d][Lp]
+__device__ __forceinline__ const bf16_t* src_cols(const bf16_t* base_sh, int tok0, int Lp, int srow, int schunk) {
+  int c = tok0 + schunk * 8;
+  c = c + 8 <= Lp ? c : Lp - 8;
+  return base_sh + (int64_t)srow * Lp + c;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int L = p.L, Lp = p.Lp;
+  const int nkb = (L + 31) / 32;
+  __shared__ RelLds rel;
+  __shared__ __attribute__((aligned(16))) char tiles[2][2][STILE];      // [buffer][K, V^T]
+  rel_stage(rel, p, h, FAST ? LOG2E : 1.f);
+  const float scale2 = p.scale * LOG2E;
+  const int qb_raw = blockIdx.x * 4 + wave;
+  const bool active = qb_raw * 32 < L;
+  const int qb = active ? qb_raw : nkb - 1;                // idle waves shadow the last block: they must keep the barriers
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* Vt = reinterpret_cast<const T*>(p.vt) + ((int64_t)seq * p.H + h) * D * Lp;
+  const int qic = qi < L ? qi : L - 1;
+  Frag<T, D> qf;
+  frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
+
+  // staging role of this thread: tile (0 = K rows, 1 = V^T rows), row, 16-byte chunk
+  const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
+  auto gsrc = [&](int kb) {
+    const T* a = src_rows(K, (int64_t)seq * L, kb * 32, L, p.ldk, h * D, srow, schunk);
+    const T* b = src_cols(Vt, kb * 32, Lp, srow, schunk);
+    return stile == 0 ? a : b;
+  };
+  char* sdst = &tiles[0][stile][0] + srow * SROW + schunk * 16;
+  u32x4 staged = *reinterpret_cast<const u32x4*>(gsrc(0));
+  *reinterpret_cast<u32x4*>(sdst) = staged;
+  __syncthreads();
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int buf = kb & 1;
+    staged = *reinterpret_cast<const u32x4*>(gsrc(kb + 1 < nkb ? kb + 1 : kb));     // next tiles in flight under this step
+    Frag<T, D> kf, vf;
+    lds_frag(kf, tiles[buf][0], ar, half);
+    lds_frag(vf, tiles[buf][1], ar, half);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    s = mma(s, kf, qf);
+    float val[16];
+    if (FAST) tile_logits_fast<true>(val, s, p, rel, qi, kb * 32, half, scale2);
+    else tile_logits<true>(val, s, p, rel, seq, h, qi, kb * 32, half);
+    float mx = val[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float mnew = fmaxf(m, mx);
+    if (!FAST && mnew == -INFINITY) mnew = 0.f;
+    const float alpha = FAST ? __builtin_amdgcn_exp2f(m - mnew) : __expf(m - mnew);
+    float pr[16], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pr[r] = FAST ? __builtin_amdgcn_exp2f(val[r] - mnew) : __expf(val[r] - mnew); ps += pr[r]; }
+    lsum = lsum * alpha + ps;
+    Frag<T, 32> pf;
+    frag_from_regs(pf, pr);
+    if (!FAST || __builtin_amdgcn_ballot_w64(mnew != m) != 0) {        // wave-uniform: skip the rescale while no maximum moved
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    }
+    m = mnew;
+    oacc = mma(oacc, vf, pf);
+    *reinterpret_cast<u32x4*>(sdst + (buf ^ 1) * 2 * STILE) = staged;   // every wave finished reading that buffer before the last barrier
+    __syncthreads();
+  }
+  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  if (active && qi < L) {
+    const float inv = 1.f / l;
+    T* O = reinterpret_cast<T*>(p.out) + ((int64_t)seq * L + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = oacc[8 * g + e] * inv;
+      store8(O + 16 * g + 8 * half, o8);
+    }
+    if (half == 0 && p.lse_out) p.lse_out[((int64_t)seq * p.H + h) * L + qi] = FAST ? (m + __log2f(l)) * LN2 : m + __logf(l);
+  }
+}
+
+// (A fused table-gradient variant of this kernel -- dS added to an LDS copy of the table with ds_add_f32, one flush per workgroup
+// -- was measured and dropped: LDS float atomics retire about one LANE per 3 clk per CU, 510 M of them per layer cost 2.8 ms against
+// 0.75 ms for the separate attn_bwd_dbias_kernel pass.)
+template <bool FAST>
+__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y;
+  const int L = p.L, Lp = p.Lp;
+  const int nkb = (L + 31) / 32;
+  __shared__ RelLds rel;
+  __shared__ __attribute__((aligned(16))) char tiles[2][3][STILE];      // [buffer][K, V, K^T]
+  rel_stage(rel, p, h, FAST ? LOG2E : 1.f);
+  const float scale2 = p.scale * LOG2E;
+  const int seq = blockIdx.z;
+  const int qb_raw = blockIdx.x * 4 + wave;
+  const bool active = qb_raw * 32 < L;
+  const int qb = active ? qb_raw : nkb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  const T* Kt = reinterpret_cast<const T*>(p.kt) + ((int64_t)seq * p.H + h) * D * Lp;
+  const T* dO = reinterpret_cast<const T*>(p.dout);
+  const int qic = qi < L ? qi : L - 1;
+  Frag<T, D> qf, dof;
+  frag_load(qf, Q + ((int64_t)seq * L + qic) * p.ldq + h * D, half, D);
+  frag_load(dof, dO + ((int64_t)seq * L + qic) * p.lddo + h * D, half, D);
+  const float lse = p.lse[((int64_t)seq * p.H + h) * L + qic] * (FAST ? LOG2E : 1.f);
+  const float delta = p.delta[((int64_t)seq * p.H + h) * L + qic];
+
+  const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
+  auto gsrc0 = [&](int kb) {                                  // pass 0: K (threads 0-127) and V (128-255)
+    const T* a = src_rows(K, (int64_t)seq * L, kb * 32, L, p.ldk, h * D, srow, schunk);
+    const T* b = src_rows(V, (int64_t)seq * L, kb * 32, L, p.ldv, h * D, srow, schunk);
+    return stile == 0 ? a : b;
+  };
+  auto gsrc1 = [&](int kb) { return src_cols(Kt, kb * 32, Lp, srow, schunk); };   // pass 1: K^T, by every thread (the upper half's copy is unused)
+  char* sdst0 = &tiles[0][stile][0] + srow * SROW + schunk * 16;
+  char* sdst1 = &tiles[0][2][0] + srow * SROW + schunk * 16;
+  u32x4 st0 = *reinterpret_cast<const u32x4*>(gsrc0(0)), st1 = *reinterpret_cast<const u32x4*>(gsrc1(0));
+  *reinterpret_cast<u32x4*>(sdst0) = st0;
+  if (stile == 0) *reinterpret_cast<u32x4*>(sdst1) = st1;
+  __syncthreads();
+
+  f32x16 dqacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int buf = kb & 1, kbn = kb + 1 < nkb ? kb + 1 : kb;
+    st0 = *reinterpret_cast<const u32x4*>(gsrc0(kbn));
+    st1 = *reinterpret_cast<const u32x4*>(gsrc1(kbn));
+    Frag<T, D> kf, vf, ktf;
+    lds_frag(kf, tiles[buf][0], ar, half);
+    lds_frag(vf, tiles[buf][1], ar, half);
+    lds_frag(ktf, tiles[buf][2], ar, half);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, kf, qf);
+    dp = mma(dp, vf, dof);
+    float val[16], ds[16];
+    if (FAST) {
+      tile_logits_fast<true>(val, s, p, rel, qi, kb * 32, half, scale2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(val[r] - lse) * (dp[r] - delta);
+    } else {
+      tile_logits<true>(val, s, p, rel, seq, h, qi, kb * 32, half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = kb * 32 + slot_index(r, half);
+        const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
+        ds[r] = pr * (dp[r] - delta);
+      }
+    }
+    Frag<T, 32> dsf;
+    frag_from_regs(dsf, ds);
+    dqacc = mma(dqacc, ktf, dsf);
+    *reinterpret_cast<u32x4*>(sdst0 + (buf ^ 1) * 3 * STILE) = st0;
+    if (stile == 0) *reinterpret_cast<u32x4*>(sdst1 + (buf ^ 1) * 3 * STILE) = st1;
+    __syncthreads();
+  }
+  if (active && qi < L) {
+    T* dQ = reinterpret_cast<T*>(p.dq) + ((int64_t)seq * L + qi) * p.lddq + h * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = dqacc[8 * g + e] * p.scale;
+      store8(dQ + 16 * g + 8 * half, o8);
+    }
+  }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int L = p.L, Lp = p.Lp;
+  const int nqb = (L + 31) / 32;
+  __shared__ RelLds rel;
+  __shared__ __attribute__((aligned(16))) char tiles[2][4][STILE];      // [buffer][Q, dO, Q^T, dO^T]
+  __shared__ float stats[2][2][32];                                      // [buffer][lse, delta][query of the tile]
+  rel_stage(rel, p, h, FAST ? LOG2E : 1.f);
+  const float scale2 = p.scale * LOG2E;
+  const int jb_raw = blockIdx.x * 4 + wave;
+  const bool active = jb_raw * 32 < L;
+  const int jb = active ? jb_raw : nqb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int kj = jb * 32 + c;
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  const T* dO = reinterpret_cast<const T*>(p.dout);
+  const T* Qt = reinterpret_cast<const T*>(p.qt) + ((int64_t)seq * p.H + h) * D * Lp;
+  const T* dOt = reinterpret_cast<const T*>(p.dot) + ((int64_t)seq * p.H + h) * D * Lp;
+  const int kjc = kj < L ? kj : L - 1;
+  Frag<T, D> kf, vf;
+  frag_load(kf, K + ((int64_t)seq * L + kjc) * p.ldk + h * D, half, D);
+  frag_load(vf, V + ((int64_t)seq * L + kjc) * p.ldv + h * D, half, D);
+  const int64_t statbase = ((int64_t)seq * p.H + h) * L;
+
+  const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
+  auto gsrc0 = [&](int qb) {                                  // pass 0: Q (threads 0-127) and dO (128-255)
+    const T* a = src_rows(Q, (int64_t)seq * L, qb * 32, L, p.ldq, h * D, srow, schunk);
+    const T* b = src_rows(dO, (int64_t)seq * L, qb * 32, L, p.lddo, h * D, srow, schunk);
+    return stile == 0 ? a : b;
+  };
+  auto gsrc1 = [&](int qb) {                                  // pass 1: Q^T and dO^T
+    const T* a = src_cols(Qt, qb * 32, Lp, srow, schunk);
+    const T* b = src_cols(dOt, qb * 32, Lp, srow, schunk);
+    return stile == 0 ? a : b;
+  };
+  auto gstat = [&](int qb) {                                  // threads 0-31: lse, 32-63: delta of the tile's 32 queries
+    int q = qb * 32 + (threadIdx.x & 31);
+    q = q < L ? q : L - 1;
+    return ((threadIdx.x & 32) ? p.delta : p.lse) + statbase + q;
+  };
+  char* sdst0 = &tiles[0][stile][0] + srow * SROW + schunk * 16;
+  char* sdst1 = &tiles[0][2 + stile][0] + srow * SROW + schunk * 16;
+  float* sstat = &stats[0][(threadIdx.x >> 5) & 1][threadIdx.x & 31];
+  u32x4 st0 = *reinterpret_cast<const u32x4*>(gsrc0(0)), st1 = *reinterpret_cast<const u32x4*>(gsrc1(0));
+  const float smul = (FAST && !(threadIdx.x & 32)) ? LOG2E : 1.f;   // lse is kept in the log2 domain on the fast path
+  float sv = *gstat(0) * smul;
+  *reinterpret_cast<u32x4*>(sdst0) = st0;
+  *reinterpret_cast<u32x4*>(sdst1) = st1;
+  if (threadIdx.x < 64) *sstat = sv;
+  __syncthreads();
+
+  f32x16 dkacc, dvacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int buf = qb & 1, qbn = qb + 1 < nqb ? qb + 1 : qb;
+    st0 = *reinterpret_cast<const u32x4*>(gsrc0(qbn));
+    st1 = *reinterpret_cast<const u32x4*>(gsrc1(qbn));
+    sv = *gstat(qbn) * smul;
+    Frag<T, D> qf, dof, qtf, dotf;
+    lds_frag(qf, tiles[buf][0], ar, half);
+    lds_frag(dof, tiles[buf][1], ar, half);
+    lds_frag(qtf, tiles[buf][2], ar, half);
+    lds_frag(dotf, tiles[buf][3], ar, half);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, qf, kf);     // D[query rho][key c]
+    dp = mma(dp, dof, vf);
+    float val[16], pr[16], ds[16];
+    if (FAST) tile_logits_fast<false>(val, s, p, rel, kj, qb * 32, half, scale2);
+    else tile_logits<false>(val, s, p, rel, seq, h, kj, qb * 32, half);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int sl = slot_index(r, half);
+      const int qi = qb * 32 + sl;
+      const float lse = stats[buf][0][sl], delta = stats[buf][1][sl];
+      if (FAST) pr[r] = __builtin_amdgcn_exp2f(val[r] - lse);
+      else pr[r] = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
+      ds[r] = pr[r] * (dp[r] - delta);
+    }
+    Frag<T, 32> pf, dsf;
+    frag_from_regs(pf, pr);
+    frag_from_regs(dsf, ds);
+    dvacc = mma(dvacc, dotf, pf);
+    dkacc = mma(dkacc, qtf, dsf);
+    *reinterpret_cast<u32x4*>(sdst0 + (buf ^ 1) * 4 * STILE) = st0;
+    *reinterpret_cast<u32x4*>(sdst1 + (buf ^ 1) * 4 * STILE) = st1;
+    if (threadIdx.x < 64) sstat[(buf ^ 1) * 64] = sv;
+    __syncthreads();
+  }
+  if (active && kj < L) {
+    T* dK = reinterpret_cast<T*>(p.dk) + ((int64_t)seq * L + kj) * p.lddk + h * D;
+    T* dV = reinterpret_cast<T*>(p.dv) + ((int64_t)seq * L + kj) * p.lddv + h * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float a8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a8[e] = dkacc[8 * g + e] * p.scale; b8[e] = dvacc[8 * g + e]; }
+      store8(dK + 16 * g + 8 * half, a8);
+      store8(dV + 16 * g + 8 * half, b8);
+    }
+  }
+}
+
+// dBias for the CTViT shape, workgroup-shared: a workgroup owns one query block and FOUR neighbouring key blocks of one head (one
+// (query, key) tile pair per wave) and walks a strided subset of the sequences.  Per sequence the ten operand tiles (Q, dO of the
+// query block; K, V of the four key blocks) are staged once through LDS with five coalesced 16-byte loads per thread; the
+// register-only attn_bwd_dbias_kernel issues eight scattered loads per lane and sequence and waits for them more than half of its
+// time (SQ_WAIT_INST_ANY 54 % of SQ_WAVE_CYCLES).  Same fast-path conventions as above (log2 domain, full tiles only).
+__global__ __launch_bounds__(256) void attn_bwd_dbias_lds_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
+  typedef bf16_t T;
+  constexpr int D = 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nkb = L / 32, ngrp = (nkb + 3) / 4;
+  const int qb = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
+  const int kb_raw = kg * 4 + wave;
+  const bool active = kb_raw < nkb;
+  const int kb = active ? kb_raw : nkb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  __shared__ __attribute__((aligned(16))) char tiles[2][10][STILE];     // [buffer][Q, dO, K x4, V x4]
+  __shared__ float stats[2][2][32];                                      // [buffer][lse * log2 e, delta][query of the block]
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  const T* dO = reinterpret_cast<const T*>(p.dout);
+
+  float add[16], acc[16];                                                // loop-invariant additive logits of this wave's tile, log2 domain
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kj = kb * 32 + slot_index(r, half);
+    float a = 0.f;
+    if (p.bias_tab) {
+      const int cls = (qi / p.gw - kj / p.gw + p.gh - 1) * (2 * p.gw - 1) + (qi % p.gw - kj % p.gw + p.gw - 1);
+      a = p.bias_tab[(int64_t)cls * p.H + h];
+    } else if (p.bias) a = p.bias[((int64_t)h * L + qi) * L + kj];
+    add[r] = a * LOG2E;
+    acc[r] = 0.f;
+  }
+  const float scale2 = p.scale * LOG2E;
+
+  // staging: pass i (0..4) fills tiles 2i and 2i+1 (threads 0-127 / 128-255)
+  const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
+  const T* sbase[5]; int64_t sld[5]; int stok[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int tt = 2 * i + stile;
+    if (tt == 0) { sbase[i] = Q; sld[i] = p.ldq; stok[i] = qb * 32; }
+    else if (tt == 1) { sbase[i] = dO; sld[i] = p.lddo; stok[i] = qb * 32; }
+    else if (tt < 6) { sbase[i] = K; sld[i] = p.ldk; stok[i] = (kg * 4 + tt - 2) * 32; }
+    else { sbase[i] = V; sld[i] = p.ldv; stok[i] = (kg * 4 + tt - 6) * 32; }
+  }
+  auto gstat = [&](int seq) {                                  // threads 0-31: lse, 32-63: delta of the block's 32 queries
+    return ((threadIdx.x & 32) ? p.delta : p.lse) + ((int64_t)seq * p.H + h) * L + qb * 32 + (threadIdx.x & 31);
+  };
+  const float smul = (threadIdx.x & 32) ? 1.f : LOG2E;
+  char* sdst = &tiles[0][stile][0] + srow * SROW + schunk * 16;          // + 2 * i * STILE per pass, + 10 * STILE per buffer
+  float* sstat = &stats[0][(threadIdx.x >> 5) & 1][threadIdx.x & 31];
+
+  int seq = split;
+  if (seq >= p.nseq) return;                                             // workgroup-uniform
+  u32x4 st[5];
+  float sv;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)seq * L, stok[i], L, sld[i], h * D, srow, schunk));
+  sv = *gstat(seq) * smul;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) *reinterpret_cast<u32x4*>(sdst + 2 * i * STILE) = st[i];
+  if (threadIdx.x < 64) *sstat = sv;
+  __syncthreads();
+  for (int it = 0; seq < p.nseq; seq += nsplit, ++it) {
+    const int buf = it & 1;
+    const int sn = seq + nsplit < p.nseq ? seq + nsplit : seq;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)sn * L, stok[i], L, sld[i], h * D, srow, schunk));
+    sv = *gstat(sn) * smul;
+    Frag<T, D> qf, dof, kf, vf;
+    lds_frag(qf, tiles[buf][0], c, half);          // B operands: the lane's own query row (no pi32)
+    lds_frag(dof, tiles[buf][1], c, half);
+    lds_frag(kf, tiles[buf][2 + wave], ar, half);
+    lds_frag(vf, tiles[buf][6 + wave], ar, half);
+    const float lse2 = stats[buf][0][c], delta = stats[buf][1][c];
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, kf, qf);
+    dp = mma(dp, vf, dof);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(__builtin_amdgcn_exp2f(fmaf(s[r], scale2, add[r]) - lse2), dp[r] - delta, acc[r]);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<u32x4*>(sdst + (buf ^ 1) * 10 * STILE + 2 * i * STILE) = st[i];
+    if (threadIdx.x < 64) sstat[(buf ^ 1) * 64] = sv;
+    __syncthreads();
+  }
+  if (active) {
+    float* dst = dbias_part + (((int64_t)split * p.H + h) * L + qi) * L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[kb * 32 + slot_index(r, half)] = acc[r];
   }
 }
 
@@ -638,7 +1140,28 @@ int launch_attn(int which, const AttnParams& p, hipStream_t stream) {
   return ctclip_check_launch("attention");
 }
 
+bool attn_lds_enabled() {
+  static int use_lds = -1;
+  if (use_lds < 0) { const char* e = getenv("CTCLIP_ATTN_LDS"); use_lds = (e && e[0] == '0') ? 0 : 1; }
+  return use_lds != 0;
+}
+
 int dispatch_attn(int which, const AttnParams& p, int D, int dtype, hipStream_t stream) {
+  const bool use_lds = attn_lds_enabled();
+  if (use_lds && dtype == DT_BF16 && D == 32 && p.L >= 128 && !p.dbias) {   // CTViT spatial shape: workgroup-shared operand tiles
+    dim3 grid((unsigned)cdiv(cdiv(p.L, 32), 4), p.H, p.nseq), block(256);
+    const bool fast = (p.L % 32) == 0 && !p.keymask && !p.bias && (!p.bias_tab || (p.gw % 8) == 0);
+    if (fast) {
+      if (which == 0) hipLaunchKernelGGL(attn_fwd_lds_kernel<true>, grid, block, 0, stream, p);
+      else if (which == 1) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<true>, grid, block, 0, stream, p);
+      else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<true>, grid, block, 0, stream, p);
+    } else {
+      if (which == 0) hipLaunchKernelGGL(attn_fwd_lds_kernel<false>, grid, block, 0, stream, p);
+      else if (which == 1) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<false>, grid, block, 0, stream, p);
+      else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<false>, grid, block, 0, stream, p);
+    }
+    return ctclip_check_launch("attention (lds)");
+  }
   if (dtype == DT_BF16 && D == 32) return launch_attn<bf16_t, 32>(which, p, stream);
   if (dtype == DT_BF16 && D == 64) return launch_attn<bf16_t, 64>(which, p, stream);
   if (dtype == DT_F32 && D == 32) return launch_attn<float, 32>(which, p, stream);
@@ -714,12 +1237,25 @@ extern "C" int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* in
 // softmax(scale * q k^T + bias[h] + keymask[seq]) v   (attention.py:156-178 / HF BertSelfAttention).
 // q,k: (nseq*L, >= H*D) row-major views with row strides ldq/ldk; vt: ctclip_head_transpose of v.
 // out (nseq*L, ldo); lse (nseq,H,L) f32 (may be null for inference).
-extern "C" int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, const float* keymask, void* out,
-                               float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
-                               int dtype, hipStream_t stream) {
+// bias: (H, L, L) f32 additive logits, or -- when bias_gh > 0 -- the relative-position table (nclass, H) of a bias_gh x bias_gw token
+// grid (L = bias_gh * bias_gw; see RelLds), which the kernels gather from LDS instead of streaming the expanded matrix.
+static int set_bias(AttnParams& p, const float* bias, int bias_gh, int bias_gw, int L) {
+  if (bias_gh <= 0) { p.bias = bias; return 0; }
+  if (!bias || bias_gw <= 0 || bias_gh * bias_gw != L || L > REL_MAXL || (2 * bias_gh - 1) * (2 * bias_gw - 1) > REL_MAXCLS) {
+    ctclip_set_error("attention: relative bias table needs L = gh * gw <= 1024 and (2gh-1)(2gw-1) <= 4096");
+    return CTCLIP_EBADARG;
+  }
+  p.bias = nullptr; p.bias_tab = bias; p.gh = bias_gh; p.gw = bias_gw;
+  return 0;
+}
+
+extern "C" int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw,
+                               const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq,
+                               int64_t ldk, int64_t ldo, float scale, int dtype, hipStream_t stream) {
   if (!q || !k || !vt || !out || bad_ld(ldq) || bad_ld(ldk) || bad_ld(ldo) || Lp % 8 || Lp < L) { ctclip_set_error("attn_fwd: bad args"); return CTCLIP_EBADARG; }
   AttnParams p{};
-  p.q = q; p.k = k; p.vt = vt; p.bias = bias; p.keymask = keymask; p.out = out; p.lse_out = lse;
+  if (int rc = set_bias(p, bias, bias_gh, bias_gw, L)) return rc;
+  p.q = q; p.k = k; p.vt = vt; p.keymask = keymask; p.out = out; p.lse_out = lse;
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.scale = scale;
   return dispatch_attn(0, p, D, dtype, stream);
 }
@@ -734,13 +1270,16 @@ static int dbias_nsplit(int nseq, int H, int L) {
   return ns;
 }
 // bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs)
-extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)dbias_nsplit(nseq, H, L) * H * L * L * 4; }
+// (+ one slab for the full (H, L, L) gradient that the relative-position mode folds into the table)
+extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)(dbias_nsplit(nseq, H, L) + 1) * H * L * L * 4; }
+extern "C" int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
 
 // Backward.  Needs the transposed copies qt, kt (of q, k) and dot (of dout) and delta = rowsum(dO*O) (computed here
-// into `delta`, (nseq,H,L) f32 scratch).  dbias (H,L,L) f32 is ACCUMULATED with atomics when non-null.
+// into `delta`, (nseq,H,L) f32 scratch).  dbias (H,L,L) f32 is ACCUMULATED when non-null; in the relative-position mode
+// (bias_gh > 0) dbias is the table gradient (nclass, H) and is OVERWRITTEN.
 extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o,
-                               const void* dout, const void* dot, const float* lse, const float* bias, const float* keymask,
-                               float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D,
+                               const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw,
+                               const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk,
                                int64_t lddv, float scale, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!q || !k || !v || !qt || !kt || !o || !dout || !dot || !lse || !delta || !dq || !dk || !dv) { ctclip_set_error("attn_bwd: null arg"); return CTCLIP_EBADARG; }
@@ -758,8 +1297,9 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     if (rc) return rc;
   }
   AttnParams p{};
+  if (int rc0 = set_bias(p, bias, bias_gh, bias_gw, L)) return rc0;
   p.q = q; p.k = k; p.v = v; p.qt = qt; p.kt = kt; p.o = o; p.dout = dout; p.dot = dot; p.lse = lse; p.delta = delta;
-  p.bias = bias; p.keymask = keymask; p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias;
+  p.keymask = keymask; p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias;
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo;
   p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.scale = scale;
   int rc;
@@ -770,7 +1310,10 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     const int nkb = (L + 31) / 32;
     dim3 grid((unsigned)((nkb * nkb + 3) / 4), H, ns);
     float* ws = (float*)workspace;
-    if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, ws, ns);
+    if (dtype == DT_BF16 && D == 32 && L >= 128 && (L % 32) == 0 && !keymask && attn_lds_enabled()) {
+      dim3 grid2((unsigned)(nkb * ((nkb + 3) / 4)), H, ns);
+      hipLaunchKernelGGL(attn_bwd_dbias_lds_kernel, grid2, dim3(256), 0, stream, p, ws, ns);
+    } else if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, ws, ns);
     else if (dtype == DT_BF16 && D == 64) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 64>), grid, dim3(256), 0, stream, p, ws, ns);
     else if (dtype == DT_F32 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<float, 32>), grid, dim3(256), 0, stream, p, ws, ns);
     else if (dtype == DT_F32 && D == 64) hipLaunchKernelGGL((attn_bwd_dbias_kernel<float, 64>), grid, dim3(256), 0, stream, p, ws, ns);
@@ -779,9 +1322,14 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     if (rc) return rc;
     const int64_t n = (int64_t)H * L * L;
     int64_t nb = cdiv(n, 256); if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, dbias, ns, n);
+    float* full = p.bias_tab ? ws + (int64_t)ns * n : dbias;     // table mode: full gradient into the extra slab, then fold
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, full, ns, n, p.bias_tab ? 0 : 1);
     rc = ctclip_check_launch("dbias_reduce");
     if (rc) return rc;
+    if (p.bias_tab) {
+      rc = ctclip_cpb_reduce(full, dbias, H, p.gh, p.gw, stream);
+      if (rc) return rc;
+    }
     p.dbias = nullptr;
   }
   rc = dispatch_attn(1, p, D, dtype, stream);

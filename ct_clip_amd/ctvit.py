@@ -116,7 +116,8 @@ class ContinuousPositionBias(nn.Module):
             x = Fn.linear(x, lin.weight, lin.bias, kpad=8 if i == 0 else None)
             if i < n - 1:
                 x = Fn.LeakyFn.apply(x, 0.1)
-        return Fn.CpbExpandFn.apply(x, gh, gw)   # (heads, hw, hw) f32
+        # the attention kernels gather from this (nclass, heads) table; Fn.CpbExpandFn materialises the reference's (heads, hw, hw)
+        return x
 
 
 class Transformer(nn.Module):
@@ -138,7 +139,7 @@ class Transformer(nn.Module):
             ]))
         self.norm_out = LayerNorm(dim)
 
-    def forward(self, x, video_shape, nseq, L, attn_bias=None):
+    def forward(self, x, video_shape, nseq, L, attn_bias=None, bias_grid=None):
         """x: (nseq*L, dim) activation in compute dtype (flat view of the reference's (nseq, L, dim))."""
         b, t, h, w = video_shape
         d = x.shape[1]
@@ -150,7 +151,7 @@ class Transformer(nn.Module):
             q = Fn.linear(xn, attn.to_q.weight)
             kv = Fn.linear(x, attn.to_kv.weight)
             o = Fn.CosineAttnFn.apply(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
-                                      float(attn.scale))
+                                      float(attn.scale), bias_grid)
             x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
             y = Fn.layer_norm(x, ff[0].weight, ff[0].bias)
@@ -245,7 +246,7 @@ class CTViT(nn.Module):
         d = tokens.shape[1]
         video_shape = (b, t, h, w)
         attn_bias = self.spatial_rel_pos_bias(h, w)
-        x = self.enc_spatial_transformer(tokens, video_shape, nseq=b * t, L=h * w, attn_bias=attn_bias)
+        x = self.enc_spatial_transformer(tokens, video_shape, nseq=b * t, L=h * w, attn_bias=attn_bias, bias_grid=(h, w))
         x = Fn.Permute0213Fn.apply(x.view(b, t, h * w, d)).view(-1, d)              # (b t)(h w) -> (b h w) t
         x = self.enc_temporal_transformer(x, video_shape, nseq=b * h * w, L=t, attn_bias=None)
         x = Fn.Permute0213Fn.apply(x.view(b, h * w, t, d)).view(-1, d)              # back to b t h w

@@ -300,24 +300,27 @@ class CosineAttnFn(Function):
     """attention.py:145-178 (self-attention, no null kv): l2norm(q)*q_scale, l2norm(k)*k_scale, sim*8 (+bias), softmax, @v."""
 
     @staticmethod
-    def forward(ctx, q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale):
+    def forward(ctx, q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid=None):
+        """bias: (H, L, L) f32, or -- with bias_grid = (gh, gw) -- the (nclass, H) relative-position table itself."""
         be = B()
         HD = H * D
         k, v = kv[:, :HD], kv[:, HD:]
         qh, qinv = be.qk_norm_fwd(q, q_scale.detach(), H, D)
         kh, kinv = be.qk_norm_fwd(k, k_scale.detach(), H, D)
         vt = be.head_transpose(v, nseq, H, L, D)
-        o, lse = be.attn_fwd(qh, kh, vt, bias, None, nseq, H, L, D, scale)
+        if bias is not None:
+            bias = bias.contiguous()
+        o, lse = be.attn_fwd(qh, kh, vt, bias, None, nseq, H, L, D, scale, bias_grid=bias_grid)
         ctx.save_for_backward(q, kv, qh, kh, qinv, kinv, o, lse, bias if bias is not None else q.new_empty(0))
         ctx.scales = (q_scale, k_scale)
-        ctx.dims = (nseq, L, H, D, scale, bias is not None)
+        ctx.dims = (nseq, L, H, D, scale, bias is not None, bias_grid)
         return o
 
     @staticmethod
     def backward(ctx, do):
         be = B()
         q, kv, qh, kh, qinv, kinv, o, lse, bias = ctx.saved_tensors
-        nseq, L, H, D, scale, has_bias = ctx.dims
+        nseq, L, H, D, scale, has_bias, bias_grid = ctx.dims
         q_scale, k_scale = ctx.scales
         HD = H * D
         do = do.contiguous()
@@ -330,7 +333,7 @@ class CosineAttnFn(Function):
         dkh = torch.empty_like(kh)
         dbias = torch.zeros_like(bias) if (has_bias and ctx.needs_input_grad[4]) else None
         be.attn_bwd(qh, kh, v, qt, kt, o, do, dot, lse, bias if has_bias else None, None, dqh, dkh, dkv[:, HD:], dbias,
-                    nseq, H, L, D, scale)
+                    nseq, H, L, D, scale, bias_grid=bias_grid)
         qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
         dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
         dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
@@ -338,7 +341,7 @@ class CosineAttnFn(Function):
         be.qk_norm_bwd(dqh, q, qinv, q_scale.detach(), dq, dqs, H, D)
         be.qk_norm_bwd(dkh, k, kinv, k_scale.detach(), dkv[:, :HD], dks, H, D)
         return (dq, dkv, None if qs_sink is not None else dqs, None if ks_sink is not None else dks, dbias,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class SdpaFn(Function):

@@ -135,7 +135,9 @@ class RefBackend:
             s = s + keymask[:, None, None, :]
         return qf, kf, s
 
-    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True):
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None):
+        if bias_grid is not None:
+            bias = self.cpb_expand(bias, *bias_grid)
         qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
         lse = torch.logsumexp(s, dim=-1)
         p = torch.exp(s - lse[..., None])
@@ -143,7 +145,9 @@ class RefBackend:
         o = torch.einsum("shij,shjd->shid", p, v).permute(0, 2, 1, 3).reshape(nseq * L, H * D)
         return o.to(q.dtype).contiguous(), lse
 
-    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale):
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None):
+        if bias_grid is not None:
+            bias = self.cpb_expand(bias, *bias_grid)
         qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
         p = torch.exp(s - lse[..., None])
         vf = _f(v[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
@@ -160,7 +164,10 @@ class RefBackend:
         dk[:, :H * D] = back(dkf).to(dk.dtype)
         dv[:, :H * D] = back(dvf).to(dv.dtype)
         if dbias is not None:
-            dbias += ds.sum(0)
+            if bias_grid is not None:
+                dbias.copy_(self.cpb_reduce(ds.sum(0), *bias_grid))   # table mode: overwritten (ctclip_attn_bwd)
+            else:
+                dbias += ds.sum(0)
 
     # ---- elementwise
     def geglu_fwd(self, u):

@@ -169,7 +169,10 @@ def test_peg_fwd_bwd(hip, ref, dtype, shape):
 @pytest.mark.parametrize("nseq,H,L,D,use_bias,use_mask", [(2, 4, 16, 32, True, False), (3, 2, 9, 32, True, False),
                                                           (4, 8, 24, 32, False, False), (2, 8, 576, 32, True, False),
                                                           (2, 12, 128, 64, False, True), (3, 4, 50, 64, False, True),
-                                                          (64, 2, 2, 32, False, False)])
+                                                          (64, 2, 2, 32, False, False),
+                                                          # workgroup-shared (LDS) kernels: fast path, ragged length with idle waves, bias
+                                                          (2, 4, 256, 32, False, False), (3, 2, 200, 32, False, False),
+                                                          (2, 4, 160, 32, True, False), (2, 3, 136, 32, False, True)])
 def test_attention_fwd_bwd(hip, ref, dtype, nseq, H, L, D, use_bias, use_mask):
     M, HD = nseq * L, H * D
     kv = rnd(M, 2 * HD, dtype=dtype, seed=1, scale=0.5)
@@ -203,6 +206,35 @@ def test_attention_fwd_bwd(hip, ref, dtype, nseq, H, L, D, use_bias, use_mask):
     close(dq, dqr, **t); close(dk, dkr, **t); close(dkv[:, HD:], dvr, **t)
     if use_bias:
         close(dbias, dbr, rtol=t["rtol"], atol=t["atol"] * nseq ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nseq,H,gh,gw,D", [(2, 4, 4, 6, 32), (3, 8, 24, 24, 32), (2, 2, 5, 7, 64), (5, 3, 1, 9, 32)])
+def test_attention_relative_bias_table(hip, ref, dtype, nseq, H, gh, gw, D):
+    """The attention kernels gather the continuous position bias from its (nclass, H) table (LDS) instead of reading the expanded
+    (H, L, L) matrix; dbias comes back folded into the table."""
+    L, HD = gh * gw, H * D
+    M = nseq * L
+    q = torch.nn.functional.normalize(rnd(M, HD, dtype=torch.float32, seed=1).reshape(M, H, D), dim=-1).view(M, HD).to(dtype)
+    k = torch.nn.functional.normalize(rnd(M, HD, dtype=torch.float32, seed=2).reshape(M, H, D), dim=-1).view(M, HD).to(dtype)
+    v, do = rnd(M, HD, dtype=dtype, seed=3, scale=0.5), rnd(M, HD, dtype=dtype, seed=4)
+    tab = rnd((2 * gh - 1) * (2 * gw - 1), H, seed=5)
+    grid, scale = (gh, gw), 8.0
+    vt = hip.head_transpose(v, nseq, H, L, D)
+    o, lse = hip.attn_fwd(q, k, vt, tab, None, nseq, H, L, D, scale, bias_grid=grid)
+    orf, lser = ref.attn_fwd(q, k, vt, tab, None, nseq, H, L, D, scale, bias_grid=grid)
+    close(o, orf, **tol(dtype, (1e-4, 1e-5), (2e-2, 2e-2))); close(lse, lser, **tol(dtype, (1e-4, 1e-4), (1e-2, 3e-2)))
+    # and it is the same function as the expanded-matrix path (the fast path works in the log2 domain: last-bit differences)
+    o2, _ = hip.attn_fwd(q, k, vt, ref.cpb_expand(tab, gh, gw), None, nseq, H, L, D, scale)
+    close(o, o2, **tol(dtype, (1e-5, 1e-6), (1e-2, 4e-3)))
+    qt, kt, dot = (hip.head_transpose(t, nseq, H, L, D) for t in (q, k, do))
+    dq, dk, dv, dtab = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q), torch.full_like(tab, 7.0)
+    hip.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, tab, None, dq, dk, dv, dtab, nseq, H, L, D, scale, bias_grid=grid)
+    dqr, dkr, dvr, dtr = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q), torch.zeros_like(tab)
+    ref.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, tab, None, dqr, dkr, dvr, dtr, nseq, H, L, D, scale, bias_grid=grid)
+    t = tol(dtype, (1e-3, 1e-4), (3e-2, 3e-2))
+    close(dq, dqr, **t); close(dk, dkr, **t); close(dv, dvr, **t)
+    close(dtab, dtr, rtol=t["rtol"], atol=t["atol"] * (nseq * L) ** 0.5)
 
 
 @pytest.mark.parametrize("dtype", DT)
