@@ -143,14 +143,15 @@ class HipBackend:
         _lib.check(rc, "ctclip_layernorm_fwd")
         return y, mean, rstd
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None):
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, add1=None, add2=None):
         rows, cols = x.shape
         assert x.is_contiguous() and dy.is_contiguous()
+        assert all(a is None or (a.is_contiguous() and a.shape == x.shape and a.dtype == x.dtype) for a in (add1, add2))
         dx = torch.empty_like(x)
         nbytes = self.lib.ctclip_layernorm_bwd_workspace(rows, cols)
         ws = self.workspace(x.device, nbytes)
-        rc = self.lib.ctclip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), rows,
-                                           cols, dcode(x.dtype), _p(ws), ws.numel(), _stream())
+        rc = self.lib.ctclip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), _p(add1),
+                                           _p(add2), rows, cols, dcode(x.dtype), _p(ws), ws.numel(), _stream())
         _lib.check(rc, "ctclip_layernorm_bwd")
         return dx
 

@@ -56,13 +56,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ add1) (+ add2),  g = dy * gamma.
+// add1 / add2: gradients that reach the same activation through its other consumers (the residual connection, the k/v projection
+// of the raw tokens): summed here instead of by two elementwise kernels over the 113-MB tensor.
 // Per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy are written to part[block][2][cols].
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
-                                                            float* __restrict__ part, int64_t rows, int cols) {
+                                                            float* __restrict__ part, int64_t rows, int cols,
+                                                            const T* __restrict__ add1, const T* __restrict__ add2) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int cc[NV]; bool ok[NV];
@@ -97,6 +100,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = rs * (a[i][e] - s1 - b[i][e] * s2);
+      if (add1) {       // kernel-uniform
+        float r1[8];
+        load8(add1 + row * cols + cc[i], r1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r1[e];
+      }
+      if (add2) {
+        float r2[8];
+        load8(add2 + row * cols + cc[i], r2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r2[e];
+      }
       if (ok[i]) store8(dx + row * cols + cc[i], o);
     }
   }
@@ -117,22 +132,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] += sum_b part[b][which][c]; block = 64 columns x 4 partial-lanes
+// out[c] += sum_b part[b][which][c]; block = 64 columns x 4 partial-lanes over one chunk of 64 partial rows (grid.y chunks, one
+// f32 atomic per column and chunk).  The first version walked all 1024 partial rows with 16 workgroups: 58 us of pure latency,
+// 76 times per step.
+constexpr int LN_RED_CHUNK = 64;
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, int nblocks, int cols) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int b0 = blockIdx.y * LN_RED_CHUNK, b1 = b0 + LN_RED_CHUNK < nblocks ? b0 + LN_RED_CHUNK : nblocks;
   float t = 0.f;
   if (c < 2 * cols) {
     const int which = c / cols, col = c % cols;
-    for (int b = pl; b < nblocks; b += 4) t += part[((int64_t)b * 2 + which) * cols + col];
+#pragma unroll 4
+    for (int b = b0 + pl; b < b1; b += 4) t += part[((int64_t)b * 2 + which) * cols + col];
   }
   red[pl][threadIdx.x & 63] = t;
   __syncthreads();
   if (pl == 0 && c < 2 * cols) {
     const int which = c / cols, col = c % cols;
     float* dst = which == 0 ? dgamma : dbeta;
-    if (dst) dst[col] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (dst) atomicAdd(dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
@@ -247,10 +267,11 @@ extern "C" int ctclip_layernorm_fwd(const void* x, const float* gamma, const flo
 static int64_t ln_bwd_blocks(int64_t rows) { int64_t nb = cdiv(rows, 8); if (nb > 1024) nb = 1024; return nb < 1 ? 1 : nb; }
 extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) { return ln_bwd_blocks(rows) * 2 * cols * 4; }
 
-// LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
+// LayerNorm backward: dx (+ add1 + add2: optional same-shape gradients of the input's other consumers, see the kernel), and
+// dgamma/dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
 extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                    void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype, void* workspace,
-                                    int64_t workspace_bytes, hipStream_t stream) {
+                                    void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols,
+                                    int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !dx || !mean || !rstd || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_bwd: bad args"); return CTCLIP_EBADARG; }
   const int64_t nb = ln_bwd_blocks(rows);
   const bool want = dgamma || dbeta;
@@ -258,7 +279,7 @@ extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* 
   float* part = want ? (float*)workspace : nullptr;
   const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
   const int nv = (cols + 511) / 512;
-#define LNB(T, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols)
+#define LNB(T, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols, (const T*)add1, (const T*)add2)
 #define LNB_NV(T) do { if (nv == 1) LNB(T, 1); else if (nv == 2) LNB(T, 2); else if (nv == 3) LNB(T, 3); else LNB(T, 4); } while (0)
   if (dtype == DT_F32) LNB_NV(float);
   else if (dtype == DT_BF16) LNB_NV(bf16_t);
@@ -267,7 +288,7 @@ extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* 
 #undef LNB_NV
   int rc = ctclip_check_launch("layernorm_bwd");
   if (rc || !want) return rc;
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64), (unsigned)cdiv(nb, LN_RED_CHUNK)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
   return ctclip_check_launch("ln_partial_reduce");
 }
 

@@ -147,14 +147,14 @@ class Transformer(nn.Module):
             # x = peg(x) + x  -- PEG sees the buffer flat-reinterpreted as (b, t, h, w, d) (attention.py:69-70)
             x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
             # x = attn(x) + x  -- q from LayerNorm(x), k/v from the RAW x (attention.py:139-143)
-            xn = Fn.layer_norm(x, attn.norm.gamma, None)
+            xn, x_kv, x = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)   # the three consumers of x: LayerNorm, to_kv, residual
             q = Fn.linear(xn, attn.to_q.weight)
-            kv = Fn.linear(x, attn.to_kv.weight)
+            kv = Fn.linear(x_kv, attn.to_kv.weight)
             o = Fn.CosineAttnFn.apply(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
                                       float(attn.scale), bias_grid)
             x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
-            y = Fn.layer_norm(x, ff[0].weight, ff[0].bias)
+            y, x = Fn.layer_norm_branch(x, ff[0].weight, ff[0].bias, 1)
             u = Fn.linear_geglu_in(y, ff[1].weight)
             g = Fn.GegluFn.apply(u)
             x = Fn.linear_geglu_out(g, ff[4].weight, residual=x)

@@ -210,6 +210,48 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class LayerNormBranchFn(Function):
+    """y = LayerNorm(x) together with `nviews` pass-through views of x for x's OTHER consumers (the residual connection,
+    the k/v projection of the raw tokens: attention.py:139-143, 324-325).  Routing those uses through this node lets the
+    backward add their gradients inside the LayerNorm backward kernel (ctclip_layernorm_bwd add1/add2) instead of through
+    autograd's elementwise accumulation kernels -- three passes over a 113-MB tensor each, 72 times per step."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, nviews):
+        y, mean, rstd = B().layernorm_fwd(x, gamma.detach() if gamma is not None else None,
+                                          beta.detach() if beta is not None else None, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return (y,) + tuple(x.view_as(x) for _ in range(nviews))
+
+    @staticmethod
+    def backward(ctx, dy, *dviews):
+        x, mean, rstd = ctx.saved_tensors
+        g, b = ctx.gamma, ctx.beta
+        want_g = g is not None and g.requires_grad
+        want_b = b is not None and b.requires_grad
+        gs = sink_of(g) if want_g else None
+        bs = sink_of(b) if want_b else None
+        dgam = (gs if gs is not None else torch.zeros_like(g, dtype=torch.float32)) if want_g else None
+        dbet = (bs if bs is not None else torch.zeros_like(b, dtype=torch.float32)) if want_b else None
+        adds = [d.contiguous() for d in dviews if d is not None]
+        extra = None
+        while len(adds) > 2:                      # the kernel takes two addends
+            extra = adds.pop() if extra is None else extra + adds.pop()
+        if extra is not None:
+            adds[0] = adds[0] + extra
+        if dy is None:
+            dy = torch.zeros_like(x)
+        dx = B().layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet,
+                               adds[0] if len(adds) > 0 else None, adds[1] if len(adds) > 1 else None)
+        return dx, (None if (not want_g or gs is not None) else dgam), (None if (not want_b or bs is not None) else dbet), None, None
+
+
+def layer_norm_branch(x, gamma, beta, nviews, eps=1e-5):
+    """-> (LayerNorm(x), x, ..., x): use the returned views of x wherever the unnormalised tensor is consumed as well."""
+    return LayerNormBranchFn.apply(x, gamma, beta, eps, nviews)
+
+
 # ------------------------------------------------------------------------------------------ patch embedding
 
 class PatchEmbedFn(Function):

@@ -144,7 +144,7 @@ int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols);
 
 /* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. */
-int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* CTViT.to_patch_emb[0:2]: Rearrange 'b c (t pt)(h p1)(w p2) -> b t h w (c pt p1 p2)' + LayerNorm statistics (ctvit.py:171-172). */
 int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, int W, int pt, int p1, int p2, int kpad, float eps, int out_dtype, hipStream_t stream);

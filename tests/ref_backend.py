@@ -54,10 +54,13 @@ class RefBackend:
             y = y + beta
         return y.to(x.dtype), mean, rstd
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None):
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, add1=None, add2=None):
         xh = (_f(x) - mean[:, None]) * rstd[:, None]
         g = _f(dy) * (gamma if gamma is not None else 1.0)
         dx = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+        for a in (add1, add2):
+            if a is not None:
+                dx = dx + _f(a)
         if dgamma is not None:
             dgamma += (_f(dy) * xh).sum(0)
         if dbeta is not None:

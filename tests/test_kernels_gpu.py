@@ -124,6 +124,12 @@ def test_layernorm_fwd_bwd(hip, ref, dtype, rows, cols):
     close(dg, dgr, rtol=1e-3, atol=1e-3 * rows ** 0.5); close(db, dbr, rtol=1e-3, atol=1e-3 * rows ** 0.5)
     y2, _, _ = hip.layernorm_fwd(x, gamma, None, 1e-5)   # gamma-only LayerNorm (attention.py:28-35)
     close(y2, ref.layernorm_fwd(x, gamma, None, 1e-5)[0], **tol(dtype))
+    # gradients of the input's other consumers folded into dx (residual, k/v projection)
+    a1, a2 = rnd(rows, cols, dtype=dtype, seed=5), rnd(rows, cols, dtype=dtype, seed=6)
+    close(hip.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, a1, a2), ref.layernorm_bwd(dy, x, gamma, mr, rr, None, None, a1, a2),
+          **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
+    close(hip.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, a1), ref.layernorm_bwd(dy, x, gamma, mr, rr, None, None, a1),
+          **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
 
 
 @pytest.mark.parametrize("dtype", DT)
