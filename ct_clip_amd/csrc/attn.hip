@@ -438,6 +438,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_kernel(AttnParams p, float
   }
 }
 
+// Relative-position mode: sum the per-split slabs AND fold (H, L, L) into the (nclass, H) table in one pass.  A workgroup takes 16
+// query rows of one head, bins its L x 16 elements in an LDS copy of the table (LDS float atomics are slow -- ~1 lane per 3 clk --
+// but this is 9 K of them per workgroup, not 500 M) and flushes the non-zero bins with global atomics.  Replaces
+// dbias_reduce_kernel + cpb_reduce_kernel (one thread per class walking up to 576 strided elements: 163 us).
+__global__ __launch_bounds__(256) void dbias_fold_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ dtab, int H,
+                                                         int gh, int gw) {
+  __shared__ float bins[REL_MAXCLS];
+  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), h = blockIdx.y;
+  for (int i = threadIdx.x; i < ncls; i += 256) bins[i] = 0.f;
+  __syncthreads();
+  const int64_t n = (int64_t)H * L * L;
+  const int q0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * L; i += 256) {
+    const int qi = q0 + i / L, kj = i % L;
+    if (qi >= L) break;
+    const int64_t off = ((int64_t)h * L + qi) * L + kj;
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + off];
+    atomicAdd(&bins[(qi / gw - kj / gw + gh - 1) * (2 * gw - 1) + (qi % gw - kj % gw + gw - 1)], t);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncls; i += 256)
+    if (bins[i] != 0.f) atomicAdd(dtab + (int64_t)i * H + h, bins[i]);
+}
+
 __global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nsplit, int64_t n, int accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float t = 0.f;
@@ -1322,14 +1347,16 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     if (rc) return rc;
     const int64_t n = (int64_t)H * L * L;
     int64_t nb = cdiv(n, 256); if (nb > 4096) nb = 4096;
-    float* full = p.bias_tab ? ws + (int64_t)ns * n : dbias;     // table mode: full gradient into the extra slab, then fold
-    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, full, ns, n, p.bias_tab ? 0 : 1);
-    rc = ctclip_check_launch("dbias_reduce");
-    if (rc) return rc;
-    if (p.bias_tab) {
-      rc = ctclip_cpb_reduce(full, dbias, H, p.gh, p.gw, stream);
-      if (rc) return rc;
+    if (p.bias_tab) {   // table mode: slabs -> (nclass, H) in one pass (overwrites dbias)
+      const int ncls = (2 * p.gh - 1) * (2 * p.gw - 1);
+      if (hipMemsetAsync(dbias, 0, (size_t)ncls * H * 4, stream) != hipSuccess) { ctclip_set_error("attn_bwd: memset failed"); return CTCLIP_EBADARG; }
+      hipLaunchKernelGGL(dbias_fold_kernel, dim3((unsigned)cdiv(L, 16), H), dim3(256), 0, stream, (const float*)workspace, ns, dbias, H, p.gh, p.gw);
+      rc = ctclip_check_launch("dbias_fold");
+    } else {
+      hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, dbias, ns, n, 1);
+      rc = ctclip_check_launch("dbias_reduce");
     }
+    if (rc) return rc;
     p.dbias = nullptr;
   }
   rc = dispatch_attn(1, p, D, dtype, stream);
