@@ -183,11 +183,14 @@ __device__ __forceinline__ void tile_logits(float (&val)[16], const f32x16& s, c
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
+  // L <= 32 (CTViT temporal attention, L = 24): one row block per sequence, so the four waves take four sequences (the first
+  // mapping left three of the four waves of every workgroup idle)
+  const bool shortseq = p.L <= 32;
+  const int qb = shortseq ? 0 : blockIdx.x * 4 + wave, h = blockIdx.y, seq = shortseq ? blockIdx.z * 4 + wave : blockIdx.z;
   const int L = p.L, Lp = p.Lp;
   __shared__ RelLds rel;
   rel_stage(rel, p, h);
-  if (qb * 32 >= L) return;
+  if (qb * 32 >= L || seq >= p.nseq) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
   const T* Q = reinterpret_cast<const T*>(p.q);
@@ -278,11 +281,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
+  // L <= 32 (CTViT temporal attention, L = 24): one row block per sequence, so the four waves take four sequences (the first
+  // mapping left three of the four waves of every workgroup idle)
+  const bool shortseq = p.L <= 32;
+  const int qb = shortseq ? 0 : blockIdx.x * 4 + wave, h = blockIdx.y, seq = shortseq ? blockIdx.z * 4 + wave : blockIdx.z;
   const int L = p.L, Lp = p.Lp;
   __shared__ RelLds rel;
   rel_stage(rel, p, h);
-  if (qb * 32 >= L) return;
+  if (qb * 32 >= L || seq >= p.nseq) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
   const T* Q = reinterpret_cast<const T*>(p.q);
@@ -475,11 +481,12 @@ __global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __res
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jb = blockIdx.x * 4 + wave, h = blockIdx.y, seq = blockIdx.z;
+  const bool shortseq = p.L <= 32;                          // see attn_fwd_kernel
+  const int jb = shortseq ? 0 : blockIdx.x * 4 + wave, h = blockIdx.y, seq = shortseq ? blockIdx.z * 4 + wave : blockIdx.z;
   const int L = p.L, Lp = p.Lp;
   __shared__ RelLds rel;
   rel_stage(rel, p, h);
-  if (jb * 32 >= L) return;
+  if (jb * 32 >= L || seq >= p.nseq) return;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int kj = jb * 32 + c;
   const T* Q = reinterpret_cast<const T*>(p.q);
@@ -1158,7 +1165,7 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const T* __restrict__ 
 
 template <typename T, int D>
 int launch_attn(int which, const AttnParams& p, hipStream_t stream) {
-  dim3 grid((unsigned)cdiv(cdiv(p.L, 32), 4), p.H, p.nseq), block(256);
+  dim3 grid((unsigned)cdiv(cdiv(p.L, 32), 4), p.H, p.L <= 32 ? (unsigned)cdiv(p.nseq, 4) : p.nseq), block(256);
   if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, block, 0, stream, p);
   else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), grid, block, 0, stream, p);
