@@ -52,7 +52,8 @@ def build(args, device, dtype):
     enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
                             temporal_patch_size=FULL["tpatch"], spatial_depth=args.spatial_depth,
                             temporal_depth=args.temporal_depth, dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=dtype)
-    bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))   # BERT-base, random init
+    # BERT-base, random init, HF default dropout 0.1 active in train mode as in the reference's training (run_train.py:9)
+    bert = BertModel(BertConfig(hidden_dropout_prob=args.bert_dropout, attention_probs_dropout_prob=args.bert_dropout))
     hw = args.image // FULL["patch"]
     clip = ct_clip_amd.CTCLIP(image_encoder=enc, text_encoder=bert, dim_text=768, dim_image=hw * hw * FULL["dim"],
                               dim_latent=FULL["dim_latent"], compute_dtype=dtype)
@@ -166,6 +167,7 @@ def main():
     ap.add_argument("--image", type=int, default=FULL["image"])
     ap.add_argument("--frames", type=int, default=FULL["frames"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--bert-dropout", type=float, default=0.1, help="HF BertConfig hidden / attention dropout (reference default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-spatial-depth", type=int, default=4, help="the CPU sample uses the reference's own 4+4 layers to stay bounded")

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTCLIP_LIB") or os.path.join(_HERE, "libctclip_hip.so")   # CTCLIP_LIB: profiling builds only
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_U64, _U32 = ctypes.c_uint64, ctypes.c_uint32
 
 # name -> (restype, argtypes).  Every entry point ends with a hipStream_t (void*) unless noted.
 SIGNATURES = {
@@ -31,9 +32,11 @@ SIGNATURES = {
     "ctclip_head_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "ctclip_qk_norm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _I, _P]),
     "ctclip_qk_norm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _P]),
-    "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
+    "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
-    "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _I, _P, _L, _P]),
+    "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
+    "ctclip_dropout": (_I, [_P, _P, _P, _L, _F, _U64, _U32, _I, _P]),
+    "ctclip_attn_dropout_mask": (_I, [_P, _I, _I, _I, _F, _U64, _P]),
     "ctclip_geglu_fwd": (_I, [_P, _P, _L, _I, _I, _P]),
     "ctclip_geglu_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ctclip_gelu_fwd": (_I, [_P, _P, _L, _I, _P]),

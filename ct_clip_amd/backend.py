@@ -216,21 +216,26 @@ class HipBackend:
         _lib.check(rc, "ctclip_qk_norm_bwd")
         return dx
 
-    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None):
-        """bias: (H, L, L) f32, or with bias_grid = (gh, gw) the relative-position table (nclass, H) (ctclip_attn_fwd)."""
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None, dropout=None):
+        """bias: (H, L, L) f32, or with bias_grid = (gh, gw) the relative-position table (nclass, H) (ctclip_attn_fwd).
+        dropout = (p, seed): attention-probability dropout."""
         gh, gw = bias_grid if bias_grid is not None else (0, 0)
+        dp, dseed = dropout if dropout is not None else (0.0, 0)
         M = nseq * L
         Lp = vt.shape[-1]
         o = torch.empty((M, H * D), dtype=q.dtype, device=q.device)
         lse = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device) if want_lse else None
         rc = self.lib.ctclip_attn_fwd(_p(q), _p(k), _p(vt), _p(bias), gh, gw, _p(keymask), _p(o), _p(lse), nseq, H, L, Lp, D,
-                                      _rowmajor(q, "q"), _rowmajor(k, "k"), H * D, float(scale), dcode(q.dtype), _stream())
+                                      _rowmajor(q, "q"), _rowmajor(k, "k"), H * D, float(scale), float(dp), int(dseed), dcode(q.dtype),
+                                      _stream())
         _lib.check(rc, "ctclip_attn_fwd")
         return o, lse
 
-    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None):
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None,
+                 dropout=None):
         Lp = qt.shape[-1]
         gh, gw = bias_grid if bias_grid is not None else (0, 0)
+        dp, dseed = dropout if dropout is not None else (0.0, 0)
         delta = torch.empty((nseq, H, L), dtype=torch.float32, device=q.device)
         ws = None
         if dbias is not None:
@@ -239,8 +244,22 @@ class HipBackend:
                                       _p(keymask), _p(delta), _p(dq), _p(dk), _p(dv), _p(dbias), nseq, H, L, Lp, D,
                                       _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(o, "o"),
                                       _rowmajor(dout, "dout"), _rowmajor(dq, "dq"), _rowmajor(dk, "dk"), _rowmajor(dv, "dv"),
-                                      float(scale), dcode(q.dtype), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                                      float(scale), float(dp), int(dseed), dcode(q.dtype), _p(ws), ws.numel() if ws is not None else 0,
+                                      _stream())
         _lib.check(rc, "ctclip_attn_bwd")
+
+    def dropout(self, x, residual, p, seed, stream_id):
+        """y = dropout(x) (+ residual); mask = philox(seed, element, stream_id).  The same call on dy is the backward."""
+        assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype))
+        y = torch.empty_like(x)
+        _lib.check(self.lib.ctclip_dropout(_p(x), _p(residual), _p(y), x.numel(), float(p), int(seed), int(stream_id), dcode(x.dtype),
+                                           _stream()), "ctclip_dropout")
+        return y
+
+    def attn_dropout_mask(self, nseq, H, L, p, seed, device):
+        m = torch.empty((nseq, H, L, L), dtype=torch.float32, device=device)
+        _lib.check(self.lib.ctclip_attn_dropout_mask(_p(m), nseq, H, L, float(p), int(seed), _stream()), "ctclip_attn_dropout_mask")
+        return m
 
     # ------------------------------------------------------------------ elementwise / streaming
     def geglu_fwd(self, u):

@@ -8,14 +8,10 @@ BertSelfAttention, BertSelfOutput, BertIntermediate, BertOutput) -- runs through
 The pooler is skipped: CT-CLIP discards it (ct_clip.py:686,762).
 """
 import math
-import warnings
 
 import torch
 
 from . import functional as Fn
-
-_warned_dropout = False
-
 
 def is_hf_bert(module):
     return hasattr(module, "embeddings") and hasattr(module, "encoder") and hasattr(module.encoder, "layer") \
@@ -24,17 +20,20 @@ def is_hf_bert(module):
 
 def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
     """Returns last_hidden_state as a (B*T, hidden) activation in ``dtype``."""
-    global _warned_dropout
     cfg = bert.config
     if getattr(cfg, "hidden_act", "gelu") != "gelu":
         raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU BERT is implemented")
     if getattr(cfg, "position_embedding_type", "absolute") != "absolute":
         raise NotImplementedError("only absolute position embeddings are implemented")
-    if bert.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0) and not _warned_dropout:
-        warnings.warn("ct_clip_amd: BERT dropout (p=%.2f/%.2f) is not applied by the HIP text tower; the forward is "
-                      "deterministic (the reference's train-mode loss is stochastic)" %
-                      (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob))
-        _warned_dropout = True
+    # train-mode dropout (HF modeling_bert.py: BertEmbeddings, BertSelfAttention, BertSelfOutput, BertOutput).  Masks are
+    # counter-based (Philox, ct_clip_amd/csrc/common.h): one 62-bit seed per forward drawn from torch's CPU generator (so that
+    # torch.manual_seed reproduces a run), call sites separated by stream ids / seed offsets, regenerated in backward.
+    p_hid = float(cfg.hidden_dropout_prob) if bert.training else 0.0
+    p_att = float(cfg.attention_probs_dropout_prob) if bert.training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hid > 0 or p_att > 0) else 0
+
+    def drop(h, residual, site):   # only reached with p_hid > 0, except for the embeddings (identity then)
+        return Fn.DropoutAddFn.apply(h, residual, p_hid, seed, site) if p_hid > 0 else h
     emb = bert.embeddings
     dev = emb.word_embeddings.weight.device
     ids = input_ids.to(dev).contiguous()
@@ -47,20 +46,28 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
     x = Fn.BertEmbedFn.apply(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                              emb.token_type_embeddings.weight, dtype)
     x = Fn.layer_norm(x, emb.LayerNorm.weight, emb.LayerNorm.bias, eps)
+    x = drop(x, None, 0)
     keymask = None
     if attention_mask is not None:
         # additive key mask, as HF builds it: (1 - mask) * finfo.min
         keymask = ((1.0 - attention_mask.to(device=dev, dtype=torch.float32)) * torch.finfo(torch.float32).min).contiguous()
     scale = 1.0 / math.sqrt(dh)
-    for layer in bert.encoder.layer:
+    for li, layer in enumerate(bert.encoder.layer):
         sa, so = layer.attention.self, layer.attention.output
         q = Fn.linear(x, sa.query.weight, sa.query.bias)
         k = Fn.linear(x, sa.key.weight, sa.key.bias)
         v = Fn.linear(x, sa.value.weight, sa.value.bias)
-        c = Fn.SdpaFn.apply(q, k, v, keymask, Bsz, T, nh, dh, scale)
-        x = Fn.layer_norm(Fn.linear(c, so.dense.weight, so.dense.bias, residual=x), so.LayerNorm.weight, so.LayerNorm.bias, eps)
+        c = Fn.SdpaFn.apply(q, k, v, keymask, Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None)
+        if p_hid > 0:    # dense -> dropout -> + input -> LayerNorm
+            h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias), x, 1 + 2 * li)
+        else:
+            h1 = Fn.linear(c, so.dense.weight, so.dense.bias, residual=x)
+        x = Fn.layer_norm(h1, so.LayerNorm.weight, so.LayerNorm.bias, eps)
         u = Fn.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         m = Fn.GeluFn.apply(u)
-        x = Fn.layer_norm(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x),
-                          layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
+        if p_hid > 0:
+            h2 = drop(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias), x, 2 + 2 * li)
+        else:
+            h2 = Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x)
+        x = Fn.layer_norm(h2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
     return x

@@ -91,6 +91,8 @@ __device__ __forceinline__ void frag_from_regs(Frag<float, 32>& f, const float (
 struct AttnParams {
   const void *q, *k, *v, *qt, *kt, *vt, *o, *dout, *dot;
   const float *bias, *keymask, *lse, *delta;
+  float drop_p, drop_inv_keep;   // attention-probability dropout (HF BertSelfAttention, train mode); 0 = off
+  uint64_t drop_seed;
   const float* bias_tab;   // relative-position form of the bias: (nclass, H) table, class(i, j) below; replaces `bias`
   int gh, gw;              // token grid of the sequence (L = gh * gw) when bias_tab is set
   void *out, *dq, *dk, *dv;
@@ -119,6 +121,13 @@ __device__ __forceinline__ void rel_stage(RelLds& rel, const AttnParams& p, int 
     rel.u[i] = (uint16_t)((t / p.gw) * (2 * p.gw - 1) + t % p.gw);
   }
   __syncthreads();
+}
+
+// multiplier of attention probability (seq, h, qi, kj) under dropout: a pure function of the seed and the linear index
+// (ctclip_attn_dropout_mask materialises the same values), so forward, dQ and dK/dV regenerate identical masks
+__device__ __forceinline__ float attn_drop(const AttnParams& p, int seq, int h, int qi, int kj) {
+  const uint64_t lin = (((uint64_t)seq * p.H + h) * p.L + qi) * p.L + kj;
+  return dropout_mult(philox4x32(p.drop_seed, lin, 0u)[0], p.drop_p, p.drop_inv_keep);
 }
 
 // scores of one 32x32 tile in "lane = column c, regs = rows slot_index(r, half)" layout -> logits
@@ -248,6 +257,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) { pr[r] = __expf(val[r] - mnew); ps += pr[r]; }
     lsum = lsum * alpha + ps;
     m = mnew;
+    if (p.drop_p > 0.f) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] *= attn_drop(p, seq, h, qic, min(kb * 32 + slot_index(r, half), L - 1));
+    }
     Frag<T, 32> pf;
     frag_from_regs(pf, pr);
 #pragma unroll
@@ -338,7 +351,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) {
       const int kj = kb * 32 + slot_index(r, half);
       const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
-      ds[r] = pr * (dp[r] - delta);
+      const float dpr = p.drop_p > 0.f ? dp[r] * attn_drop(p, seq, h, qic, kj < L ? kj : L - 1) : dp[r];   // d(dropout(P)) / dP
+      ds[r] = pr * (dpr - delta);
       if (p.dbias && qi < L && kj < L) atomicAdd(p.dbias + ((int64_t)h * L + qi) * L + kj, ds[r]);
     }
     Frag<T, 32> dsf;
@@ -541,7 +555,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       const int qc = qi < L ? qi : L - 1;
       const float lse = p.lse[statbase + qc], delta = p.delta[statbase + qc];
       pr[r] = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
-      ds[r] = pr[r] * (dp[r] - delta);
+      const float dm = p.drop_p > 0.f ? attn_drop(p, seq, h, qc, kjc) : 1.f;
+      ds[r] = pr[r] * (dp[r] * dm - delta);
+      pr[r] *= dm;                                           // dV sees the dropped probabilities
     }
     Frag<T, 32> pf, dsf;
     frag_from_regs(pf, pr);
@@ -1180,7 +1196,7 @@ bool attn_lds_enabled() {
 
 int dispatch_attn(int which, const AttnParams& p, int D, int dtype, hipStream_t stream) {
   const bool use_lds = attn_lds_enabled();
-  if (use_lds && dtype == DT_BF16 && D == 32 && p.L >= 128 && !p.dbias) {   // CTViT spatial shape: workgroup-shared operand tiles
+  if (use_lds && dtype == DT_BF16 && D == 32 && p.L >= 128 && !p.dbias && p.drop_p == 0.f) {   // CTViT spatial shape: workgroup-shared operand tiles
     dim3 grid((unsigned)cdiv(cdiv(p.L, 32), 4), p.H, p.nseq), block(256);
     const bool fast = (p.L % 32) == 0 && !p.keymask && !p.bias && (!p.bias_tab || (p.gw % 8) == 0);
     if (fast) {
@@ -1281,12 +1297,22 @@ static int set_bias(AttnParams& p, const float* bias, int bias_gh, int bias_gw, 
   return 0;
 }
 
+// dropout_p > 0: HF attention-probability dropout (train mode), mask = philox(dropout_seed, linear score index); the same
+// (dropout_p, dropout_seed) must be passed to ctclip_attn_bwd.
+static int set_dropout(AttnParams& p, float dropout_p, uint64_t dropout_seed) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) { ctclip_set_error("attention: 0 <= dropout_p < 1"); return CTCLIP_EBADARG; }
+  p.drop_p = dropout_p; p.drop_inv_keep = 1.f / (1.f - dropout_p); p.drop_seed = dropout_seed;
+  return 0;
+}
+
 extern "C" int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw,
                                const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq,
-                               int64_t ldk, int64_t ldo, float scale, int dtype, hipStream_t stream) {
+                               int64_t ldk, int64_t ldo, float scale, float dropout_p, uint64_t dropout_seed, int dtype,
+                               hipStream_t stream) {
   if (!q || !k || !vt || !out || bad_ld(ldq) || bad_ld(ldk) || bad_ld(ldo) || Lp % 8 || Lp < L) { ctclip_set_error("attn_fwd: bad args"); return CTCLIP_EBADARG; }
   AttnParams p{};
   if (int rc = set_bias(p, bias, bias_gh, bias_gw, L)) return rc;
+  if (int rc = set_dropout(p, dropout_p, dropout_seed)) return rc;
   p.q = q; p.k = k; p.vt = vt; p.keymask = keymask; p.out = out; p.lse_out = lse;
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.scale = scale;
   return dispatch_attn(0, p, D, dtype, stream);
@@ -1313,7 +1339,8 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
                                const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw,
                                const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk,
-                               int64_t lddv, float scale, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                               int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed, int dtype, void* workspace,
+                               int64_t workspace_bytes, hipStream_t stream) {
   if (!q || !k || !v || !qt || !kt || !o || !dout || !dot || !lse || !delta || !dq || !dk || !dv) { ctclip_set_error("attn_bwd: null arg"); return CTCLIP_EBADARG; }
   if (bad_ld(ldq) || bad_ld(ldk) || bad_ld(ldv) || bad_ld(ldo) || bad_ld(lddo) || bad_ld(lddq) || bad_ld(lddk) || bad_ld(lddv) || Lp % 8 || Lp < L) { ctclip_set_error("attn_bwd: strides must be multiples of 8"); return CTCLIP_EBADARG; }
   const int64_t M = (int64_t)nseq * L;
@@ -1330,6 +1357,8 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
   }
   AttnParams p{};
   if (int rc0 = set_bias(p, bias, bias_gh, bias_gw, L)) return rc0;
+  if (int rc0 = set_dropout(p, dropout_p, dropout_seed)) return rc0;
+  if (dropout_p > 0.f && dbias) { ctclip_set_error("attn_bwd: dropout together with a bias gradient is not implemented"); return CTCLIP_EUNSUPPORTED; }
   p.q = q; p.k = k; p.v = v; p.qt = qt; p.kt = kt; p.o = o; p.dout = dout; p.dot = dot; p.lse = lse; p.delta = delta;
   p.keymask = keymask; p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias;
   p.nseq = nseq; p.H = H; p.L = L; p.Lp = Lp; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo;

@@ -120,4 +120,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based random numbers for dropout: Philox4x32-10 (Salmon et al., SC'11; the generator curand / torch use) keyed by
+// the 64-bit seed, counter = (index lo, index hi, stream id, 0).  The mask is a pure function of (seed, stream, element index):
+// the backward pass regenerates it instead of storing it, and tests/ref_backend.py reproduces it bit for bit in torch.
+__device__ __forceinline__ u32x4 philox4x32(uint64_t seed, uint64_t index, uint32_t stream) {
+  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = stream, c3 = 0u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+// keep-multiplier of one element: 0 with probability p, 1 / (1 - p) otherwise (u = top 24 bits / 2^24 >= p keeps)
+__device__ __forceinline__ float dropout_mult(uint32_t word, float p, float inv_keep) { return (float)(word >> 8) * (1.f / 16777216.f) >= p ? inv_keep : 0.f; }
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -215,6 +215,28 @@ __global__ void cpb_reduce_kernel(const float* __restrict__ dbias, float* __rest
   dtab[(int64_t)cls * H + h] = t;
 }
 
+// ---- dropout (HF BertEmbeddings / BertSelfOutput / BertOutput: nn.Dropout(hidden_dropout_prob) in train mode):
+//      y = x * keep / (1 - p) (+ residual); element i takes word (i & 3) of philox(seed, i >> 2, stream).
+//      The same call with dy in place of x is the backward.
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n4, float p, float inv_keep,
+                               uint64_t seed, uint32_t stream) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4 w = philox4x32(seed, (uint64_t)i, stream);
+    float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+    load4(x + i * 4, v);
+    if (res) load4(res + i * 4, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * dropout_mult(w[e], p, inv_keep) + r[e];
+    store4(y + i * 4, v);
+  }
+}
+// the multiplier the attention kernels apply to probability (seq, h, i, j): word 0 of philox(seed, linear index, 0) -- for tests
+__global__ void attn_dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, float inv_keep, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = dropout_mult(philox4x32(seed, (uint64_t)i, 0u)[0], p, inv_keep);
+}
+
 // ---- BERT embeddings (HF BertEmbeddings): x[r] = word[ids[r]] + pos[r % T] + type[0]
 template <typename T>
 __global__ void bert_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
@@ -384,6 +406,22 @@ extern "C" int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh,
   const int n = (2 * gh - 1) * (2 * gw - 1) * H;
   hipLaunchKernelGGL(cpb_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dbias, dtab, H, gh, gw);
   return ctclip_check_launch("cpb_reduce");
+}
+// nn.Dropout in train mode (HF modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput), optionally fused with the residual
+// add that follows it: y = dropout(x) + residual.  n % 4 == 0.  `stream_id` separates the call sites of one step.
+extern "C" int ctclip_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id,
+                              int dtype, hipStream_t s) {
+  if (!x || !y || n % 4 || p < 0.f || p >= 1.f) { ctclip_set_error("dropout: n % 4 == 0, 0 <= p < 1"); return CTCLIP_EBADARG; }
+  const float inv_keep = 1.f / (1.f - p);
+  BY_DTYPE(dtype, hipLaunchKernelGGL(dropout_kernel<T>, grid_for(n / 4), dim3(256), 0, s, (const T*)x, (const T*)residual, (T*)y, n / 4, p, inv_keep, seed, stream_id));
+  return ctclip_check_launch("dropout");
+}
+// mask[(seq, h, i, j)] = the multiplier ctclip_attn_fwd/bwd apply to attention probability (seq, h, i, j) for (p, seed): 0 or 1/(1-p)
+extern "C" int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint64_t seed, hipStream_t s) {
+  if (!mask || p < 0.f || p >= 1.f) { ctclip_set_error("attn_dropout_mask: bad args"); return CTCLIP_EBADARG; }
+  const int64_t n = (int64_t)nseq * H * L * L;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, grid_for(n), dim3(256), 0, s, mask, n, p, 1.f / (1.f - p), seed);
+  return ctclip_check_launch("attn_dropout_mask");
 }
 extern "C" int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows,
                                      int Tlen, int Hd, int dtype, hipStream_t s) {

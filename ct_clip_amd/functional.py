@@ -390,27 +390,44 @@ class SdpaFn(Function):
     """HF BertSelfAttention core: softmax(q k^T / sqrt(d) + mask) v; q, k, v are (M, H*D) activations."""
 
     @staticmethod
-    def forward(ctx, q, k, v, keymask, nseq, L, H, D, scale):
+    def forward(ctx, q, k, v, keymask, nseq, L, H, D, scale, dropout=None):
+        """dropout = (p, seed) or None: HF attention_probs_dropout_prob in train mode."""
         be = B()
         vt = be.head_transpose(v, nseq, H, L, D)
-        o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale)
+        o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale, dropout=dropout)
         ctx.save_for_backward(q, k, v, o, lse, keymask if keymask is not None else q.new_empty(0))
-        ctx.dims = (nseq, L, H, D, scale, keymask is not None)
+        ctx.dims = (nseq, L, H, D, scale, keymask is not None, dropout)
         return o
 
     @staticmethod
     def backward(ctx, do):
         be = B()
         q, k, v, o, lse, keymask = ctx.saved_tensors
-        nseq, L, H, D, scale, has_mask = ctx.dims
+        nseq, L, H, D, scale, has_mask, dropout = ctx.dims
         do = do.contiguous()
         qt = be.head_transpose(q, nseq, H, L, D)
         kt = be.head_transpose(k, nseq, H, L, D)
         dot = be.head_transpose(do, nseq, H, L, D)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, keymask if has_mask else None, dq, dk, dv, None,
-                    nseq, H, L, D, scale)
-        return dq, dk, dv, None, None, None, None, None, None
+                    nseq, H, L, D, scale, dropout=dropout)
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+class DropoutAddFn(Function):
+    """y = dropout(x) (+ residual) -- nn.Dropout(hidden_dropout_prob) of HF BertEmbeddings / BertSelfOutput / BertOutput and the
+    residual add that follows it.  The mask is regenerated from (seed, stream_id) in backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed, stream_id):
+        ctx.args = (p, seed, stream_id, residual is not None)
+        return B().dropout(x.contiguous(), residual.contiguous() if residual is not None else None, p, seed, stream_id)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, stream_id, has_res = ctx.args
+        dy = dy.contiguous()
+        return B().dropout(dy, None, p, seed, stream_id), (dy if has_res else None), None, None, None
 
 
 # ------------------------------------------------------------------------------------------ small ops

@@ -33,13 +33,13 @@ int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y, float* in
 int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, hipStream_t stream);
 
 /* softmax(scale*q k^T + bias[h] + keymask[seq]) v (attention.py:156-178; HF BertSelfAttention). */
-int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw, const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int dtype, hipStream_t stream);
+int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw, const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p, uint64_t dropout_seed, int dtype, hipStream_t stream);
 
 /* bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs). */
 int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L);
 
 /* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). */
-int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* thread-local message of the last failing call. */
 const char* ctclip_last_error(void);
@@ -121,6 +121,12 @@ int ctclip_cpb_expand(const float* tab, float* bias, int H, int gh, int gw, hipS
 
 /* backward of the gather (deterministic segmented sum). */
 int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
+
+/* TODO: document */
+int ctclip_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, int dtype, hipStream_t s);
+
+/* TODO: document */
+int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint64_t seed, hipStream_t s);
 
 /* HF BertEmbeddings: word + position + token_type(0) lookup. */
 int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows, int Tlen, int Hd, int dtype, hipStream_t s);

@@ -138,27 +138,65 @@ class RefBackend:
             s = s + keymask[:, None, None, :]
         return qf, kf, s
 
-    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None):
+    # ---- Philox4x32-10 in torch (ct_clip_amd/csrc/common.h philox4x32): the dropout masks of the HIP kernels, bit for bit
+    @staticmethod
+    def philox(seed, index, stream):
+        M32 = 0xFFFFFFFF
+        c0, c1 = index & M32, (index >> 32) & M32
+        c2, c3 = torch.full_like(index, stream), torch.zeros_like(index)
+        k0, k1 = seed & M32, (seed >> 32) & M32
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2          # < 2^64: exact in int64 only up to 2^63, so split the product
+            hi0, lo0 = (((0xD2511F53 >> 16) * c0 + ((0xD2511F53 & 0xFFFF) * c0 >> 16)) >> 16) & M32, p0 & M32
+            hi1, lo1 = (((0xCD9E8D57 >> 16) * c2 + ((0xCD9E8D57 & 0xFFFF) * c2 >> 16)) >> 16) & M32, p1 & M32
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+        return c0, c1, c2, c3
+
+    @staticmethod
+    def _mult(word, p):
+        return torch.where((word >> 8).to(torch.float32) * (1.0 / 16777216.0) >= torch.tensor(p, dtype=torch.float32), 1.0 / (1.0 - p), 0.0)
+
+    def dropout(self, x, residual, p, seed, stream_id):
+        n = x.numel()
+        idx = torch.arange(n // 4, dtype=torch.int64)            # integer Philox on the CPU (no device JIT of int64 kernels)
+        words = torch.stack(self.philox(seed, idx, stream_id), dim=1).reshape(-1)
+        y = _f(x).reshape(-1) * self._mult(words, p).to(x.device)
+        if residual is not None:
+            y = y + _f(residual).reshape(-1)
+        return y.reshape(x.shape).to(x.dtype)
+
+    def attn_dropout_mask(self, nseq, H, L, p, seed, device):
+        idx = torch.arange(nseq * H * L * L, dtype=torch.int64)
+        return self._mult(self.philox(seed, idx, 0)[0], p).reshape(nseq, H, L, L).to(device)
+
+    def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None, dropout=None):
         if bias_grid is not None:
             bias = self.cpb_expand(bias, *bias_grid)
         qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
         lse = torch.logsumexp(s, dim=-1)
         p = torch.exp(s - lse[..., None])
+        if dropout is not None:
+            p = p * self.attn_dropout_mask(nseq, H, L, dropout[0], dropout[1], p.device)
         v = _f(vt[..., :L]).permute(0, 1, 3, 2)  # (nseq, H, L, D)
         o = torch.einsum("shij,shjd->shid", p, v).permute(0, 2, 1, 3).reshape(nseq * L, H * D)
         return o.to(q.dtype).contiguous(), lse
 
-    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None):
+    def attn_bwd(self, q, k, v, qt, kt, o, dout, dot, lse, bias, keymask, dq, dk, dv, dbias, nseq, H, L, D, scale, bias_grid=None,
+                 dropout=None):
         if bias_grid is not None:
             bias = self.cpb_expand(bias, *bias_grid)
         qf, kf, s = self._scores(q, k, bias, keymask, nseq, H, L, D, scale)
         p = torch.exp(s - lse[..., None])
+        dm = self.attn_dropout_mask(nseq, H, L, dropout[0], dropout[1], p.device) if dropout is not None else None
         vf = _f(v[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
         dof = _f(dout[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
         of = _f(o[:, :H * D]).reshape(nseq, L, H, D).permute(0, 2, 1, 3)
         delta = (dof * of).sum(-1)
-        dvf = torch.einsum("shij,shid->shjd", p, dof)
+        dvf = torch.einsum("shij,shid->shjd", p if dm is None else p * dm, dof)
         dp = torch.einsum("shid,shjd->shij", dof, vf)
+        if dm is not None:
+            dp = dp * dm
         ds = p * (dp - delta[..., None])
         dqf = torch.einsum("shij,shjd->shid", ds, kf) * scale
         dkf = torch.einsum("shij,shid->shjd", ds, qf) * scale

@@ -68,3 +68,31 @@ def test_same_seed_same_init_as_reference(golden):
               "visual_transformer.enc_temporal_transformer.layers.0.3.4.weight", "visual_transformer.vq._codebook.embed",
               "visual_transformer.spatial_rel_pos_bias.net.1.0.weight"]:
         torch.testing.assert_close(sd[k], g["state_dict"][k], rtol=0, atol=0)
+
+
+def test_bert_train_mode_dropout(ref_backend):
+    """HF hidden / attention-probability dropout in train mode: stochastic per forward, reproducible under torch.manual_seed,
+    absent in eval mode, and differentiable (masks regenerated in backward)."""
+    from transformers import BertConfig, BertModel
+    from ct_clip_amd import bert as B
+    torch.manual_seed(0)
+    model = BertModel(BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                                 max_position_embeddings=32, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))
+    ids = torch.randint(0, 100, (2, 16))
+    mask = torch.ones(2, 16, dtype=torch.int64)
+    mask[1, 12:] = 0
+    model.train()
+    torch.manual_seed(1); a = B.bert_last_hidden_state(model, ids, mask, torch.float32)
+    torch.manual_seed(1); b = B.bert_last_hidden_state(model, ids, mask, torch.float32)
+    torch.manual_seed(2); c = B.bert_last_hidden_state(model, ids, mask, torch.float32)
+    assert torch.equal(a, b) and not torch.allclose(a, c)
+    a.float().square().mean().backward()
+    g = model.encoder.layer[0].attention.self.query.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    model.eval()
+    e1 = B.bert_last_hidden_state(model, ids, mask, torch.float32)
+    e2 = B.bert_last_hidden_state(model, ids, mask, torch.float32)
+    assert torch.equal(e1, e2)
+    with torch.no_grad():   # eval mode = the HF module itself
+        hf = model(input_ids=ids, attention_mask=mask)[0].reshape(-1, 64)
+    torch.testing.assert_close(e1.detach(), hf, rtol=1e-4, atol=1e-4)

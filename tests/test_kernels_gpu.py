@@ -244,6 +244,51 @@ def test_attention_relative_bias_table(hip, ref, dtype, nseq, H, gh, gw, D):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_dropout_is_philox(hip, ref, dtype):
+    """nn.Dropout of the BERT tower: the mask is Philox4x32-10(seed, element, stream) -- reproduced bit for bit in torch."""
+    x, res = rnd(64, 768, dtype=dtype, seed=1), rnd(64, 768, dtype=dtype, seed=2)
+    seed = 0x1234_5678_9ABC_DEF
+    for p, sid, r in ((0.1, 0, None), (0.1, 7, res), (0.5, 3, res)):
+        y, yr = hip.dropout(x, r, p, seed, sid), ref.dropout(x, r, p, seed, sid)
+        if r is None:
+            close(y, yr, rtol=0, atol=0)                     # same mask, same single multiply
+        else:
+            close(y, yr, **tol(dtype, (1e-6, 1e-6), (8e-3, 8e-3)))   # x * m + r is one fused multiply-add on the device
+    y = hip.dropout(x, None, 0.1, seed, 0)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    assert not torch.equal(y, hip.dropout(x, None, 0.1, seed, 1)) and not torch.equal(y, hip.dropout(x, None, 0.1, seed + 1, 0))
+    close(hip.attn_dropout_mask(2, 3, 40, 0.1, seed, DEV), ref.attn_dropout_mask(2, 3, 40, 0.1, seed, DEV), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nseq,H,L,D,use_mask", [(2, 12, 128, 64, True), (3, 4, 50, 64, False), (2, 4, 24, 32, False)])
+def test_attention_probability_dropout(hip, ref, dtype, nseq, H, L, D, use_mask):
+    """HF BertSelfAttention in train mode: dropout on the softmax output, regenerated identically in forward, dQ and dK/dV."""
+    M, HD = nseq * L, H * D
+    q, k = rnd(M, HD, dtype=dtype, seed=1, scale=0.5), rnd(M, HD, dtype=dtype, seed=2, scale=0.5)
+    v, do = rnd(M, HD, dtype=dtype, seed=3, scale=0.5), rnd(M, HD, dtype=dtype, seed=4)
+    mask = None
+    if use_mask:
+        mask = torch.zeros(nseq, L, device=DEV)
+        mask[0, L - 5:] = torch.finfo(torch.float32).min
+    drop, scale = (0.1, 987654321012345), D ** -0.5
+    vt = hip.head_transpose(v, nseq, H, L, D)
+    o, lse = hip.attn_fwd(q, k, vt, None, mask, nseq, H, L, D, scale, dropout=drop)
+    orf, lser = ref.attn_fwd(q, k, vt, None, mask, nseq, H, L, D, scale, dropout=drop)
+    close(o, orf, **tol(dtype, (1e-4, 1e-5), (2e-2, 2e-2))); close(lse, lser, **tol(dtype, (1e-4, 1e-4), (1e-2, 3e-2)))
+    o0, _ = hip.attn_fwd(q, k, vt, None, mask, nseq, H, L, D, scale)
+    assert (o.float() - o0.float()).abs().max() > 1e-3            # and it does something
+    qt, kt, dot = (hip.head_transpose(t, nseq, H, L, D) for t in (q, k, do))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    hip.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, None, mask, dq, dk, dv, None, nseq, H, L, D, scale, dropout=drop)
+    dqr, dkr, dvr = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    ref.attn_bwd(q, k, v, qt, kt, orf.to(dtype), do, dot, lser, None, mask, dqr, dkr, dvr, None, nseq, H, L, D, scale, dropout=drop)
+    t = tol(dtype, (1e-3, 1e-4), (3e-2, 3e-2))
+    close(dq, dqr, **t); close(dk, dkr, **t); close(dv, dvr, **t)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("H,D", [(4, 32), (12, 64)])
 def test_qk_norm(hip, ref, dtype, H, D):
     M, HD = 200, H * D
