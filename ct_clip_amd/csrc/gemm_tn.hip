@@ -240,9 +240,22 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(TnParams p) {
     }
 }
 
-// out[m][n] (+)= sum_s slab[s][m][n]
+// out[m][n] (+)= sum_s slab[s][m][n]; VEC: four columns per thread (16-byte loads / stores), f32 output
+template <bool VEC>
 __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t M, int64_t N, int64_t slab_ld, void* __restrict__ C,
                                  int64_t ldc, int out_dtype, int accumulate) {
+  if (VEC) {
+    const int64_t n4 = N / 4, total = M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t m = i / n4, n = (i % n4) * 4;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int s = 0; s < nsplit; ++s) t += *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * M + m) * slab_ld + n);
+      f32x4* c = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + m * ldc + n);
+      *c = accumulate ? *c + t : t;
+    }
+    return;
+  }
   const int64_t total = M * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / N, n = i % N;
@@ -305,8 +318,9 @@ int ctclip_gemm_tn_try(const void* A, const void* B, void* C, const float* bias,
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(per * 8)), dim3(NTH), NPANEL * PANEL, stream, p);
   int rc = ctclip_check_launch("gemm_tn");
   if (rc) return rc;
-  int64_t nb = cdiv(M * N, 256); if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)p.slabs, p.nsplit, M, N, p.slab_ld, C, ldc,
-                     out_dtype, accumulate);
+  const bool vec = out_dtype == DT_F32 && (N % 4) == 0 && (ldc % 4) == 0 && (reinterpret_cast<uintptr_t>(C) % 16) == 0;
+  int64_t nb = cdiv(vec ? M * N / 4 : M * N, 256); if (nb > 4096) nb = 4096;
+  if (vec) hipLaunchKernelGGL(tn_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)p.slabs, p.nsplit, M, N, p.slab_ld, C, ldc, out_dtype, accumulate);
+  else hipLaunchKernelGGL(tn_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)p.slabs, p.nsplit, M, N, p.slab_ld, C, ldc, out_dtype, accumulate);
   return ctclip_check_launch("gemm_tn reduce");
 }
