@@ -61,7 +61,7 @@ def build(args, device, dtype):
     clip.to(device)
     trainer = ct_clip_amd.CTClipTrainer(clip, num_train_steps=10 ** 9, batch_size=args.batch, tokenizer=object(), lr=1.25e-6,
                                         train_dataset=[0], evaluate=False, checkpoint=False, num_workers=0,
-                                        results_folder=os.path.join(ROOT, "gpurun_out", "bench_results"), sync_loss_every=0)
+                                        results_folder=os.path.join(ROOT, "gpurun_out", "bench_results"), sync_loss_every=0, device=device)
     return clip, trainer
 
 
@@ -186,10 +186,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # CTCLIP_BENCH_BACKEND=gloo CTCLIP_BENCH_SINGLE_DEVICE=1: rehearsal of the multi-rank code path on a ONE-GPU box (all ranks on
+    # cuda:0, collectives staged through the host) -- used to check the N > 1 path where no multi-GPU node is available
+    backend_name = os.environ.get("CTCLIP_BENCH_BACKEND", "nccl")
+    if os.environ.get("CTCLIP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend_name == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend_name)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     from ct_clip_amd import backend

@@ -101,12 +101,15 @@ class CTClipTrainer(nn.Module):
                  lr=1.25e-6, wd=0.0, max_grad_norm=0.5, save_results_every=1, save_model_every=1,
                  results_folder="./ctclip/", num_workers=8, accelerate_kwargs: dict = dict(),
                  train_dataset=None, valid_dataset=None, evaluate=True, checkpoint=True, max_text_len=512,
-                 sync_loss_every=1):
+                 sync_loss_every=1, device=None):
         super().__init__()
         if "RANK" in os.environ and "WORLD_SIZE" in os.environ and not _dist.is_on() and int(os.environ["WORLD_SIZE"]) > 1:
             torch.distributed.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
         local_rank = int(os.environ.get("LOCAL_RANK", 0))
-        self.device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        if device is not None:      # (additive) explicit placement instead of cuda:LOCAL_RANK
+            self.device = torch.device(device)
+        else:
+            self.device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
         self.CTClip = CTClip.to(self.device)
