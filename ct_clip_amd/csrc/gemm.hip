@@ -30,6 +30,8 @@ int ctclip_gemm_tn_try(const void* A, const void* B, void* C, const float* bias,
                        int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int accumulate, int split_k, float alpha, void* workspace,
                        int64_t workspace_bytes, hipStream_t stream);
 int64_t ctclip_gemm_tn_workspace(int64_t M, int64_t N, int64_t K, int split_k);
+int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
+                              int32_t* part_idx, int* nparts, hipStream_t stream);
 int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
                        hipStream_t stream);
@@ -406,9 +408,17 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
   p.nparts = 2 * p.ntn;
   p.part_val = reinterpret_cast<float*>(workspace);
   p.part_idx = reinterpret_cast<int32_t*>(p.part_val + M * p.nparts);
-  dim3 grid(p.ntm * p.ntn, 1);
-  rc = (in_dtype == DT_F32) ? launch_layout<float, EPI_ARGMAX>(p, 1, 1, grid, stream)
-                            : launch_layout<bf16_t, EPI_ARGMAX>(p, 1, 1, grid, stream);
+  rc = 1;
+  if (in_dtype == DT_BF16) {   // large code searches run on the persistent NT kernel (2.6 ms -> MFMA-bound for the 110592 x 8192 VQ search)
+    int np = 0;
+    rc = ctclip_gemm_nt_argmax_try(A, B, M, N, K, lda, ldb, p.part_val, reinterpret_cast<int32_t*>(p.part_val + M * 2 * cdiv(N, 256)), &np, stream);
+    if (rc == 0) { p.nparts = np; p.part_idx = reinterpret_cast<int32_t*>(p.part_val + M * np); }
+  }
+  if (rc == 1) {
+    dim3 grid(p.ntm * p.ntn, 1);
+    rc = (in_dtype == DT_F32) ? launch_layout<float, EPI_ARGMAX>(p, 1, 1, grid, stream)
+                              : launch_layout<bf16_t, EPI_ARGMAX>(p, 1, 1, grid, stream);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(argmax_reduce_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, stream, p.part_val, p.part_idx, out_idx,
                      out_val, M, p.nparts);

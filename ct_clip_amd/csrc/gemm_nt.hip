@@ -58,6 +58,8 @@ struct NtParams {
   int out_dtype, res_dtype, accumulate;
   float alpha;
   int ntm, ntn;
+  // arg-max epilogue (vector-quantiser code search): no C; per (row, tile column half) partial (max, lowest index of the max)
+  float* part_val; int32_t* part_idx; int nparts;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -287,7 +289,30 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     // ---------------- epilogue, straight from registers: acc[a][b][r] = C[m0 + wm*64 + a*16 + lg*4 + r][n0 + wn*128 + li*8 + b]:
     // a lane owns 8 consecutive columns, 16 lanes one 256-B (bf16) row segment, one 16-byte store instruction writes 4 full rows
     // of the wave tile.  The stores are not waited for here: they retire under the next tile's first one and a half sub-steps.
-    {
+    if (p.part_val) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
+      const int64_t col0 = n0 + wn * 128 + li * 8;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float best = -INFINITY; int bidx = 0x7fffffff;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const float v = acc[a][b][r];
+            if (col0 + b < p.N && v > best) { best = v; bidx = (int)(col0 + b); }
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bidx, o, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+          }
+          const int64_t row = m0 + wm * 64 + a * 16 + lg * 4 + r;
+          if (li == 0 && row < p.M) {
+            const int64_t slot = row * p.nparts + (n0 / TN) * 2 + wn;
+            p.part_val[slot] = best; p.part_idx[slot] = bidx;
+          }
+        }
+    } else {
       const bool vec_ok = ((p.ldc % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.C) % 16) == 0) &&
                           (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
       const int64_t col = n0 + wn * 128 + li * 8;
@@ -383,6 +408,37 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 
 }  // namespace
 
+static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
+    raised = true;
+  }
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? (prop.multiProcessorCount & ~7) : 256; }
+  if (nontemporal) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
+  return ctclip_check_launch("gemm_nt");
+}
+
+// Row-wise arg-max of A B^T on the same kernel (ctclip_gemm_argmax, bf16): partials (M x nparts), nparts = 2 * ceil(N / 256).
+// Returns 1 when the shape is not eligible.
+int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
+                              int32_t* part_idx, int* nparts, hipStream_t stream) {
+  if (K % TK || K / TK < 2) return 1;
+  if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
+  const int64_t ntm = cdiv(M, TM), ntn = cdiv(N, TN);
+  if (ntm * ntn < 160) return 1;
+  NtParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.alpha = 1.f;
+  p.ntm = (int)ntm; p.ntn = (int)ntn;
+  p.part_val = part_val; p.part_idx = part_idx; p.nparts = (int)(2 * ntn);
+  *nparts = p.nparts;
+  return nt_launch(p, false, stream);
+}
+
 // Internal entry used by ctclip_gemm's dispatcher (gemm.hip).  Returns 1 when the shape is not eligible.
 int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
@@ -398,18 +454,8 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.out_dtype = out_dtype; p.res_dtype = res_dtype; p.accumulate = accumulate; p.alpha = alpha;
   p.ntm = (int)ntm; p.ntn = (int)ntn;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
-    raised = true;
-  }
-  static int ncu = 0;
-  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? (prop.multiProcessorCount & ~7) : 256; }
   // outputs that cannot stay in the 32 MiB of L2 anyway are written with the non-temporal hint (measured -9 % on the 623-MB FF
   // hidden activation: they no longer evict the operand panels the other CUs of the XCD are about to re-read)
   const bool nontemporal = ((NT_ABL & 64) != 0) || (M * N * (out_dtype == DT_F32 ? 4 : 2) > ((int64_t)NT_STREAM_MB << 20));
-  if (nontemporal) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
-  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
-  return ctclip_check_launch("gemm_nt");
+  return nt_launch(p, nontemporal, stream);
 }

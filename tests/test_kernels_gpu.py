@@ -107,6 +107,25 @@ def test_gemm_argmax(hip, ref, dtype):
     assert not (idx2 == 900).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 8192, 256), (5000, 8200, 128)])
+def test_gemm_argmax_large_runs_on_the_nt_kernel(hip, ref, M, N, K):
+    """The vector-quantiser code search at training size (110592 x 8192) goes through the persistent NT kernel's arg-max epilogue."""
+    xn = torch.nn.functional.normalize(rnd(M, K, seed=12), dim=-1).to(torch.bfloat16)
+    en = torch.nn.functional.normalize(rnd(N, K, seed=13), dim=-1).to(torch.bfloat16)
+    idx, val = hip.gemm_argmax(xn, en)
+    sim = xn.float() @ en.float().t()
+    rval, ridx = sim.max(dim=-1)
+    close(val, rval, rtol=1e-3, atol=1e-3)
+    agree = (idx == ridx).float().mean().item()
+    assert agree >= 0.99, agree
+    # where the indices differ the values are ties up to accumulation order
+    picked = sim.gather(1, idx[:, None])[:, 0]
+    assert (rval - picked).max().item() < 2e-3
+    e2 = en.clone(); e2[5] = e2[N - 7]                     # ties -> lowest index
+    idx2, _ = hip.gemm_argmax(xn, e2)
+    assert not (idx2 == N - 7).any()
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,cols", [(37, 512), (1000, 768), (5, 64), (130, 2048)])
