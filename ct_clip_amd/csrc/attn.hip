@@ -947,24 +947,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnParams p) {
   }
 }
 
-// dBias for the CTViT shape, workgroup-shared: a workgroup owns one query block and FOUR neighbouring key blocks of one head (one
-// (query, key) tile pair per wave) and walks a strided subset of the sequences.  Per sequence the ten operand tiles (Q, dO of the
-// query block; K, V of the four key blocks) are staged once through LDS with five coalesced 16-byte loads per thread; the
-// register-only attn_bwd_dbias_kernel issues eight scattered loads per lane and sequence and waits for them more than half of its
-// time (SQ_WAIT_INST_ANY 54 % of SQ_WAVE_CYCLES).  Same fast-path conventions as above (log2 domain, full tiles only).
-__global__ __launch_bounds__(256) void attn_bwd_dbias_lds_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
+// dBias for the CTViT shape, workgroup-shared: a workgroup of EIGHT waves owns two neighbouring query blocks and four neighbouring
+// key blocks of one head (one (query, key) tile pair per wave) and walks a strided subset of the sequences.  Per sequence the twelve
+// operand tiles (Q, dO of the two query blocks; K, V of the four key blocks) are staged once through LDS with three coalesced
+// 16-byte loads per thread -- 1.5 tiles of traffic per tile pair (the 1 x 4 arrangement of the first LDS version moved 2.5 and sat
+// at the L2 bandwidth; the register-only attn_bwd_dbias_kernel issues eight scattered loads per lane and sequence and waits for
+// them more than half of its time, SQ_WAIT_INST_ANY 54 % of SQ_WAVE_CYCLES).  Same fast-path conventions as above (log2 domain,
+// full tiles only).
+__global__ __launch_bounds__(512) void attn_bwd_dbias_lds_kernel(AttnParams p, float* __restrict__ dbias_part, int nsplit) {
   typedef bf16_t T;
   constexpr int D = 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = p.L, nkb = L / 32, ngrp = (nkb + 3) / 4;
-  const int qb = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
-  const int kb_raw = kg * 4 + wave;
-  const bool active = kb_raw < nkb;
-  const int kb = active ? kb_raw : nkb - 1;
+  const int qg = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
+  const int qsel = wave >> 2, ksel = wave & 3;
+  const int qb_raw = qg * 2 + qsel, kb_raw = kg * 4 + ksel;
+  const bool active = qb_raw < nkb && kb_raw < nkb;
+  const int qb = qb_raw < nkb ? qb_raw : nkb - 1, kb = kb_raw < nkb ? kb_raw : nkb - 1;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int qi = qb * 32 + c;
-  __shared__ __attribute__((aligned(16))) char tiles[2][10][STILE];     // [buffer][Q, dO, K x4, V x4]
-  __shared__ float stats[2][2][32];                                      // [buffer][lse * log2 e, delta][query of the block]
+  __shared__ __attribute__((aligned(16))) char tiles[2][12][STILE];     // [buffer][Q x2, dO x2, K x4, V x4]
+  __shared__ float stats[2][2][2][32];                                   // [buffer][query block][lse * log2 e, delta][query]
   const T* Q = reinterpret_cast<const T*>(p.q);
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* V = reinterpret_cast<const T*>(p.v);
@@ -984,47 +987,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_lds_kernel(AttnParams p, f
   }
   const float scale2 = p.scale * LOG2E;
 
-  // staging: pass i (0..4) fills tiles 2i and 2i+1 (threads 0-127 / 128-255)
+  // staging: pass i (0..2) fills tiles 4i .. 4i+3 (128 threads each): pass 0 = Q0 Q1 dO0 dO1, pass 1 = K0..K3, pass 2 = V0..V3
   const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
-  const T* sbase[5]; int64_t sld[5]; int stok[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int tt = 2 * i + stile;
-    if (tt == 0) { sbase[i] = Q; sld[i] = p.ldq; stok[i] = qb * 32; }
-    else if (tt == 1) { sbase[i] = dO; sld[i] = p.lddo; stok[i] = qb * 32; }
-    else if (tt < 6) { sbase[i] = K; sld[i] = p.ldk; stok[i] = (kg * 4 + tt - 2) * 32; }
-    else { sbase[i] = V; sld[i] = p.ldv; stok[i] = (kg * 4 + tt - 6) * 32; }
-  }
-  auto gstat = [&](int seq) {                                  // threads 0-31: lse, 32-63: delta of the block's 32 queries
-    return ((threadIdx.x & 32) ? p.delta : p.lse) + ((int64_t)seq * p.H + h) * L + qb * 32 + (threadIdx.x & 31);
+  const T* sbase[3] = {stile < 2 ? Q : dO, K, V};
+  const int64_t sld[3] = {stile < 2 ? p.ldq : p.lddo, p.ldk, p.ldv};
+  const int stok[3] = {(qg * 2 + (stile & 1)) * 32, (kg * 4 + stile) * 32, (kg * 4 + stile) * 32};
+  auto gstat = [&](int seq) {    // threads 0-127: [query block][lse | delta][32 queries]
+    int q = (qg * 2 + ((threadIdx.x >> 6) & 1)) * 32 + (threadIdx.x & 31);
+    q = q < L ? q : L - 1;
+    return ((threadIdx.x & 32) ? p.delta : p.lse) + ((int64_t)seq * p.H + h) * L + q;
   };
   const float smul = (threadIdx.x & 32) ? 1.f : LOG2E;
-  char* sdst = &tiles[0][stile][0] + srow * SROW + schunk * 16;          // + 2 * i * STILE per pass, + 10 * STILE per buffer
-  float* sstat = &stats[0][(threadIdx.x >> 5) & 1][threadIdx.x & 31];
+  char* sdst = &tiles[0][stile][0] + srow * SROW + schunk * 16;          // + 4 * i * STILE per pass, + 12 * STILE per buffer
+  float* sstat = &stats[0][0][0][0] + (threadIdx.x & 127);
 
   int seq = split;
   if (seq >= p.nseq) return;                                             // workgroup-uniform
-  u32x4 st[5];
+  u32x4 st[3];
   float sv;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)seq * L, stok[i], L, sld[i], h * D, srow, schunk));
+  for (int i = 0; i < 3; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)seq * L, stok[i], L, sld[i], h * D, srow, schunk));
   sv = *gstat(seq) * smul;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) *reinterpret_cast<u32x4*>(sdst + 2 * i * STILE) = st[i];
-  if (threadIdx.x < 64) *sstat = sv;
+  for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sdst + 4 * i * STILE) = st[i];
+  if (threadIdx.x < 128) *sstat = sv;
   __syncthreads();
   for (int it = 0; seq < p.nseq; seq += nsplit, ++it) {
     const int buf = it & 1;
     const int sn = seq + nsplit < p.nseq ? seq + nsplit : seq;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)sn * L, stok[i], L, sld[i], h * D, srow, schunk));
+    for (int i = 0; i < 3; ++i) st[i] = *reinterpret_cast<const u32x4*>(src_rows(sbase[i], (int64_t)sn * L, stok[i], L, sld[i], h * D, srow, schunk));
     sv = *gstat(sn) * smul;
     Frag<T, D> qf, dof, kf, vf;
-    lds_frag(qf, tiles[buf][0], c, half);          // B operands: the lane's own query row (no pi32)
-    lds_frag(dof, tiles[buf][1], c, half);
-    lds_frag(kf, tiles[buf][2 + wave], ar, half);
-    lds_frag(vf, tiles[buf][6 + wave], ar, half);
-    const float lse2 = stats[buf][0][c], delta = stats[buf][1][c];
+    lds_frag(qf, tiles[buf][qsel], c, half);          // B operands: the lane's own query row (no pi32)
+    lds_frag(dof, tiles[buf][2 + qsel], c, half);
+    lds_frag(kf, tiles[buf][4 + ksel], ar, half);
+    lds_frag(vf, tiles[buf][8 + ksel], ar, half);
+    const float lse2 = stats[buf][qsel][0][c], delta = stats[buf][qsel][1][c];
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1033,8 +1032,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_lds_kernel(AttnParams p, f
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fmaf(__builtin_amdgcn_exp2f(fmaf(s[r], scale2, add[r]) - lse2), dp[r] - delta, acc[r]);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) *reinterpret_cast<u32x4*>(sdst + (buf ^ 1) * 10 * STILE + 2 * i * STILE) = st[i];
-    if (threadIdx.x < 64) sstat[(buf ^ 1) * 64] = sv;
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(sdst + (buf ^ 1) * 12 * STILE + 4 * i * STILE) = st[i];
+    if (threadIdx.x < 128) sstat[(buf ^ 1) * 128] = sv;
     __syncthreads();
   }
   if (active) {
@@ -1372,8 +1371,8 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     dim3 grid((unsigned)((nkb * nkb + 3) / 4), H, ns);
     float* ws = (float*)workspace;
     if (dtype == DT_BF16 && D == 32 && L >= 128 && (L % 32) == 0 && !keymask && attn_lds_enabled()) {
-      dim3 grid2((unsigned)(nkb * ((nkb + 3) / 4)), H, ns);
-      hipLaunchKernelGGL(attn_bwd_dbias_lds_kernel, grid2, dim3(256), 0, stream, p, ws, ns);
+      dim3 grid2((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, ns);
+      hipLaunchKernelGGL(attn_bwd_dbias_lds_kernel, grid2, dim3(512), 0, stream, p, ws, ns);
     } else if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, p, ws, ns);
     else if (dtype == DT_BF16 && D == 64) hipLaunchKernelGGL((attn_bwd_dbias_kernel<bf16_t, 64>), grid, dim3(256), 0, stream, p, ws, ns);
     else if (dtype == DT_F32 && D == 32) hipLaunchKernelGGL((attn_bwd_dbias_kernel<float, 32>), grid, dim3(256), 0, stream, p, ws, ns);
