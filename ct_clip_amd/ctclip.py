@@ -90,6 +90,22 @@ class CTCLIP(nn.Module):
         dev = self.temperature.device
         return self.tokenizer(prompt, return_tensors="pt", padding="max_length", truncation=True, max_length=512).to(dev)
 
+    # ---- the two towers on their own (additive API: zero-shot scoring, latent export -- the reference re-runs the whole forward)
+    def encode_text(self, text):
+        """HF BatchEncoding-like (.input_ids, .attention_mask) -> (Bt, dim_latent) l2-normalised f32 text latents (ct_clip.py:685-686,762,771)."""
+        ids, mask = text.input_ids, text.attention_mask
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self.compute_dtype)
+        cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
+        return Fn.l2norm_f32(Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32))
+
+    def encode_image(self, image, return_tokens=False):
+        """(Bi, 1, F, H, W) volume -> (Bi, dim_latent) l2-normalised f32 image latents (ct_clip.py:715-767,771) [, the token grid]."""
+        enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)
+        Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
+        enc_image = Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1))
+        lat = Fn.l2norm_f32(Fn.visual_latent(enc_image, self.to_visual_latent.weight))
+        return (lat, enc_tokens) if return_tokens else lat
+
     def forward(self, text, image, device=None, return_loss=False, return_encodings=False, return_latents=False,
                 freeze_image_encoder=False, freeze_text_encoder=False, text_to_image=True, aug_text=None, aug_image=None):
         # freeze_* are accepted and ignored exactly as in the reference (ct_clip.py:709-715)
