@@ -70,3 +70,20 @@ def test_inference_driver_writes_the_reference_files(golden, ref_backend, tmp_pa
     assert np.load(tmp_path / "zs" / "labels_weights.npz")["data"].shape == (2, 2)
     assert (tmp_path / "zs" / "accessions.txt").read_text().split() == ["acc_0", "acc_1"]
     assert int(inf.steps.item()) == 1
+
+
+def test_latent_export_matches_return_latents(golden, ref_backend, tmp_path):
+    """scripts/forward_data.py: text/<acc>.npz and image/<acc>.npz hold exactly CTCLIP.forward(return_latents=True)[0:2]."""
+    from ct_clip_amd.forward_data import CTClipInference as Export
+    g = golden("tiny")
+    c = g["config"]
+    clip = build_model(c, g["state_dict"], torch.device("cpu"), torch.float32).eval()
+    tok = StubTokenizer(c["vocab"], 32)
+    torch.manual_seed(5)
+    vol = torch.rand(1, c["frames"], c["image"], c["image"]) * 2 - 1
+    Export(clip, results_folder=str(tmp_path / "lat"), dataset=[(vol, "no acute findings", torch.zeros(1, 2), "case_7")], tokenizer=tok,
+           max_text_len=32).infer()
+    with torch.no_grad():
+        tl, il, _ = clip(tok(["no acute findings"], max_length=32), vol[None], device=torch.device("cpu"), return_latents=True)
+    np.testing.assert_allclose(np.load(tmp_path / "lat" / "text" / "case_7.npz")["arr"], tl.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.load(tmp_path / "lat" / "image" / "case_7.npz")["arr"], il.numpy(), rtol=1e-6, atol=1e-7)
