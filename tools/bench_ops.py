@@ -1,5 +1,6 @@
-"""Stand-alone timing of the non-GEMM hot kernels at the bench shapes (bf16, B=8): PEG fwd/bwd, attention fwd/bwd.
-usage: python tools/bench_ops.py [peg|attn|all] [iters]"""
+"""Stand-alone timing of the non-GEMM hot kernels at the bench shapes (bf16, B=8): PEG, spatial / temporal attention, the streaming
+kernels (LayerNorm, GEGLU, qk-norm, head transpose).
+usage: python tools/bench_ops.py [peg|attn|tattn|stream|all] [iters]"""
 import json
 import os
 import sys
@@ -68,4 +69,41 @@ if what in ("attn", "all"):
     for name, (fn, fl) in cases.items():
         us = timeit(fn)
         out[name] = dict(avg_us=round(us, 1), tflops=round(fl / us / 1e6, 1))
+if what in ("tattn", "all"):
+    # temporal attention of the CTViT: 4608 sequences of 24 tokens, 8 heads x 32, no bias
+    nseq, H, L, D = 8 * 576, 8, 24, 32
+    HD, M = H * D, nseq * L
+    nrm = lambda t: torch.nn.functional.normalize(t.float().reshape(M, H, D), dim=-1).view(M, HD).to(torch.bfloat16)
+    q, k, v, do = nrm(rnd(M, HD)), nrm(rnd(M, HD)), rnd(M, HD), rnd(M, HD)
+    vt = be.head_transpose(v, nseq, H, L, D)
+    o, lse = be.attn_fwd(q, k, vt, None, None, nseq, H, L, D, 8.0)
+    qt, kt, dot = (be.head_transpose(t, nseq, H, L, D) for t in (q, k, do))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    out["attn_fwd temporal (4608 x 24)"] = dict(avg_us=round(timeit(lambda: be.attn_fwd(q, k, vt, None, None, nseq, H, L, D, 8.0)), 1))
+    out["attn_bwd temporal (4608 x 24)"] = dict(avg_us=round(timeit(
+        lambda: be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, None, dq, dk, dv, None, nseq, H, L, D, 8.0)), 1))
+if what in ("stream", "all"):
+    M, d, Hp = 110592, 512, 1408
+    x, dy = rnd(M, d), rnd(M, d)
+    gamma, beta = rnd(d, dt=torch.float32), rnd(d, dt=torch.float32)
+    nb = x.numel() * 2
+    y, mean, rstd = be.layernorm_fwd(x, gamma, beta, 1e-5)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    us = timeit(lambda: be.layernorm_fwd(x, gamma, beta, 1e-5))
+    out["layernorm_fwd (110592 x 512)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(2 * nb / us / 1e3, 1))
+    us = timeit(lambda: be.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db))
+    out["layernorm_bwd + dgamma/dbeta"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(3 * nb / us / 1e3, 1))
+    us = timeit(lambda: be.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, x, dy))
+    out["layernorm_bwd + two addends"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(5 * nb / us / 1e3, 1))
+    u, dgl = rnd(M, 2 * Hp), rnd(M, Hp)
+    us = timeit(lambda: be.geglu_fwd(u))
+    out["geglu_fwd (110592 x 2816)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(3 * M * Hp * 2 / us / 1e3, 1))
+    us = timeit(lambda: be.geglu_bwd(dgl, u))
+    out["geglu_bwd"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(5 * M * Hp * 2 / us / 1e3, 1))
+    q = rnd(M, 256)
+    sv = rnd(32, dt=torch.float32)
+    us = timeit(lambda: be.qk_norm_fwd(q, sv, 8, 32))
+    out["qk_norm_fwd (110592 x 256)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(2 * q.numel() * 2 / us / 1e3, 1))
+    us = timeit(lambda: be.head_transpose(q, 192, 8, 576, 32))
+    out["head_transpose (192 x 8 x 576 x 32)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(2 * q.numel() * 2 / us / 1e3, 1))
 print(json.dumps(out, indent=1))
