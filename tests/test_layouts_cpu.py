@@ -1,0 +1,99 @@
+"""The index arithmetic the HIP kernels rest on, restated in Python and checked exhaustively (no GPU): operand permutations are
+bijections, LDS images are bank-conflict free for the service groups MI355X_MICROARCH.md lists, the transposing-read image of
+gemm_tn.hip delivers the fragment the MFMA expects under the lane mapping measured by tools/tr_probe.hip, and the relative-position
+bias classes of a fragment run are consecutive.  Each function names the kernel lines it mirrors."""
+import itertools
+
+B128_GROUPS = [[*range(0, 4), *range(12, 16), *range(20, 28)], [*range(4, 12), *range(16, 20), *range(28, 32)]]
+B128_GROUPS += [[l + 32 for l in g] for g in B128_GROUPS]          # ds_read_b128: four groups of 16 lanes, one LDS cycle each
+
+
+def slots16(addrs):
+    """16-byte slot of the 256-byte bank row touched by each address"""
+    return [(a // 16) % 16 for a in addrs]
+
+
+def test_gemm_nt_b_row_permutation_and_epilogue_columns():
+    # gemm_nt.hip enter_b: LDS row rho of the B panel holds tile column (rho & 0x80) + (rho & 15) * 8 + ((rho >> 4) & 7)
+    col = lambda rho: (rho & 0x80) + ((rho & 15) << 3) + ((rho >> 4) & 7)
+    assert sorted(col(r) for r in range(256)) == list(range(256))
+    # fragment b of wave column wn reads LDS rows wn*128 + b*16 + li: lane li then owns columns wn*128 + li*8 + b, b = 0..7
+    for wn, li in itertools.product(range(2), range(16)):
+        assert [col(wn * 128 + b * 16 + li) for b in range(8)] == [wn * 128 + li * 8 + b for b in range(8)]
+
+
+def test_gemm_nt_fragment_reads_are_bank_conflict_free():
+    # gemm_nt.hip swz(): row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); lane (li, lg) reads row base + li, chunk ks*4 + lg
+    swz = lambda row, chunk: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+    for base, ks in itertools.product(range(0, 256, 16), range(2)):
+        for grp in B128_GROUPS:
+            addrs = [swz(base + (l & 15), ks * 4 + (l >> 4)) for l in grp]
+            assert len(set(slots16(addrs))) == 16
+
+
+def tr_read(lds, lane_addr):
+    """ds_read_b64_tr_b16 as measured (tools/tr_probe.hip): in each 16-lane group, output lane i element j = element i & 3 of the
+    four bf16 addressed by lane 4 j + (i >> 2).  lds: dict byte address -> value of the 2-byte element at that address."""
+    out = {}
+    for g in range(4):
+        for i in range(16):
+            out[g * 16 + i] = [lds[lane_addr[g * 16 + 4 * j + (i >> 2)] + 2 * (i & 3)] for j in range(4)]
+    return out
+
+
+def test_gemm_tn_transposed_fragments():
+    # gemm_tn.hip loader: piece = wave*4 + j, quarter qd = piece >> 3, k row r = (piece & 7) * 8 + (lane >> 3), LDS position
+    # pos = lane & 7 holds source sub-chunk c = (pos >> 1) ^ ((r >> 1) & 3), half pos & 1  ->  tile column qd*64 + c*16 + (pos&1)*8 + e
+    lds = {}
+    for piece, lane in itertools.product(range(32), range(64)):
+        qd, r, pos = piece >> 3, (piece & 7) * 8 + (lane >> 3), lane & 7
+        c = (pos >> 1) ^ ((r >> 1) & 3)
+        col0 = qd * 64 + c * 16 + (pos & 1) * 8
+        for e in range(8):
+            lds[piece * 1024 + lane * 16 + 2 * e] = (r, col0 + e)          # (k, column) stored at this LDS address
+    assert len(lds) == 64 * 256                                            # every (k, column) of the 64 x 256 panel exactly once
+    assert sorted(lds.values()) == [(k, c) for k in range(64) for c in range(256)]
+    # fragment read (read_frag / fadr): lane (li, lg) addresses row ks*32 + 16*second + lg*4 + (li >> 2), sub-chunk c, piece li & 3
+    for q, c, ks in itertools.product(range(4), range(4), range(2)):
+        frag = {l: [] for l in range(64)}
+        for second in range(2):
+            addr = {}
+            for l in range(64):
+                li, lg = l & 15, l >> 4
+                frow = lg * 4 + (li >> 2)
+                r = ks * 32 + 16 * second + frow
+                addr[l] = q * 8192 + r * 128 + ((c ^ ((frow >> 1) & 3)) << 5) + (li & 3) * 8
+                # bank check: a half-wave (32 lanes) must cover 32 distinct 8-byte slots of the 256-byte bank row
+            for half in range(2):
+                assert len({(addr[l] // 8) % 32 for l in range(half * 32, half * 32 + 32)}) == 32
+            got = tr_read(lds, addr)
+            for l in range(64):
+                frag[l] += got[l]
+        for l in range(64):
+            li, lg = l & 15, l >> 4
+            # lane (li, lg) holds column q*64 + c*16 + li at the eight k-slots 4 lg + j and 16 + 4 lg + j of this sub-step
+            assert frag[l] == [(ks * 32 + s * 16 + lg * 4 + j, q * 64 + c * 16 + li) for s in range(2) for j in range(4)]
+
+
+def test_attention_lds_tile_rows_are_conflict_free():
+    # attn.hip lds_frag: tile + pi32(c) * 80 + half * 16 (+ 32): rows are 80 bytes apart
+    pi32 = lambda c: (c & 3) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 16)
+    for off in (0, 32):
+        for grp in B128_GROUPS:
+            addrs = [pi32(l & 31) * 80 + (l >> 5) * 16 + off for l in grp]
+            assert len(set(slots16(addrs))) == 16
+
+
+def test_relative_bias_classes_of_a_fragment_run_are_consecutive():
+    # attn.hip tile_logits_fast: u(t) = (t // gw) * (2 gw - 1) + t % gw, class(i, j) = u(i) - u(j) + c0; the eight keys of a run
+    # (8-aligned) lie in one image row when gw % 8 == 0, so class(i, j0 + e) = class(i, j0) - e
+    for gh, gw in ((24, 24), (3, 8), (5, 16)):
+        u = lambda t: (t // gw) * (2 * gw - 1) + t % gw
+        c0 = (gh - 1) * (2 * gw - 1) + (gw - 1)
+        cls = lambda i, j: (i // gw - j // gw + gh - 1) * (2 * gw - 1) + (i % gw - j % gw + gw - 1)
+        L = gh * gw
+        for i in range(L):
+            for j0 in range(0, L, 8):
+                base = u(i) - u(j0) + c0
+                assert [cls(i, j0 + e) for e in range(8)] == [base - e for e in range(8)]
+                assert 0 <= base - 7 and base < (2 * gh - 1) * (2 * gw - 1)
