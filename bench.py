@@ -8,8 +8,11 @@ gathered-negatives CLIP loss, backward, gradient all-reduce (N > 1), global grad
 already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel (bf16 MFMA GEMM, FeedForward in-projection shape): algorithmic FLOPs per launch / mean
-                  launch duration measured with events on the launch stream inside the timed steps, vs the 2.5 PFLOP/s dense peak.
+  roofline     -- the GEMM shape with the largest total time in the timed steps (round 1: the weight-gradient GEMM M=1365 N=512
+                  K=110592 on gemm_tn_kernel): algorithmic FLOPs per launch / mean launch duration measured with events on the
+                  launch stream around every launch, vs the 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch of the
+                  same kernel and shape from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), top5 = the
+                  other shapes.
   cpu_baseline -- the CPU oracle (a restatement of the reference, kind "port") timed on the host cores on a bounded sample
                   (one volume of the same configuration, one training step).
 """
