@@ -47,9 +47,18 @@ def synth_inputs(c):
 def subsample(t, limit=20000):
     flat = t.detach().reshape(-1)
     if flat.numel() <= limit:
-        return dict(full=True, value=t.detach().clone())
+        return dict(full=True, value=t.detach().clone(), norm=flat.norm().clone())
     stride = (flat.numel() + limit - 1) // limit
     return dict(full=False, stride=stride, value=flat[::stride].clone(), norm=flat.norm().clone())
+
+
+def perturb_1d(clip, seed):
+    """Make every 1-D parameter "interesting" (LayerNorm gammas=1 / biases=0 / scales=1 at init hide bugs)."""
+    g = torch.Generator().manual_seed(99 + seed)
+    with torch.no_grad():
+        for name, p in clip.named_parameters():
+            if p.ndim <= 1 and p.numel() > 0 and name != "temperature":
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
 
 
 def build(c):
@@ -71,12 +80,7 @@ def build(c):
                              dim_image=hw * hw * c["dim"], dim_latent=c["dim_latent"],
                              extra_latent_projection=False, use_mlm=False, downsample_image_embeds=False,
                              use_all_token_embeds=False)
-    # make every parameter "interesting" (LayerNorm gammas=1 / biases=0 / scales=1 at init hide bugs)
-    g = torch.Generator().manual_seed(99 + c["seed"])
-    with torch.no_grad():
-        for name, p in clip.named_parameters():
-            if p.ndim <= 1 and p.numel() > 0 and name != "temperature":
-                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    perturb_1d(clip, c["seed"])
     ref_shim.seed_rel_pos(image_encoder, hw, hw)
     return clip, t, hw
 
@@ -145,6 +149,113 @@ def run_case(name, c):
           f"({os.path.getsize(path) / 1e6:.1f} MB)")
 
 
+# BASELINE.json configs[1] geometry at the reference scripts' own depth (run_train.py:17-27): 480x480x240, patch 20x20x10,
+# dim 512, 4+4 layers, 8192 codes, BERT-base, T=128; B=2 so that the contrastive loss and all gradients exist.
+# Weights (284 M used parameters) and the 442-MB input batch cannot be stored: both are regenerated from the seeds
+# (`tests/helpers.build_model` + `perturb_1d` + `synth_inputs` below); the fixture holds fingerprints of every reference
+# parameter and of the inputs so a test can prove it rebuilt exactly what the reference ran on.
+FULL_CASE = dict(seed=2, batch=2, frames=240, image=480, patch=20, tpatch=10, dim=512, sdepth=4, tdepth=4,
+                 heads=8, dim_head=32, codebook=8192, T=128, bert_hidden=768, bert_layers=12, bert_heads=12,
+                 bert_inter=3072, vocab=30522, max_pos=512, dim_latent=512)
+
+
+def fingerprint(t):
+    f = t.detach().reshape(-1).double()
+    return dict(shape=tuple(t.shape), sum=float(f.sum()), abssum=float(f.abs().sum()),
+                head=t.detach().reshape(-1)[:4].clone(), tail=t.detach().reshape(-1)[-4:].clone())
+
+
+def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000):
+    import time
+    t0 = time.time()
+    clip, t, hw = build(c)
+    video, ids, mask = synth_inputs(c)
+    text = ref_shim.TextBatch(ids, mask)
+    sd0 = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    unused = ("_extra.", "to_pixels", "to_patch_emb_first_frame", "pooler.")
+    prints = {k: fingerprint(v) for k, v in sd0.items() if not any(u in k for u in unused)}
+
+    # the product's own constructors under the same seed + the same perturbation must give the SAME weights (this is what
+    # lets the GPU test rebuild them without the reference): checked here, key by key, bit for bit
+    from tests.helpers import build_model, perturb_1d
+    mine = build_model(c, None, torch.device("cpu"), torch.float32)
+    perturb_1d(mine, c["seed"])
+    sdm = mine.state_dict()
+    for k in prints:
+        if k.endswith("position_ids") or k.endswith("token_type_ids"):
+            continue
+        assert torch.equal(sdm[k], sd0[k]), f"seeded rebuild differs from the reference at {k}"
+    del mine, sdm
+    print(f"[{name}] reference built, seeded rebuild identical ({time.time() - t0:.0f} s)", flush=True)
+
+    inter = {}
+    vt = clip.visual_transformer
+
+    def hook(key, f=lambda o: o):
+        def fn(_m, _i, o):
+            o = o[0] if isinstance(o, tuple) else o
+            inter[key] = subsample(f(o), inter_limit)
+        return fn
+
+    L = hw * hw
+    corner_rows = [0, hw - 1, L - hw, L - 1]     # the four corner queries see every one of the (2h-1)(2w-1) offsets
+    hs = [vt.to_patch_emb.register_forward_hook(hook("patch_emb")),
+          vt.spatial_rel_pos_bias.register_forward_hook(hook("attn_bias_corner_rows", lambda o: o[:, corner_rows, :])),
+          vt.enc_spatial_transformer.register_forward_hook(hook("spatial_out")),
+          vt.enc_temporal_transformer.register_forward_hook(hook("temporal_out")),
+          vt.enc_spatial_transformer.layers[0][0].register_forward_hook(hook("s0_peg")),
+          vt.enc_spatial_transformer.layers[0][1].register_forward_hook(hook("s0_attn")),
+          vt.enc_spatial_transformer.layers[0][3].register_forward_hook(hook("s0_ff")),
+          vt.enc_temporal_transformer.layers[0][0].register_forward_hook(hook("t0_peg")),
+          vt.enc_temporal_transformer.layers[0][1].register_forward_hook(hook("t0_attn")),
+          vt.enc_temporal_transformer.layers[0][3].register_forward_hook(hook("t0_ff"))]
+    vq_out = {}
+
+    def vq_hook(_m, _i, o):
+        vq_out["indices"] = o[1].detach().clone()
+    hs.append(vt.vq.register_forward_hook(vq_hook))
+
+    clip.train()
+    loss = clip(text, video, return_loss=True, device=torch.device("cpu"))
+    print(f"[{name}] train forward done, loss {float(loss):.6f} ({time.time() - t0:.0f} s)", flush=True)
+    loss.backward()
+    print(f"[{name}] backward done ({time.time() - t0:.0f} s)", flush=True)
+    grads = {k: subsample(p.grad, grad_limit) for k, p in clip.named_parameters() if p.grad is not None}
+    for k, p in clip.named_parameters():
+        if p.grad is not None:
+            grads[k]["norm"] = p.grad.detach().norm().clone()
+    grad_sq = sum(float((p.grad.double() ** 2).sum()) for p in clip.parameters() if p.grad is not None)
+    sd1 = clip.state_dict()
+    vq_after = {"visual_transformer.vq._codebook.cluster_size": sd1["visual_transformer.vq._codebook.cluster_size"].detach().clone(),
+                "visual_transformer.vq._codebook.embed": subsample(sd1["visual_transformer.vq._codebook.embed"], inter_limit)}
+    for h in hs:
+        h.remove()
+    clip.zero_grad(set_to_none=True)
+
+    clip.load_state_dict(sd0)
+    clip.eval()
+    with torch.no_grad():
+        tl, il, toks = clip(text, video, return_latents=True, device=torch.device("cpu"))
+        enc_text, enc_image = clip(text, video, return_encodings=True, device=torch.device("cpu"))
+        ev_idx = vt(video, return_only_codebook_ids=True)
+    print(f"[{name}] eval forwards done ({time.time() - t0:.0f} s)", flush=True)
+    out = dict(config=c, weight_fingerprints=prints, video_fingerprint=fingerprint(video), input_ids=ids, attention_mask=mask,
+               loss=loss.detach().clone(), intermediates=inter, vq_indices=vq_out["indices"].to(torch.int16),
+               grads=grads, grad_norm=torch.tensor(grad_sq).sqrt().float(), vq_after=vq_after,
+               eval_text_latents=tl, eval_image_latents=il, eval_tokens=subsample(toks, inter_limit),
+               eval_vq_indices=ev_idx.to(torch.int16), eval_enc_text_cls=enc_text[:, 0].clone(),
+               eval_enc_image=subsample(enc_image, inter_limit))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: loss={float(loss):.6f} grad_norm={float(out['grad_norm']):.6f} -> {path} "
+          f"({os.path.getsize(path) / 1e6:.1f} MB)")
+
+
 if __name__ == "__main__":
-    for name, c in CASES.items():
-        run_case(name, c)
+    which = sys.argv[1:] or list(CASES)
+    for name in which:
+        if name == "full1":
+            run_full_case()
+        else:
+            run_case(name, CASES[name])

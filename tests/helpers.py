@@ -34,6 +34,37 @@ def build_model(c, state_dict, device, compute_dtype):
     return clip.to(device)
 
 
+def perturb_1d(clip, seed):
+    """The perturbation oracle/gen_golden.py applies to the reference after init (every 1-D parameter += 0.1 * randn)."""
+    g = torch.Generator().manual_seed(99 + seed)
+    with torch.no_grad():
+        for name, p in clip.named_parameters():
+            if p.ndim <= 1 and p.numel() > 0 and name != "temperature":
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+def synth_inputs(c):
+    """Same seeded inputs as oracle/gen_golden.py:synth_inputs (the full-size fixture stores only their fingerprints)."""
+    g = torch.Generator().manual_seed(1234 + c["seed"])
+    video = torch.rand(c["batch"], 1, c["frames"], c["image"], c["image"], generator=g) * 2 - 1
+    T = c["T"]
+    ids = torch.randint(3, c["vocab"], (c["batch"], T), generator=g)
+    lens = torch.randint(T // 2, T + 1, (c["batch"],), generator=g)
+    ids[:, 0] = 1
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    for b in range(c["batch"]):
+        ids[b, lens[b] - 1] = 2
+    ids = ids * mask
+    return video, ids, mask.long()
+
+
+def fingerprint_ok(t, fp, exact=True):
+    f = t.detach().reshape(-1).double()
+    return (tuple(t.shape) == tuple(fp["shape"]) and torch.equal(t.detach().reshape(-1)[:4].cpu(), fp["head"])
+            and torch.equal(t.detach().reshape(-1)[-4:].cpu(), fp["tail"])
+            and abs(float(f.sum()) - fp["sum"]) <= 1e-9 * max(1.0, fp["abssum"]))
+
+
 def check_grad(rec, mine, rtol, atol_rel, floor=0.0):
     """floor: absolute noise floor (gradients that are mathematically zero, e.g. a bias in front of a LayerNorm, come
     out as rounding noise ~1e-11 in both implementations)."""
