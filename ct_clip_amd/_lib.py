@@ -27,6 +27,9 @@ SIGNATURES = {
     "ctclip_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "ctclip_patch_ln_fwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "ctclip_l2norm_rows": (_I, [_P, _P, _P, _L, _I, _L, _F, _I, _I, _P]),
+    "ctclip_l2norm_split3": (_I, [_P, _P, _P, _L, _I, _L, _F, _I, _I, _P]),
+    "ctclip_segment_sum_workspace": (_L, [_L, _I]),
+    "ctclip_segment_sum": (_I, [_P, _I, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "ctclip_peg_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ctclip_peg_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ctclip_head_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),

@@ -174,6 +174,27 @@ class HipBackend:
         _lib.check(rc, "ctclip_l2norm_rows")
         return y, inv
 
+    def l2norm_split3(self, x, order, eps=1e-12):
+        """Unit rows as the bf16 expansion [hi | hi | lo] (order 0) / [hi | lo | hi] (order 1): (rows, 3 * cols) bf16, inv norms."""
+        rows, cols = x.shape
+        y = torch.empty((rows, 3 * cols), dtype=torch.bfloat16, device=x.device)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rc = self.lib.ctclip_l2norm_split3(_p(x), _p(y), _p(inv), rows, cols, _rowmajor(x, "l2norm_split3 x"), float(eps),
+                                           dcode(x.dtype), int(order), _stream())
+        _lib.check(rc, "ctclip_l2norm_split3")
+        return y, inv
+
+    def segment_sum(self, keys, x, out, nseg, rowscale=None, counts=None, accumulate=False, key_mod=0):
+        """out[key[r]] (+)= rowscale[r] * x[r] in ascending row order (deterministic); keys None: key(r) = r % key_mod."""
+        M, d = x.shape
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == nseg * d
+        assert keys is None or (keys.dtype == torch.int64 and keys.is_contiguous() and keys.numel() == M)
+        ws = self.workspace(x.device, self.lib.ctclip_segment_sum_workspace(M, nseg))
+        rc = self.lib.ctclip_segment_sum(_p(keys), int(key_mod), _p(x), _rowmajor(x, "segment_sum x"), _p(rowscale), _p(out), _p(counts),
+                                         M, d, nseg, int(accumulate), dcode(x.dtype), _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_segment_sum")
+        return out
+
     # ------------------------------------------------------------------ PEG
     def peg_fwd(self, x, w, bias):
         B, D1, D2, D3, C = x.shape
@@ -361,11 +382,14 @@ class HipBackend:
         return x
 
     def bert_embed_bwd(self, ids, dx, dword, dpos, dtype0):
+        """Embedding-table gradients as deterministic segmented sums (no float atomics): rows of dx grouped by token id / position."""
         B, T = ids.shape
-        Hd = dx.shape[1]
-        rc = self.lib.ctclip_bert_embed_bwd(_p(ids), _p(dx), _p(dword), _p(dpos), _p(dtype0), B * T, T, Hd, dcode(dx.dtype),
-                                            _stream())
-        _lib.check(rc, "ctclip_bert_embed_bwd")
+        if dword is not None:
+            self.segment_sum(ids.reshape(-1), dx, dword, dword.shape[0], accumulate=True)
+        if dpos is not None:
+            self.segment_sum(None, dx, dpos, dpos.shape[0], accumulate=True, key_mod=T)
+        if dtype0 is not None:
+            self.segment_sum(None, dx, dtype0[:1], 1, accumulate=True, key_mod=1)
 
     # ------------------------------------------------------------------ VQ
     def vq_gather(self, embed, idx, dtype):
@@ -375,12 +399,12 @@ class HipBackend:
         _lib.check(self.lib.ctclip_vq_gather(_p(embed), _p(idx), _p(out), M, d, dcode(dtype), _stream()), "ctclip_vq_gather")
         return out
 
-    def vq_ema(self, idx, xn, cluster_size, embed, decay):
+    def vq_ema(self, idx, x, inv, cluster_size, embed, decay):
+        """bins = histogram(idx), esum[c] = sum of the unit rows x[r] * inv[r] assigned to code c (row order: deterministic)."""
         C, d = embed.shape
-        bins = torch.zeros(C, dtype=torch.float32, device=embed.device)
-        esum = torch.zeros((C, d), dtype=torch.float32, device=embed.device)
-        _lib.check(self.lib.ctclip_vq_ema_accum(_p(idx), _p(xn), _p(bins), _p(esum), idx.numel(), d, dcode(xn.dtype), _stream()),
-                   "ctclip_vq_ema_accum")
+        bins = torch.empty(C, dtype=torch.float32, device=embed.device)
+        esum = torch.empty((C, d), dtype=torch.float32, device=embed.device)
+        self.segment_sum(idx.reshape(-1), x, esum, C, rowscale=inv, counts=bins)
         return bins, esum
 
     def vq_ema_update(self, cluster_size, embed, bins, esum, decay):

@@ -188,7 +188,10 @@ class VectorQuantize(nn.Module):
 
     def forward(self, x2d):
         cb = self._codebook
-        q, idx = Fn.VqFn.apply(x2d, cb.embed[0], cb.cluster_size[0], self.training, cb.decay)
+        # `teacher_indices` (test hook, never set by the product): quantise with the given code ids instead of searching --
+        # SURVEY.md Appendix D protocol 2a, separates kernel error from code flips in bf16 parity tests
+        forced = getattr(self, "teacher_indices", None)
+        q, idx = Fn.VqFn.apply(x2d, cb.embed[0], cb.cluster_size[0], self.training, cb.decay, forced)
         return q, idx
 
 

@@ -158,6 +158,9 @@ int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, 
 /* F.normalize(x, dim=-1) (attention.py:22-23; ct_clip.py:49-50; VQ l2norm). */
 int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int out_dtype, hipStream_t stream);
 
+/* TODO: document */
+int ctclip_l2norm_split3(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int order, hipStream_t stream);
+
 /* bytes of workspace ctclip_grad_norm_clip needs. */
 int64_t ctclip_grad_norm_workspace(void);
 
@@ -166,6 +169,12 @@ int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, floa
 
 /* torch.optim.Adam(lr, betas=(0.9,0.99), eps=1e-8).step() over a flat buffer (optimizer.py:24; CTCLIPTrainer.py:262). */
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, hipStream_t s);
+
+/* TODO: document */
+int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);
+
+/* TODO: document */
+int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* x, int64_t ldx, const float* rowscale, float* out, float* counts_f, int64_t M, int d, int nseg, int accumulate, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }

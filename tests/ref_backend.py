@@ -81,6 +81,28 @@ class RefBackend:
         inv = 1.0 / xf.norm(dim=-1).clamp(min=eps)
         return (xf * inv[:, None]).to(out_dtype), inv
 
+    def l2norm_split3(self, x, order, eps=1e-12):
+        xf = _f(x)
+        inv = 1.0 / xf.norm(dim=-1).clamp_min(eps)
+        t = xf * inv[:, None]
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return torch.cat([hi, hi, lo] if order == 0 else [hi, lo, hi], dim=1), inv
+
+    def segment_sum(self, keys, x, out, nseg, rowscale=None, counts=None, accumulate=False, key_mod=0):
+        M, d = x.shape
+        k = keys.reshape(-1) if keys is not None else torch.arange(M, device=x.device) % key_mod
+        v = _f(x) if rowscale is None else _f(x) * rowscale[:, None]
+        acc = torch.zeros((nseg, d), dtype=torch.float32, device=x.device).index_add_(0, k, v)
+        o = out.view(nseg, d)
+        if accumulate:
+            o += acc
+        else:
+            o.copy_(acc)
+        if counts is not None:
+            counts.copy_(torch.bincount(k, minlength=nseg).float())
+        return out
+
     # ---- PEG
     def peg_fwd(self, x, w, bias):
         C = x.shape[-1]
@@ -302,10 +324,11 @@ class RefBackend:
     def vq_gather(self, embed, idx, dtype):
         return embed[idx.reshape(-1)].to(dtype)
 
-    def vq_ema(self, idx, xn, cluster_size, embed, decay):
+    def vq_ema(self, idx, x, inv, cluster_size, embed, decay):
         C, d = embed.shape
-        bins = torch.bincount(idx.reshape(-1), minlength=C).float()
-        esum = torch.zeros((C, d), device=embed.device).index_add_(0, idx.reshape(-1), _f(xn))
+        xn = _f(x) * inv[:, None]
+        bins = torch.zeros(C, dtype=torch.float32, device=embed.device).index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), device=embed.device))
+        esum = torch.zeros((C, d), dtype=torch.float32, device=embed.device).index_add_(0, idx.reshape(-1), xn)
         return bins, esum
 
     def vq_ema_update(self, cluster_size, embed, bins, esum, decay):

@@ -1,0 +1,133 @@
+"""BASELINE.json configs[1] geometry (480x480x240, patch 20x20x10, dim 512, 24^3 tokens, 8192 codes, BERT-base, T=128) against
+tests/golden/full1.pt -- outputs of the REAL reference at that size (oracle/gen_golden.py full1: 4+4 layers, B=2, forward +
+backward).  Weights and inputs are rebuilt from the seeds (the fixture proves with fingerprints that they are the tensors the
+reference ran on).  Protocol of SURVEY.md Appendix D:
+  * f32 parity mode: tokens / latents / loss <= 1e-4, VQ code agreement >= 99.9 %, gradients by relative Frobenius error;
+  * bf16 performance mode with TEACHER-FORCED VQ indices (kernel error without code flips): loss <= 1e-2 rel, latents cosine;
+  * bf16 free-running: code agreement reported and bounded (>= 0.95), loss bounded.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import TextBatch, build_model, fingerprint_ok, perturb_1d, synth_inputs  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def full():
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "full1.pt"), weights_only=False)
+    c = g["config"]
+    clip = build_model(c, None, torch.device("cpu"), torch.float32)
+    perturb_1d(clip, c["seed"])
+    sd = clip.state_dict()
+    bad = [k for k, fp in g["weight_fingerprints"].items()
+           if not (k.endswith("position_ids") or k.endswith("token_type_ids")) and not fingerprint_ok(sd[k], fp)]
+    assert not bad, f"seeded rebuild differs from the reference weights: {bad[:5]}"
+    video, ids, mask = synth_inputs(c)
+    assert fingerprint_ok(video, g["video_fingerprint"])
+    assert torch.equal(ids, g["input_ids"]) and torch.equal(mask, g["attention_mask"])
+    state = {k: v.clone() for k, v in sd.items()}
+    return g, clip, state, video, ids, mask
+
+
+def sub(rec, mine):
+    m = mine.detach().float().cpu()
+    return m if rec["full"] else m.reshape(-1)[::rec["stride"]]
+
+
+def rel_err(rec, mine):
+    a, b = sub(rec, mine), rec["value"].float().reshape(-1)
+    return float((a.reshape(-1) - b).norm() / (b.norm() + 1e-30))
+
+
+def prepare(full, dtype, train):
+    g, clip, state, video, ids, mask = full
+    clip.load_state_dict(state)
+    clip.compute_dtype = dtype
+    clip.visual_transformer.compute_dtype = dtype
+    clip.to(DEV)
+    clip.train(train)
+    for p in clip.parameters():
+        p.grad = None
+    clip.visual_transformer.vq.__dict__.pop("teacher_indices", None)
+    return g, clip, TextBatch(ids.to(DEV), mask.to(DEV)), video.to(DEV)
+
+
+def test_f32_full_size_matches_reference(full):
+    g, clip, text, video = prepare(full, torch.float32, True)
+    loss = clip(text, video, return_loss=True, device=DEV)
+    rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
+    print(f"[full1 f32] loss {float(loss):.6f} reference {float(g['loss']):.6f} rel {rel:.2e}")
+    assert rel < 1e-4
+    loss.backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
+    assert abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"]) < 1e-3
+    grads = dict((n, p.grad) for n, p in clip.named_parameters() if p.grad is not None)
+    worst, n = ("", 0.0), 0
+    for k, rec in g["grads"].items():
+        if rec["value"].numel() == 0 or float(rec["norm"]) < 1e-7 * float(g["grad_norm"]):
+            continue        # mathematically-zero gradients (a bias in front of a LayerNorm) are rounding noise on both sides
+        e = rel_err(rec, grads[k])
+        if e > worst[1]:
+            worst = (k, e)
+        n += 1
+    print(f"[full1 f32] {n} gradients, worst relative error {worst[1]:.2e} ({worst[0]})")
+    assert n > 150 and worst[1] < 2e-2
+    sd = clip.state_dict()
+    cs, cs_ref = sd["visual_transformer.vq._codebook.cluster_size"].cpu(), g["vq_after"]["visual_transformer.vq._codebook.cluster_size"]
+    ntok = g["vq_indices"].numel()
+    assert float((cs - cs_ref).abs().sum()) <= 0.4 * 1e-3 * ntok + 1e-3     # a flipped code moves two bins by (1 - decay) = 0.2 each
+    assert rel_err(g["vq_after"]["visual_transformer.vq._codebook.embed"], sd["visual_transformer.vq._codebook.embed"]) < 1e-3
+    # eval-mode products, from the ORIGINAL buffers (the train forward above applied the EMA update in place)
+    clip.load_state_dict(full[2])
+    clip.eval()
+    with torch.no_grad():
+        tl, il, toks = clip(text, video, return_latents=True, device=DEV)
+        ids = clip.visual_transformer(video, return_only_codebook_ids=True)
+    agree = (ids.reshape(-1).cpu() == g["eval_vq_indices"].reshape(-1).long()).float().mean().item()
+    print(f"[full1 f32] VQ code agreement {agree:.5f}")
+    assert agree >= 0.999
+    torch.testing.assert_close(tl.cpu(), g["eval_text_latents"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(il.cpu(), g["eval_image_latents"], rtol=1e-3, atol=2e-4)
+    assert rel_err(g["eval_tokens"], toks) < 2e-2      # a flipped code replaces a whole 512-vector: bounded by the agreement above
+
+
+def _bf16_run(full, teacher):
+    g, clip, text, video = prepare(full, torch.bfloat16, True)
+    if teacher:
+        clip.visual_transformer.vq.teacher_indices = g["vq_indices"].long().to(DEV)
+    loss = clip(text, video, return_loss=True, device=DEV)
+    rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
+    loss.backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
+    gn_rel = abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"])
+    clip.load_state_dict(full[2])
+    clip.eval()
+    with torch.no_grad():
+        tl, il, _ = clip(text, video, return_latents=True, device=DEV)
+        clip.visual_transformer.vq.__dict__.pop("teacher_indices", None)
+        ids = clip.visual_transformer(video, return_only_codebook_ids=True)
+    agree = (ids.reshape(-1).cpu() == g["eval_vq_indices"].reshape(-1).long()).float().mean().item()
+    cos_i = torch.nn.functional.cosine_similarity(il.cpu(), g["eval_image_latents"]).min().item()
+    cos_t = torch.nn.functional.cosine_similarity(tl.cpu(), g["eval_text_latents"]).min().item()
+    return rel, gn_rel, agree, cos_i, cos_t
+
+
+def test_bf16_full_size_teacher_forced(full):
+    rel, gn_rel, agree, cos_i, cos_t = _bf16_run(full, True)
+    print(f"[full1 bf16 teacher-forced] loss rel {rel:.2e}, grad-norm rel {gn_rel:.2e}, free-running code agreement {agree:.4f}, "
+          f"latent cosine image {cos_i:.5f} text {cos_t:.5f}")
+    assert rel < 1e-2 and gn_rel < 5e-2 and cos_i > 0.999 and cos_t > 0.999
+
+
+def test_bf16_full_size_free_running(full):
+    rel, gn_rel, agree, cos_i, cos_t = _bf16_run(full, False)
+    print(f"[full1 bf16 free-running] loss rel {rel:.2e}, grad-norm rel {gn_rel:.2e}, code agreement {agree:.4f}, "
+          f"latent cosine image {cos_i:.5f} text {cos_t:.5f}")
+    assert agree >= 0.95 and rel < 3e-2 and cos_t > 0.999

@@ -394,15 +394,58 @@ def test_vq_kernels(hip, ref, dtype):
     C, d, M = 512, 128, 1000
     embed = torch.nn.functional.normalize(rnd(C, d, seed=1), dim=-1)
     idx = torch.randint(0, C // 2, (M,)).to(DEV)      # upper half of the codebook unused -> bins == 0 branch
-    xn = torch.nn.functional.normalize(rnd(M, d, seed=2), dim=-1).to(dtype)
+    x = rnd(M, d, seed=2).to(dtype)
+    inv = 1.0 / x.float().norm(dim=-1)
     close(hip.vq_gather(embed, idx, dtype), ref.vq_gather(embed, idx, dtype), **tol(dtype, (0, 0), (1e-2, 1e-2)))
-    bins, esum = hip.vq_ema(idx, xn, None, embed, 0.8)
-    br, er = ref.vq_ema(idx, xn, None, embed, 0.8)
-    close(bins, br, rtol=0, atol=0); close(esum, er, rtol=1e-4, atol=1e-4)
+    bins, esum = hip.vq_ema(idx, x, inv, None, embed, 0.8)
+    br, er = ref.vq_ema(idx, x, inv, None, embed, 0.8)
+    close(bins, br, rtol=0, atol=0); close(esum, er, rtol=1e-5, atol=1e-5)
+    b2, e2 = hip.vq_ema(idx, x, inv, None, embed, 0.8)
+    assert torch.equal(esum, e2) and torch.equal(bins, b2)         # row-order summation: bit-identical from run to run
     cl, em = torch.rand(C, device=DEV), embed.clone()
     clr, emr = cl.clone(), em.clone()
     hip.vq_ema_update(cl, em, bins, esum, 0.8); ref.vq_ema_update(clr, emr, br, er, 0.8)
     close(cl, clr, rtol=1e-5, atol=1e-6); close(em, emr, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,d,nseg", [(5000, 512, 8192), (1024, 768, 30522), (3001, 64, 7), (40, 8, 1)])
+def test_segment_sum(hip, ref, dtype, M, d, nseg):
+    x = rnd(M, d, dtype=dtype, seed=5)
+    keys = torch.randint(0, nseg, (M,)).to(DEV)
+    sc = rnd(M, seed=6)
+    out, outr = torch.ones(nseg, d, device=DEV), torch.ones(nseg, d, device=DEV)
+    cnt, cntr = torch.empty(nseg, device=DEV), torch.empty(nseg, device=DEV)
+    hip.segment_sum(keys, x, out, nseg, rowscale=sc, counts=cnt, accumulate=True)
+    ref.segment_sum(keys, x, outr, nseg, rowscale=sc, counts=cntr, accumulate=True)
+    close(cnt, cntr, rtol=0, atol=0); close(out, outr, rtol=1e-4, atol=1e-4)
+    out2 = torch.full((nseg, d), 3.0, device=DEV)
+    hip.segment_sum(None, x, out2, nseg, key_mod=min(nseg, 5))
+    outr2 = torch.empty(nseg, d, device=DEV)
+    ref.segment_sum(None, x, outr2, nseg, key_mod=min(nseg, 5))
+    close(out2, outr2, rtol=1e-4, atol=1e-4)
+    again = torch.empty(nseg, d, device=DEV)
+    hip.segment_sum(None, x, again, nseg, key_mod=min(nseg, 5))
+    assert torch.equal(out2, again)
+
+
+def test_vq_split3_search_is_f32_grade(hip, ref):
+    """The three-term bf16 expansion reproduces the f32 cosine arg-max (vector_quantize_pytorch searches in f32)."""
+    C, d, M = 8192, 512, 20000
+    embed = torch.nn.functional.normalize(rnd(C, d, seed=1), dim=-1)
+    x = rnd(M, d, seed=2).to(torch.bfloat16)
+    xs, inv = hip.l2norm_split3(x, 0)
+    es, _ = hip.l2norm_split3(embed, 1)
+    xr, invr = ref.l2norm_split3(x, 0)
+    assert torch.equal(xs, xr) or (xs.float() - xr.float()).abs().max() < 1e-2
+    close(inv, invr, rtol=1e-5, atol=0)
+    idx, val = hip.gemm_argmax(xs, es)
+    xn = torch.nn.functional.normalize(x.float(), dim=-1)
+    full = xn @ embed.t()
+    refval, refidx = full.max(dim=-1)
+    agree = (idx == refidx).float().mean().item()
+    close(val, refval, rtol=0, atol=2e-5)
+    assert agree >= 0.9995, agree
 
 
 # ---------------------------------------------------------------- CLIP head
