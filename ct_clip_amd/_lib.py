@@ -38,6 +38,13 @@ SIGNATURES = {
     "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
     "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
+    "ctclip_attn2_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "ctclip_attn2_prep": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "ctclip_attn2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _I, _I, _I, _P]),
+    "ctclip_attn2_bwd_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "ctclip_attn2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "ctclip_attn2_unprep_workspace": (_L, []),
+    "ctclip_attn2_unprep": (_I, [_P] * 9 + [_F, _P, _P, _P, _L, _L, _L, _P, _P, _L, _I, _P, _L, _P]),
     "ctclip_dropout": (_I, [_P, _P, _P, _L, _F, _U64, _U32, _I, _P]),
     "ctclip_attn_dropout_mask": (_I, [_P, _I, _I, _I, _F, _U64, _P]),
     "ctclip_geglu_fwd": (_I, [_P, _P, _L, _I, _I, _P]),

@@ -269,6 +269,52 @@ class HipBackend:
                                       _stream())
         _lib.check(rc, "ctclip_attn_bwd")
 
+    # ------------------------------------------------------------------ attention, second generation (csrc/attn2.hip)
+    def attn2_supported(self, dtype, H, L, D, bias_grid, has_bias):
+        gh, gw = bias_grid if bias_grid is not None else (0, 0)
+        return dtype == torch.bfloat16 and bool(self.lib.ctclip_attn2_supported(H, L, D, gh, gw, int(has_bias)))
+
+    def attn2_prep(self, q, k, v, q_scale, k_scale, scale, H):
+        """row-major q, k, v (M, H*32) views -> head-planar q~, k^, v (H, M, 32) + inverse norms (M, H)."""
+        M = q.shape[0]
+        dev = q.device
+        qh, kh, vh = (torch.empty((H, M, 32), dtype=q.dtype, device=dev) for _ in range(3))
+        qinv, kinv = (torch.empty((M, H), dtype=torch.float32, device=dev) for _ in range(2))
+        rc = self.lib.ctclip_attn2_prep(_p(q), _p(k), _p(v), _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _p(q_scale),
+                                        _p(k_scale), float(scale), _p(qh), _p(kh), _p(vh), _p(qinv), _p(kinv), M, H, _stream())
+        _lib.check(rc, "ctclip_attn2_prep")
+        return qh, kh, vh, qinv, kinv
+
+    def attn2_fwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, nseq, L):
+        H, M, _ = qh.shape
+        gh, gw = bias_grid if tab is not None else (0, 0)
+        o = torch.empty((M, H * 32), dtype=qh.dtype, device=qh.device)
+        lse2 = torch.empty((H, M), dtype=torch.float32, device=qh.device)
+        rc = self.lib.ctclip_attn2_fwd(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o), H * 32,
+                                       _p(lse2), nseq, H, L, _stream())
+        _lib.check(rc, "ctclip_attn2_fwd")
+        return o, lse2
+
+    def attn2_bwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab):
+        H, M, _ = qh.shape
+        gh, gw = bias_grid if tab is not None else (0, 0)
+        dqh, dkh, dvh = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
+        dtab = torch.empty_like(tab) if (want_dtab and tab is not None) else None
+        ws = self.workspace(qh.device, self.lib.ctclip_attn2_bwd_workspace(nseq, H, L, gh if dtab is not None else 0, gw))
+        rc = self.lib.ctclip_attn2_bwd(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o),
+                                       _rowmajor(o, "o"), _p(dout), _rowmajor(dout, "dout"), _p(lse2), _p(dqh), _p(dkh), _p(dvh), _p(dtab),
+                                       nseq, H, L, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_attn2_bwd")
+        return dqh, dkh, dvh, dtab
+
+    def attn2_unprep(self, dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale):
+        H, M, _ = qh.shape
+        ws = self.workspace(qh.device, self.lib.ctclip_attn2_unprep_workspace())
+        rc = self.lib.ctclip_attn2_unprep(_p(dqh), _p(dkh), _p(dvh), _p(qh), _p(kh), _p(qinv), _p(kinv), _p(q_scale), _p(k_scale),
+                                          float(scale), _p(dq), _p(dk), _p(dv), _rowmajor(dq, "dq"), _rowmajor(dk, "dk"), _rowmajor(dv, "dv"),
+                                          _p(dq_scale), _p(dk_scale), M, H, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_attn2_unprep")
+
     def dropout(self, x, residual, p, seed, stream_id):
         """y = dropout(x) (+ residual); mask = philox(seed, element, stream_id).  The same call on dy is the backward."""
         assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype))

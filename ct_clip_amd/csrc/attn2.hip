@@ -1,0 +1,921 @@
+// Cosine attention of the CTViT spatial transformer (attention.py:127-181; bf16, d_head 32, L = gh * gw a multiple of 32 with the
+// continuous position bias of attention.py:257-276) -- second generation.  Round 1's kernels (attn.hip) were VALU-bound at ~290 vector
+// instructions per 32 x 32 score tile and wave and needed five side kernels per layer (two qk-norm passes, three head transposes,
+// delta).  What changed, and why:
+//
+//  * HEAD-PLANAR OPERANDS  x[h][token][32]: a (sequence, head) slab is one contiguous 36-KB block, a 32-token tile 2 KB.  One
+//    streaming prep kernel writes q~ = l2norm(q) * q_scale * (scale * log2 e), k^ = l2norm(k) * k_scale and v in that layout
+//    (attention.py:152-154 folded in); nothing is transposed in memory any more: the k-major operands of the second products
+//    (V^T, K^T, Q^T, dO^T) are read from the same row-major LDS tiles with the gfx950 transposing read ds_read_b64_tr_b16.
+//  * EVERYTHING ADDITIVE GOES INTO THE MFMA ACCUMULATOR INPUT.  S = K Q^T is issued with C = (bias table entry of the tile,
+//    gathered from LDS) - M2, so the matrix core delivers log2-domain logits minus a bound: no scale multiply (folded into q~),
+//    no bias add.  dP is issued with C = -delta.
+//  * NO RUNNING MAXIMUM.  Cosine attention has bounded logits: |q~ . k^| <= c max|q_scale| max|k_scale|.  With
+//    M2 = that bound + max(bias) every exp2 argument is <= 0 and the softmax needs no row maximum, no rescale and no second exp:
+//    per score the forward is v_exp_f32 + one add (row sum) + half a v_cvt_pk.  The bound is only used when it cannot underflow
+//    (2 c max|qs| max|ks| + range(bias) <= 100 in log2 units, i.e. |q_scale||k_scale| < ~4); otherwise the same kernels take a
+//    workgroup-uniform branch to the classical online-softmax forms.  Both paths are tested.
+//  * BACKWARD IN TWO PASSES + dBias: P = E w with E = exp2(z - M2) <= 1 and the per-query factor w = exp2(M2 - lse2) folded into
+//    dO' = w dO, delta' = w delta once (by the dQ kernel, which also computes delta), so both passes spend one exp2 and one multiply per
+//    score.  The query pass writes dq^, the key pass dk^ and dv, all head-planar; one streaming kernel applies the l2norm
+//    backward, un-planarises and reduces the q/k scale gradients deterministically (two stages, no atomics).
+//
+// Register tile: one wave = 32 query rows (or key rows) x a 32-wide tile of the other axis, mfma_f32_32x32x16_bf16, lane = column.
+// Operand tiles of a step are fetched once per workgroup (16 B per loader thread, two steps ahead in registers) into a
+// double-buffered LDS ring.  LDS rows are 64 B; the four 16-byte chunks of row r sit at position chunk ^ ((r >> 2) & 3): every
+// 16-lane service group of the b128 fragment reads then touches 16 distinct 16-B slots, and a transposing read (four rows x 64 B
+// per half-wave) covers one whole 256-B bank row (tests/test_layouts_cpu.py restates and checks this arithmetic).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr int D = 32;                       // head dim
+constexpr int TILE = 32 * 64;               // bytes of one 32-row operand tile
+constexpr int MAXCLS = 4096, MAXL = 1024;
+constexpr float SAFE_SPAN = 100.f;          // log2 units: exp2(-100) ~ 8e-31 is a normal f32 / bf16 number
+
+__device__ __forceinline__ int pi32(int c) { return (c & 3) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 16); }
+__device__ __forceinline__ int slot_index(int r, int half) { return 16 * (r >> 3) + 8 * half + (r & 7); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+struct Frag { bf16x8 v[2]; };               // 32 contraction slots of one lane: slots 8 half + e (v[0]) and 16 + 8 half + e (v[1])
+
+__device__ __forceinline__ f32x16 mma(f32x16 acc, const Frag& a, const Frag& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
+}
+__device__ __forceinline__ Frag pack(const float (&p)[16]) {
+  Frag f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack2bf(p[8 * g + 2 * e], p[8 * g + 2 * e + 1]);
+    f.v[g] = __builtin_bit_cast(bf16x8, w);
+  }
+  return f;
+}
+// row-major fragment of LDS tile row `row` (64 B, swizzled): contraction slots = the lane's 16 head dims 8 half + e, 16 + 8 half + e
+__device__ __forceinline__ Frag lds_rows(const char* tile, int row, int half) {
+  Frag f;
+  f.v[0] = *reinterpret_cast<const bf16x8*>(tile + swz(row, half));
+  f.v[1] = *reinterpret_cast<const bf16x8*>(tile + swz(row, 2 + half));
+  return f;
+}
+// the same from global memory: the lane's own token row of a head-planar operand (64 B)
+__device__ __forceinline__ Frag global_row(const bf16_t* row, int half) {
+  Frag f;
+  f.v[0] = *reinterpret_cast<const bf16x8*>(row + 8 * half);
+  f.v[1] = *reinterpret_cast<const bf16x8*>(row + 16 + 8 * half);
+  return f;
+}
+// Transposed fragment of a row-major LDS tile [token][32 dims] with ds_read_b64_tr_b16: output row (MFMA A row) i = lane & 31 is
+// head dim pi32(i), contraction slots are the tile's tokens 8 half + e (v[0]) and 16 + 8 half + e (v[1]).  Measured semantics
+// (tools/tr_probe.hip): in each 16-lane group, output lane t element j = element t & 3 of the 8 bytes addressed by lane
+// 4 j + (t >> 2).  Lane t' therefore points at token k0 + (t' >> 2), dims cbase + 4 sigma(t' & 3) .. + 3 (sigma swaps 1 and 2, which
+// realises pi32 inside the group), cbase = 16 * ((lane >> 4) & 1).  troff[j0] = the lane's byte offset for k0 = 8 half + 4 j0; the second
+// half of the tile (tokens 16..31) is 1024 B further on and has the same swizzle phase.
+struct TrOff { uint32_t o[2]; };
+__device__ __forceinline__ TrOff tr_offsets(int lane) {
+  const int t = lane & 15, grp = (lane >> 4) & 1, half = lane >> 5;
+  const int sg = ((t & 1) << 1) | ((t >> 1) & 1);          // sigma(t & 3)
+  TrOff r;
+#pragma unroll
+  for (int j0 = 0; j0 < 2; ++j0) {
+    const int row = 8 * half + 4 * j0 + (t >> 2);
+    r.o[j0] = (uint32_t)(swz(row, 2 * grp + (sg >> 1)) + 8 * (sg & 1));
+  }
+  return r;
+}
+__device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ Frag lds_cols(const char* tile, const TrOff& tr) {
+  const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
+  const u32x2 a0 = tr_read(base + tr.o[0]), a1 = tr_read(base + tr.o[1]);
+  const u32x2 b0 = tr_read(base + 1024 + tr.o[0]), b1 = tr_read(base + 1024 + tr.o[1]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  Frag f;
+  f.v[0] = __builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+  f.v[1] = __builtin_bit_cast(bf16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+  return f;
+}
+
+struct Params {
+  const bf16_t *qh, *kh, *vh;              // head-planar [H][M][32]: q~, k^, v
+  const float* tab;                        // (ncls, H) position-bias table (natural units), or null
+  const float *q_scale, *k_scale;          // (32) learned scales (for the logit bound)
+  int gh, gw, H, L, nseq;
+  int64_t M;                               // nseq * L
+  float c;                                 // scale * log2 e (already folded into q~)
+  // forward
+  bf16_t* out; int64_t ldo;                // (M, >= H*32) row-major
+  float* lse2;                             // [H][M] log2-domain log-sum-exp
+  // backward
+  const bf16_t* o; const bf16_t* dout; int64_t lddo;
+  bf16_t* dop;                             // [H][M][32]: dO' = w dO (written by the query pass, read by the key pass and dBias)
+  float* deltap;                           // [H][M]: delta' = w delta
+  bf16_t *dqh, *dkh, *dvh;                 // head-planar gradients
+  float* dbias_part; int nsplit;           // dBias slabs [nsplit][H][L][L]
+};
+
+// ---- per-workgroup preamble: stage the bias table of head h (log2 domain) and the token -> offset-class index, and derive the
+// logit bound.  All threads of the workgroup must call it.  Returns M2 (log2-domain bound folded into the staged table when safe).
+struct Rel {
+  float tab[MAXCLS];
+  __attribute__((aligned(16))) uint16_t u[MAXL];
+  float red[2][16];
+  float m2; int safe;
+};
+// REVERSED: entry i holds class ncls - 1 - i, so that the descending classes of a key run are ASCENDING addresses and land in
+// consecutive registers without moves (the kernels whose tile rows are keys); the key pass keeps the natural order.
+template <bool REVERSED>
+__device__ __forceinline__ void stage_rel(Rel& rel, const Params& p, int h) {
+  const int ncls = p.tab ? (2 * p.gh - 1) * (2 * p.gw - 1) : 0;
+  const int nth = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int i = tid; i < ncls; i += nth) {
+    const float t = p.tab[(int64_t)(REVERSED ? ncls - 1 - i : i) * p.H + h] * LOG2E;
+    rel.tab[i] = t;
+    mx = fmaxf(mx, t); mn = fminf(mn, t);
+  }
+  if (ncls == 0) { mx = 0.f; mn = 0.f; if (tid == 0) rel.tab[0] = 0.f; }
+  for (int i = tid; i < p.L; i += nth) rel.u[i] = p.tab ? (uint16_t)((i / p.gw) * (2 * p.gw - 1) + i % p.gw) : (uint16_t)0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+  if (lane == 0) { rel.red[0][wave] = mx; rel.red[1][wave] = mn; }
+  __syncthreads();
+  if (wave == 0) {
+    float a = lane < 32 ? fabsf(p.q_scale[lane]) : fabsf(p.k_scale[lane - 32]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));     // lanes 0-31: max|q_scale|, 32-63: max|k_scale|
+    const float qk = a * __shfl_xor(a, 32, 64) * p.c;
+    float tmx = -INFINITY, tmn = INFINITY;
+    for (int w = 0; w < nw; ++w) { tmx = fmaxf(tmx, rel.red[0][w]); tmn = fminf(tmn, rel.red[1][w]); }
+    if (lane == 0) {
+      const float span = 2.f * qk + (tmx - tmn);
+      rel.safe = (span <= SAFE_SPAN && span == span) ? 1 : 0;
+      rel.m2 = qk + tmx;
+    }
+  }
+  __syncthreads();
+  if (rel.safe) {
+    const float m2 = rel.m2;
+    for (int i = tid; i < (ncls ? ncls : 1); i += nth) rel.tab[i] -= m2;
+    __syncthreads();
+  }
+}
+
+// offset-class gather of one 32 x 32 tile as the MFMA accumulator input.  Rows (registers) are KEYS, lane = query: class of key
+// run (8 consecutive tokens of one image row; needs gw % 8 == 0) descends by one per key.  Rows are QUERIES, lane = key: ascends.
+template <bool ROWS_ARE_KEYS, bool TAB>
+__device__ __forceinline__ f32x16 bias_tile(const Rel& rel, const Params& p, int ucol, int row_base, int half) {
+  f32x16 cb;
+  if (!TAB) {
+    const float t = rel.tab[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cb[r] = t;
+    return cb;
+  }
+  const int c0 = (p.gh - 1) * (2 * p.gw - 1) + (p.gw - 1);
+  const int ncls = (2 * p.gh - 1) * (2 * p.gw - 1);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int urow0 = rel.u[row_base + 16 * g + 8 * half];
+    // keys: class(e) = ucol - urow0 + c0 - e, stored reversed at ncls - 1 - class; queries: class(e) = urow0 - ucol + c0 + e
+    const float* b = rel.tab + (ROWS_ARE_KEYS ? ncls - 1 - (ucol - urow0 + c0) : urow0 - ucol + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cb[8 * g + e] = b[e];
+  }
+  return cb;
+}
+
+// work item of a workgroup: XCD-aware decode.  Hardware places workgroup b on XCD b % 8; the `per` consecutive items handled by one
+// XCD are the row-block groups of the same (sequence, head), which then share their operand slab through that XCD's L2.
+__device__ __forceinline__ bool decode_item(int ngroups, int nitems, int& grp, int& sh) {
+  const int per = (nitems + 7) >> 3;
+  const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (w >= nitems) return false;
+  sh = w / ngroups; grp = w % ngroups;
+  return true;
+}
+
+// loader: thread `lt` of the 256 loader threads moves 16 B of a pair of tiles per step: tile (lt >> 7), row (lt & 127) >> 2,
+// source chunk lt & 3  ->  LDS position swz(row, chunk).
+struct Loader {
+  const char* src;          // global address of this thread's chunk of tile 0 (advance by TILE bytes per tile)
+  int dst;                  // byte offset inside a ring slot
+};
+
+// ================================================================================================================== forward
+// every global load issued so far has landed (s_waitcnt vmcnt(0), lgkmcnt / expcnt untouched).  Placed in front of the tile loops: the
+// loop-invariant operand fragments come from global loads, and without a visible wait the compiler re-waits for them -- vmcnt(0),
+// i.e. for the tile prefetches too -- in front of the first MFMA of EVERY step.
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+template <int NW, bool SAFE, bool TAB>
+__device__ __forceinline__ void fwd_body(const Params& p, Rel& rel, char (*ring)[2][TILE], int seq, int h, int grp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nkb = L / 32;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int nqb = L / 32;
+  const int qb_raw = grp * NW + wave;
+  const bool active = qb_raw < nqb;
+  const int qb = active ? qb_raw : nqb - 1;
+  const int qi = qb * 32 + c;
+  const int64_t slab = ((int64_t)h * p.M + (int64_t)seq * L) * D;
+  const Frag qf = global_row(p.qh + slab + (int64_t)qi * D, half);
+  const int ucol = rel.u[qi];
+  const TrOff tr = tr_offsets(lane);
+
+  const bool is_loader = threadIdx.x < 256;
+  const int lt = threadIdx.x & 255, ltile = lt >> 7, lrow = (lt & 127) >> 2, lchunk = lt & 3;
+  const char* lsrc = reinterpret_cast<const char*>((ltile == 0 ? p.kh : p.vh) + slab) + lrow * 64 + lchunk * 16;
+  const int ldst = ltile * TILE + swz(lrow, lchunk);
+  auto gload = [&](int kb) { return *reinterpret_cast<const u32x4*>(lsrc + (int64_t)(kb < nkb ? kb : nkb - 1) * TILE); };
+  u32x4 st0{}, st1{};
+  if (is_loader) {
+    const u32x4 first = gload(0);
+    st0 = gload(1); st1 = gload(2);
+    *reinterpret_cast<u32x4*>(&ring[0][0][0] + ldst) = first;
+  }
+  __syncthreads();
+  drain_vmem();
+
+  float lsum = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f, m = -INFINITY;
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+
+  auto step = [&](int kb, u32x4& st) {
+    const int buf = kb & 1;
+    if (is_loader) {
+      *reinterpret_cast<u32x4*>(&ring[buf ^ 1][0][0] + ldst) = st;     // tile kb + 1 (loaded two steps ago) -> the slot freed by step kb - 1
+      st = gload(kb + 3);
+    }
+    const f32x16 cb = bias_tile<true, TAB>(rel, p, ucol, kb * 32, half);
+    const Frag kf = lds_rows(ring[buf][0], ar, half);
+    f32x16 s = mma(cb, kf, qf);
+    float pr[16];
+    if (SAFE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) { lsum += pr[r]; ls1 += pr[r + 1]; ls2 += pr[r + 2]; ls3 += pr[r + 3]; }   // four short chains
+    } else {
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(s[r] - mnew); ps += pr[r]; }
+      lsum = lsum * alpha + ps;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      m = mnew;
+    }
+    const Frag pf = pack(pr);
+    const Frag vf = lds_cols(ring[buf][1], tr);
+    oacc = mma(oacc, vf, pf);
+    __syncthreads();
+  };
+  int kb = 0;
+  for (; kb + 1 < nkb; kb += 2) { step(kb, st0); step(kb + 1, st1); }
+  if (kb < nkb) step(kb, st0);
+
+  lsum = (lsum + ls1) + (ls2 + ls3);
+  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  if (active) {
+    const float inv = 1.f / l;
+    bf16_t* O = p.out + ((int64_t)seq * L + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = oacc[8 * g + e] * inv;
+      store8(O + 16 * g + 8 * half, o8);
+    }
+    if (half == 0 && p.lse2) p.lse2[(int64_t)h * p.M + (int64_t)seq * L + qi] = (SAFE ? rel.m2 : m) + __log2f(l);
+  }
+}
+
+template <int NW, bool TAB>
+__global__ __launch_bounds__(NW * 64) void attn2_fwd_kernel(Params p) {
+  __shared__ Rel rel;
+  __shared__ __attribute__((aligned(16))) char ring[2][2][TILE];         // [slot][K^ | V]
+  const int ngroups = (p.L / 32 + NW - 1) / NW;
+  int grp, sh;
+  const bool ok = decode_item(ngroups, ngroups * p.nseq * p.H, grp, sh);
+  const int seq = ok ? sh / p.H : 0, h = ok ? sh % p.H : 0;
+  stage_rel<true>(rel, p, h);
+  if (!ok) return;                                                       // workgroup-uniform
+  if (rel.safe) fwd_body<NW, true, TAB>(p, rel, ring, seq, h, grp);
+  else fwd_body<NW, false, TAB>(p, rel, ring, seq, h, grp);
+}
+
+// ================================================================================================================== dQ pass
+// lane = query.  Also computes delta = rowsum(dO * O), w = exp2(M2 - lse2) (1 when the bound is not in use), and publishes
+// dO' = w dO (head-planar) and delta' = w delta for the key pass and the dBias kernel.
+template <int NW, bool SAFE, bool TAB>
+__device__ __forceinline__ void dq_body(const Params& p, Rel& rel, char (*ring)[2][TILE], int seq, int h, int grp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nkb = L / 32;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qb_raw = grp * NW + wave;
+  const bool active = qb_raw < nkb;
+  const int qb = active ? qb_raw : nkb - 1;
+  const int qi = qb * 32 + c;
+  const int64_t tok = (int64_t)seq * L + qi;
+  const int64_t slab = ((int64_t)h * p.M + (int64_t)seq * L) * D;
+  const Frag qf = global_row(p.qh + slab + (int64_t)qi * D, half);
+  const int ucol = rel.u[qi];
+  const TrOff tr = tr_offsets(lane);
+
+  // delta, w, dO'
+  float dov[16], ov[16];
+  {
+    float a[8], b[8];
+    load8(p.dout + tok * p.lddo + h * D + 8 * half, a); load8(p.dout + tok * p.lddo + h * D + 16 + 8 * half, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dov[e] = a[e]; dov[8 + e] = b[e]; }
+    load8(p.o + tok * p.ldo + h * D + 8 * half, a); load8(p.o + tok * p.ldo + h * D + 16 + 8 * half, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ov[e] = a[e]; ov[8 + e] = b[e]; }
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) delta += dov[e] * ov[e];
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse2 = p.lse2[(int64_t)h * p.M + tok];
+  const float w = SAFE ? __builtin_amdgcn_exp2f(rel.m2 - lse2) : 1.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dov[e] *= w;
+  const Frag dof = pack(dov);
+  const float deltap = delta * w;
+  if (active) {
+    bf16_t* dst = p.dop + slab + (int64_t)qi * D;
+    *reinterpret_cast<bf16x8*>(dst + 8 * half) = dof.v[0];
+    *reinterpret_cast<bf16x8*>(dst + 16 + 8 * half) = dof.v[1];
+    if (half == 0) p.deltap[(int64_t)h * p.M + tok] = deltap;
+  }
+  f32x16 cdel;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cdel[r] = -deltap;
+
+  const bool is_loader = threadIdx.x < 256;
+  const int lt = threadIdx.x & 255, ltile = lt >> 7, lrow = (lt & 127) >> 2, lchunk = lt & 3;
+  const char* lsrc = reinterpret_cast<const char*>((ltile == 0 ? p.kh : p.vh) + slab) + lrow * 64 + lchunk * 16;
+  const int ldst = ltile * TILE + swz(lrow, lchunk);
+  auto gload = [&](int kb) { return *reinterpret_cast<const u32x4*>(lsrc + (int64_t)(kb < nkb ? kb : nkb - 1) * TILE); };
+  u32x4 st0{}, st1{};
+  if (is_loader) {
+    const u32x4 first = gload(0);
+    st0 = gload(1); st1 = gload(2);
+    *reinterpret_cast<u32x4*>(&ring[0][0][0] + ldst) = first;
+  }
+  __syncthreads();
+  drain_vmem();
+
+  f32x16 dqacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
+  auto step = [&](int kb, u32x4& st) {
+    const int buf = kb & 1;
+    if (is_loader) {
+      *reinterpret_cast<u32x4*>(&ring[buf ^ 1][0][0] + ldst) = st;
+      st = gload(kb + 3);
+    }
+    const f32x16 cb = bias_tile<true, TAB>(rel, p, ucol, kb * 32, half);
+    const Frag kf = lds_rows(ring[buf][0], ar, half);
+    const Frag vf = lds_rows(ring[buf][1], ar, half);
+    const f32x16 s = mma(cb, kf, qf);
+    const f32x16 dp = mma(cdel, vf, dof);                               // dP' - delta'
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(SAFE ? s[r] : s[r] - lse2) * dp[r];
+    const Frag dsf = pack(ds);
+    const Frag ktf = lds_cols(ring[buf][0], tr);
+    dqacc = mma(dqacc, ktf, dsf);
+    __syncthreads();
+  };
+  int kb = 0;
+  for (; kb + 1 < nkb; kb += 2) { step(kb, st0); step(kb + 1, st1); }
+  if (kb < nkb) step(kb, st0);
+
+  if (active) {                       // dq^ = scale * dS k^ ; c = scale * log2 e
+    const float sc = p.c * LN2;
+    bf16_t* dst = p.dqh + slab + (int64_t)qi * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = dqacc[8 * g + e] * sc;
+      store8(dst + 16 * g + 8 * half, o8);
+    }
+  }
+}
+
+template <int NW, bool TAB>
+__global__ __launch_bounds__(NW * 64) void attn2_bwd_dq_kernel(Params p) {
+  __shared__ Rel rel;
+  __shared__ __attribute__((aligned(16))) char ring[2][2][TILE];         // [slot][K^ | V]
+  const int ngroups = (p.L / 32 + NW - 1) / NW;
+  int grp, sh;
+  const bool ok = decode_item(ngroups, ngroups * p.nseq * p.H, grp, sh);
+  const int seq = ok ? sh / p.H : 0, h = ok ? sh % p.H : 0;
+  stage_rel<true>(rel, p, h);
+  if (!ok) return;
+  if (rel.safe) dq_body<NW, true, TAB>(p, rel, ring, seq, h, grp);
+  else dq_body<NW, false, TAB>(p, rel, ring, seq, h, grp);
+}
+
+// ================================================================================================================== dK, dV pass
+// lane = key.  Tiles of Q~ and dO' (32 queries each) + their statistics stream through LDS.
+template <int NW, bool SAFE, bool TAB>
+__device__ __forceinline__ void dkv_body(const Params& p, Rel& rel, char (*ring)[2][TILE], float (*stats)[2][32], int seq, int h, int grp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nqb = L / 32;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int jb_raw = grp * NW + wave;
+  const bool active = jb_raw < nqb;
+  const int jb = active ? jb_raw : nqb - 1;
+  const int kj = jb * 32 + c;
+  const int64_t slab = ((int64_t)h * p.M + (int64_t)seq * L) * D;
+  const int64_t sbase = (int64_t)h * p.M + (int64_t)seq * L;
+  const Frag kf = global_row(p.kh + slab + (int64_t)kj * D, half);
+  const Frag vf = global_row(p.vh + slab + (int64_t)kj * D, half);
+  const int ucol = rel.u[kj];
+  const TrOff tr = tr_offsets(lane);
+
+  const bool is_loader = threadIdx.x < 256;
+  const int lt = threadIdx.x & 255, ltile = lt >> 7, lrow = (lt & 127) >> 2, lchunk = lt & 3;
+  const char* lsrc = reinterpret_cast<const char*>((ltile == 0 ? p.qh : p.dop) + slab) + lrow * 64 + lchunk * 16;
+  const int ldst = ltile * TILE + swz(lrow, lchunk);
+  auto gload = [&](int qb) { return *reinterpret_cast<const u32x4*>(lsrc + (int64_t)(qb < nqb ? qb : nqb - 1) * TILE); };
+  // statistics loader: the 64 threads after the tile loaders: [-delta' | -lse2] of the tile's 32 queries
+  const bool is_stat = threadIdx.x >= 256 && threadIdx.x < 320;
+  const int sidx = threadIdx.x & 31, swhich = (threadIdx.x >> 5) & 1;
+  auto sload = [&](int qb) { return -((swhich ? p.lse2 : p.deltap)[sbase + (qb < nqb ? qb : nqb - 1) * 32 + sidx]); };
+  u32x4 st0{}, st1{};
+  float sv0 = 0.f, sv1 = 0.f;
+  if (is_loader) {
+    const u32x4 first = gload(0);
+    st0 = gload(1); st1 = gload(2);
+    *reinterpret_cast<u32x4*>(&ring[0][0][0] + ldst) = first;
+  }
+  if (is_stat) {
+    const float first = sload(0);
+    sv0 = sload(1); sv1 = sload(2);
+    stats[0][swhich][sidx] = first;
+  }
+  __syncthreads();
+  drain_vmem();
+
+  f32x16 dkacc, dvacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
+  auto step = [&](int qb, u32x4& st, float& sv) {
+    const int buf = qb & 1;
+    if (is_loader) {
+      *reinterpret_cast<u32x4*>(&ring[buf ^ 1][0][0] + ldst) = st;
+      st = gload(qb + 3);
+    }
+    if (is_stat) {
+      stats[buf ^ 1][swhich][sidx] = sv;
+      sv = sload(qb + 3);
+    }
+    const f32x16 cb = bias_tile<false, TAB>(rel, p, ucol, qb * 32, half);
+    const Frag qf = lds_rows(ring[buf][0], ar, half);
+    const Frag dof = lds_rows(ring[buf][1], ar, half);
+    // -delta' of the tile's queries in register order (queries 8 half + e and 16 + 8 half + e): the dP accumulator input
+    f32x16 cdel;
+    {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&stats[buf][0][8 * half]), a1 = *reinterpret_cast<const f32x4*>(&stats[buf][0][8 * half + 4]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&stats[buf][0][16 + 8 * half]), b1 = *reinterpret_cast<const f32x4*>(&stats[buf][0][16 + 8 * half + 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
+    }
+    f32x16 s = mma(cb, qf, kf);              // S[query rho][key c] (log2 domain, - M2 when SAFE)
+    const f32x16 dp = mma(cdel, dof, vf);    // dP' - delta'
+    if (!SAFE) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&stats[buf][1][8 * half]), a1 = *reinterpret_cast<const f32x4*>(&stats[buf][1][8 * half + 4]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&stats[buf][1][16 + 8 * half]), b1 = *reinterpret_cast<const f32x4*>(&stats[buf][1][16 + 8 * half + 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += a0[e]; s[4 + e] += a1[e]; s[8 + e] += b0[e]; s[12 + e] += b1[e]; }
+    }
+    float pr[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(s[r]); ds[r] = pr[r] * dp[r]; }
+    const Frag pf = pack(pr), dsf = pack(ds);
+    const Frag dotf = lds_cols(ring[buf][1], tr);
+    const Frag qtf = lds_cols(ring[buf][0], tr);
+    dvacc = mma(dvacc, dotf, pf);
+    dkacc = mma(dkacc, qtf, dsf);
+    __syncthreads();
+  };
+  int qb = 0;
+  for (; qb + 1 < nqb; qb += 2) { step(qb, st0, sv0); step(qb + 1, st1, sv1); }
+  if (qb < nqb) step(qb, st0, sv0);
+
+  if (active) {                       // dk^ = scale * dS^T q^ = ln 2 * dS^T q~
+    bf16_t* dK = p.dkh + slab + (int64_t)kj * D;
+    bf16_t* dV = p.dvh + slab + (int64_t)kj * D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float a8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a8[e] = dkacc[8 * g + e] * LN2; b8[e] = dvacc[8 * g + e]; }
+      store8(dK + 16 * g + 8 * half, a8);
+      store8(dV + 16 * g + 8 * half, b8);
+    }
+  }
+}
+
+template <int NW, bool TAB>
+__global__ __launch_bounds__(NW * 64) void attn2_bwd_dkv_kernel(Params p) {
+  __shared__ Rel rel;
+  __shared__ __attribute__((aligned(16))) char ring[2][2][TILE];         // [slot][Q~ | dO']
+  __shared__ __attribute__((aligned(16))) float stats[2][2][32];         // [slot][-delta' | -lse2][query of the tile]
+  const int ngroups = (p.L / 32 + NW - 1) / NW;
+  int grp, sh;
+  const bool ok = decode_item(ngroups, ngroups * p.nseq * p.H, grp, sh);
+  const int seq = ok ? sh / p.H : 0, h = ok ? sh % p.H : 0;
+  stage_rel<false>(rel, p, h);
+  if (!ok) return;
+  if (rel.safe) dkv_body<NW, true, TAB>(p, rel, ring, stats, seq, h, grp);
+  else dkv_body<NW, false, TAB>(p, rel, ring, stats, seq, h, grp);
+}
+
+// ================================================================================================================== dBias
+// dBias[h][i][j] = sum over sequences of dS.  A workgroup of eight waves owns 2 query blocks x 4 key blocks of one head (one tile
+// pair per wave, its bias tile and 16 accumulators in registers) and walks a strided subset of the sequences; per sequence the
+// twelve operand tiles (Q~, dO' of the two query blocks, K^, V of the four key blocks) go through LDS once.  Slabs per split are
+// summed and folded into the (ncls, H) table gradient by dbias_fold2_kernel (deterministic).
+template <bool SAFE>
+__device__ __forceinline__ void dbias_body(const Params& p, Rel& rel, char (*tiles)[12][TILE], float (*stats)[2][2][32], int h, int qg, int kg, int split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nkb = L / 32;
+  const int qsel = wave >> 2, ksel = wave & 3;
+  const int qb_raw = qg * 2 + qsel, kb_raw = kg * 4 + ksel;
+  const bool active = qb_raw < nkb && kb_raw < nkb;
+  const int qb = qb_raw < nkb ? qb_raw : nkb - 1, kb = kb_raw < nkb ? kb_raw : nkb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  const f32x16 cb = bias_tile<true, true>(rel, p, rel.u[qi], kb * 32, half);    // loop invariant
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // staging: thread t: pass i (0..2) fills tiles 4i .. 4i+3 (128 threads each): pass 0 = Q0 Q1 dO'0 dO'1, pass 1 = K0..K3, pass 2 = V0..V3
+  const int stile = threadIdx.x >> 7, srow = (threadIdx.x & 127) >> 2, schunk = threadIdx.x & 3;
+  const int64_t hbase = (int64_t)h * p.M * D;
+  const bf16_t* sbase[3] = {stile < 2 ? p.qh : p.dop, p.kh, p.vh};
+  int stok[3] = {(qg * 2 + (stile & 1)) * 32, (kg * 4 + stile) * 32, (kg * 4 + stile) * 32};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) stok[i] = stok[i] < L ? stok[i] : L - 32;
+  auto gsrc = [&](int i, int seq) {
+    return reinterpret_cast<const u32x4*>(sbase[i] + hbase + ((int64_t)seq * L + stok[i] + srow) * D + schunk * 8);
+  };
+  auto gstat = [&](int seq) {    // threads 0-127: [query block][lse2 | delta'][32 queries]
+    int q = (qg * 2 + ((threadIdx.x >> 6) & 1)) * 32;
+    q = (q < L ? q : L - 32) + (threadIdx.x & 31);
+    return ((threadIdx.x & 32) ? p.deltap : p.lse2) + (int64_t)h * p.M + (int64_t)seq * L + q;
+  };
+  const int sdst = stile * TILE + swz(srow, schunk);
+  float* sstat = &stats[0][0][0][0] + (threadIdx.x & 127);
+
+  int seq = split;
+  u32x4 st[3];
+  float sv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st[i] = *gsrc(i, seq);
+  if (threadIdx.x < 128) sv = *gstat(seq);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(&tiles[0][4 * i][0] + sdst) = st[i];
+  if (threadIdx.x < 128) *sstat = sv;
+  __syncthreads();
+  drain_vmem();
+  for (int it = 0; seq < p.nseq; seq += p.nsplit, ++it) {
+    const int buf = it & 1;
+    const int sn = seq + p.nsplit < p.nseq ? seq + p.nsplit : seq;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st[i] = *gsrc(i, sn);
+    if (threadIdx.x < 128) sv = *gstat(sn);
+    const Frag qf = lds_rows(tiles[buf][qsel], c, half);            // B operands: the lane's own query row
+    const Frag dof = lds_rows(tiles[buf][2 + qsel], c, half);
+    const Frag kf = lds_rows(tiles[buf][4 + ksel], ar, half);
+    const Frag vf = lds_rows(tiles[buf][8 + ksel], ar, half);
+    const float lse2 = stats[buf][qsel][0][c], deltap = stats[buf][qsel][1][c];
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    const f32x16 s = mma(cb, kf, qf);
+    const f32x16 dp = mma(zero, vf, dof);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(__builtin_amdgcn_exp2f(SAFE ? s[r] : s[r] - lse2), dp[r] - deltap, acc[r]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(&tiles[buf ^ 1][4 * i][0] + sdst) = st[i];
+    if (threadIdx.x < 128) sstat[(buf ^ 1) * 128] = sv;
+    __syncthreads();
+  }
+  if (active) {
+    float* dst = p.dbias_part + (((int64_t)split * p.H + h) * L + qi) * L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[kb * 32 + slot_index(r, half)] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(512) void attn2_bwd_dbias_kernel(Params p) {
+  __shared__ Rel rel;
+  __shared__ __attribute__((aligned(16))) char tiles[2][12][TILE];     // [buffer][Q~ x2, dO' x2, K^ x4, V x4]
+  __shared__ float stats[2][2][2][32];                                   // [buffer][query block][lse2, delta'][query]
+  const int nkb = p.L / 32, ngrp = (nkb + 3) / 4;
+  const int qg = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
+  stage_rel<true>(rel, p, h);
+  if (split >= p.nseq) return;
+  if (rel.safe) dbias_body<true>(p, rel, tiles, stats, h, qg, kg, split);
+  else dbias_body<false>(p, rel, tiles, stats, h, qg, kg, split);
+}
+
+// slabs -> table gradient (ncls, H): class bins in LDS, one workgroup per (16 query rows, head); rows and splits are summed in a
+// fixed order and the per-workgroup bins are written to a second slab that the last stage adds up in index order (no atomics on
+// floating-point data reach global memory).
+__global__ __launch_bounds__(256) void dbias_bin_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ bins_out, int H, int gh, int gw) {
+  __shared__ float bins[MAXCLS];
+  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), h = blockIdx.y;
+  for (int i = threadIdx.x; i < ncls; i += 256) bins[i] = 0.f;
+  __syncthreads();
+  const int64_t n = (int64_t)H * L * L;
+  const int q0 = blockIdx.x * 16;
+  // a class (dy, dx) receives, from one query row, at most one key: different rows are handled one after the other, so that every
+  // bin sees a fixed summation order and no two threads of a step touch the same bin
+  for (int qr = 0; qr < 16; ++qr) {
+    const int qi = q0 + qr;
+    if (qi >= L) break;
+    for (int kj = threadIdx.x; kj < L; kj += 256) {
+      const int64_t off = ((int64_t)h * L + qi) * L + kj;
+      float t = 0.f;
+      for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + off];
+      bins[(qi / gw - kj / gw + gh - 1) * (2 * gw - 1) + (qi % gw - kj % gw + gw - 1)] += t;
+    }
+    __syncthreads();
+  }
+  float* dst = bins_out + ((int64_t)blockIdx.x * H + h) * ncls;
+  for (int i = threadIdx.x; i < ncls; i += 256) dst[i] = bins[i];
+}
+__global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict__ bins, int nblk, float* __restrict__ dtab, int H, int ncls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncls * H) return;
+  const int cls = i / H, h = i % H;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += bins[((int64_t)b * H + h) * ncls + cls];
+  dtab[i] = t;
+}
+
+// ================================================================================================================== prep / unprep
+// q (M, ldq >= H*32), k and v (M, ldk) row-major  ->  q~, k^, v head-planar + inverse norms (M, H).  Four threads per (token, head).
+__global__ __launch_bounds__(256) void attn_prep_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                        int64_t ldq, int64_t ldk, int64_t ldv, const float* __restrict__ q_scale,
+                                                        const float* __restrict__ k_scale, float c, bf16_t* __restrict__ qh, bf16_t* __restrict__ kh,
+                                                        bf16_t* __restrict__ vh, float* __restrict__ qinv, float* __restrict__ kinv, int64_t M, int H) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = M * H * 4;
+  const bool ok = tid < total;
+  const int64_t t = ok ? tid : total - 1;
+  const int j = (int)(t & 3);
+  const int64_t mh = t >> 2;
+  const int h = (int)(mh % H);
+  const int64_t m = mh / H;
+  float a[8], b[8];
+  load8(q + m * ldq + h * D + 8 * j, a);
+  load8(k + m * ldk + h * D + 8 * j, b);
+  const u32x4 vv = *reinterpret_cast<const u32x4*>(v + m * ldv + h * D + 8 * j);
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sa += a[e] * a[e]; sb += b[e] * b[e]; }
+  sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+  sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
+  const float ia = 1.f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.f / fmaxf(sqrtf(sb), 1e-12f);
+  if (!ok) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] *= ia * q_scale[8 * j + e] * c; b[e] *= ib * k_scale[8 * j + e]; }
+  const int64_t dst = ((int64_t)h * M + m) * D + 8 * j;
+  store8(qh + dst, a);
+  store8(kh + dst, b);
+  *reinterpret_cast<u32x4*>(vh + dst) = vv;
+  if (j == 0) { qinv[m * H + h] = ia; kinv[m * H + h] = ib; }
+}
+
+// head-planar dq^, dk^, dv + saved q~, k^, inverse norms  ->  row-major dq (M, lddq), dk | dv (M, lddk) through the l2norm backward
+//   u = x inv = x^ / scale_vec ; g = dx^ * scale_vec ; dx = inv (g - u (u . g)) ; dscale[d] = sum dx^ u
+// and per-workgroup partial sums of the two scale gradients (part: [blocks][2][32]; summed by scale_grad_sum_kernel).
+__global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restrict__ dqh, const bf16_t* __restrict__ dkh, const bf16_t* __restrict__ dvh,
+                                                          const bf16_t* __restrict__ qh, const bf16_t* __restrict__ kh, const float* __restrict__ qinv,
+                                                          const float* __restrict__ kinv, const float* __restrict__ q_scale, const float* __restrict__ k_scale,
+                                                          float c, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t lddq,
+                                                          int64_t lddk, int64_t lddv, float* __restrict__ part, int64_t M, int H) {
+  __shared__ float red[2][8][32];
+  const int j = threadIdx.x & 3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float rqs[8], rks[8], accq[8], acck[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float qs = q_scale[8 * j + e] * c, ks = k_scale[8 * j + e];
+    rqs[e] = fabsf(qs) > 1e-30f ? 1.f / qs : 0.f;      // u = x~ / (scale c); a scale of exactly zero has no recoverable direction
+    rks[e] = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+    accq[e] = 0.f; acck[e] = 0.f;
+  }
+  const int64_t total = M * H * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t - threadIdx.x + 0 < total; t += (int64_t)gridDim.x * 256) {
+    const bool ok = t < total;
+    const int64_t tt = ok ? t : total - 1;
+    const int64_t mh = tt >> 2;
+    const int h = (int)(mh % H);
+    const int64_t m = mh / H;
+    const int64_t src = ((int64_t)h * M + m) * D + 8 * j;
+    float gq[8], xq[8], gk[8], xk[8];
+    load8(dqh + src, gq); load8(qh + src, xq);
+    load8(dkh + src, gk); load8(kh + src, xk);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(dvh + src);
+    const float iq = qinv[m * H + h], ik = kinv[m * H + h];
+    float dotq = 0.f, dotk = 0.f, uq[8], uk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uq[e] = xq[e] * rqs[e]; uk[e] = xk[e] * rks[e];
+      if (ok) { accq[e] += gq[e] * uq[e]; acck[e] += gk[e] * uk[e]; }
+      gq[e] *= q_scale[8 * j + e]; gk[e] *= k_scale[8 * j + e];
+      dotq += uq[e] * gq[e]; dotk += uk[e] * gk[e];
+    }
+    dotq += __shfl_xor(dotq, 1, 64); dotq += __shfl_xor(dotq, 2, 64);
+    dotk += __shfl_xor(dotk, 1, 64); dotk += __shfl_xor(dotk, 2, 64);
+    if (ok) {
+      float oq[8], ok8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { oq[e] = iq * (gq[e] - uq[e] * dotq); ok8[e] = ik * (gk[e] - uk[e] * dotk); }
+      store8(dq + m * lddq + h * D + 8 * j, oq);
+      store8(dk + m * lddk + h * D + 8 * j, ok8);
+      *reinterpret_cast<u32x4*>(dv + m * lddv + h * D + 8 * j) = vv;
+    }
+  }
+  // deterministic in-block reduction: lanes with equal j (stride 4) by a fixed xor tree, then the four waves in order
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { accq[e] += __shfl_xor(accq[e], o, 64); acck[e] += __shfl_xor(acck[e], o, 64); }
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][wave][8 * lane + e] = accq[e]; red[1][wave][8 * lane + e] = acck[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5, d = threadIdx.x & 31;
+    part[((int64_t)blockIdx.x * 2 + which) * 32 + d] = red[which][0][d] + red[which][1][d] + red[which][2][d] + red[which][3][d];
+  }
+}
+__global__ void scale_grad_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dqs, float* __restrict__ dks) {
+  const int which = threadIdx.x >> 5, d = threadIdx.x & 31;
+  if (threadIdx.x >= 64) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += part[((int64_t)b * 2 + which) * 32 + d];
+  float* dst = which ? dks : dqs;
+  if (dst) dst[d] += t;
+}
+
+constexpr int NW_ROWS = 6;               // row blocks (waves) per workgroup of the three main kernels
+constexpr int UNPREP_BLOCKS = 2048;
+
+bool shape_ok(int H, int L, int gh, int gw, const float* tab) {
+  if (L % 32 || L < 64 || L > MAXL) return false;
+  if (tab && (gh * gw != L || gw % 8 || (2 * gh - 1) * (2 * gw - 1) > MAXCLS)) return false;
+  return H > 0;
+}
+int dbias_splits(int nseq, int H, int L) {
+  const int nkb = L / 32;
+  const int blocks = ((nkb + 1) / 2) * ((nkb + 3) / 4) * H;
+  int ns = (1024 + blocks - 1) / blocks;
+  if (ns > nseq) ns = nseq;
+  if (ns > 8) ns = 8;
+  return ns < 1 ? 1 : ns;
+}
+inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// 1 when ctclip_attn2_* serve this shape (bf16, d_head 32): L % 32 == 0, 64 <= L <= 1024; with a bias table gw % 8 == 0.
+extern "C" int ctclip_attn2_supported(int H, int L, int D_, int bias_gh, int bias_gw, int has_bias) {
+  static const float dummy = 0.f;
+  return D_ == D && shape_ok(H, L, bias_gh, bias_gw, has_bias ? &dummy : nullptr) ? 1 : 0;
+}
+
+// attention.py:152-154 + layout: q (M, ldq), k (M, ldk), v (M, ldv) bf16 row-major (H heads of 32) -> head-planar
+// q~ = l2norm(q) * q_scale * (scale * log2 e), k^ = l2norm(k) * k_scale, v ; inverse norms (M, H) f32.
+extern "C" int ctclip_attn2_prep(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* q_scale,
+                                 const float* k_scale, float scale, void* qh, void* kh, void* vh, float* qinv, float* kinv, int64_t M, int H,
+                                 hipStream_t stream) {
+  if (!q || !k || !v || !qh || !kh || !vh || !qinv || !kinv || !q_scale || !k_scale || ldq % 8 || ldk % 8 || ldv % 8 || M <= 0) { ctclip_set_error("attn2_prep: bad args"); return CTCLIP_EBADARG; }
+  hipLaunchKernelGGL(attn_prep_kernel, dim3((unsigned)cdiv(M * H * 4, 256)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                     ldq, ldk, ldv, q_scale, k_scale, scale * LOG2E, (bf16_t*)qh, (bf16_t*)kh, (bf16_t*)vh, qinv, kinv, M, H);
+  return ctclip_check_launch("attn2_prep");
+}
+
+// softmax(scale q^ k^T + bias) v on the prepared operands (attention.py:156-178).  tab: (ncls, H) position-bias table of a
+// bias_gh x bias_gw token grid (attention.py:257-276 evaluated on the distinct offsets) or null.  out: (M, ldo) bf16 row-major;
+// lse2: [H][M] f32 (log2-domain log-sum-exp, consumed by ctclip_attn2_bwd).
+extern "C" int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale,
+                                const float* k_scale, float scale, void* out, int64_t ldo, float* lse2, int nseq, int H, int L,
+                                hipStream_t stream) {
+  if (!qh || !kh || !vh || !out || !lse2 || !q_scale || !k_scale || ldo % 8) { ctclip_set_error("attn2_fwd: bad args"); return CTCLIP_EBADARG; }
+  if (!shape_ok(H, L, bias_gh, bias_gw, tab)) { ctclip_set_error("attn2_fwd: unsupported shape (L % 32 == 0, 64 <= L <= 1024, gw % 8 == 0)"); return CTCLIP_EUNSUPPORTED; }
+  Params p{};
+  p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
+  p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = (int64_t)nseq * L; p.c = scale * LOG2E;
+  p.out = (bf16_t*)out; p.ldo = ldo; p.lse2 = lse2;
+  const int ngroups = (L / 32 + NW_ROWS - 1) / NW_ROWS;
+  const int nitems = ngroups * nseq * H;
+  const dim3 grid((unsigned)(((nitems + 7) / 8) * 8)), block(NW_ROWS * 64);
+  if (tab) hipLaunchKernelGGL((attn2_fwd_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((attn2_fwd_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
+  return ctclip_check_launch("attn2_fwd");
+}
+
+extern "C" int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_gh, int bias_gw) {
+  const int64_t M = (int64_t)nseq * L;
+  int64_t n = a256(H * M * D * 2) + a256(H * M * 4);                                   // dO', delta'
+  if (bias_gh > 0) {
+    const int ncls = (2 * bias_gh - 1) * (2 * bias_gw - 1);
+    n += a256((int64_t)dbias_splits(nseq, H, L) * H * L * L * 4) + a256((int64_t)cdiv(L, 16) * H * ncls * 4);
+  }
+  return n;
+}
+
+// Backward of ctclip_attn2_fwd: dqh, dkh, dvh head-planar gradients w.r.t. q^ (NOT q~), k^, v; dtab (ncls, H) OVERWRITTEN when
+// non-null.  o, dout: (M, ldo / lddo) row-major.
+extern "C" int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale,
+                                const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2,
+                                void* dqh, void* dkh, void* dvh, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes,
+                                hipStream_t stream) {
+  if (!qh || !kh || !vh || !o || !dout || !lse2 || !dqh || !dkh || !dvh || !q_scale || !k_scale || ldo % 8 || lddo % 8) { ctclip_set_error("attn2_bwd: bad args"); return CTCLIP_EBADARG; }
+  if (!shape_ok(H, L, bias_gh, bias_gw, tab)) { ctclip_set_error("attn2_bwd: unsupported shape"); return CTCLIP_EUNSUPPORTED; }
+  if (dtab && !tab) { ctclip_set_error("attn2_bwd: dtab without a table"); return CTCLIP_EBADARG; }
+  if (!workspace || workspace_bytes < ctclip_attn2_bwd_workspace(nseq, H, L, dtab ? bias_gh : 0, bias_gw)) { ctclip_set_error("attn2_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int64_t M = (int64_t)nseq * L;
+  Params p{};
+  p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
+  p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = M; p.c = scale * LOG2E;
+  p.o = (const bf16_t*)o; p.ldo = ldo; p.dout = (const bf16_t*)dout; p.lddo = lddo; p.lse2 = const_cast<float*>(lse2);
+  char* w = (char*)workspace;
+  p.dop = (bf16_t*)w; w += a256(H * M * D * 2);
+  p.deltap = (float*)w; w += a256(H * M * 4);
+  p.dqh = (bf16_t*)dqh; p.dkh = (bf16_t*)dkh; p.dvh = (bf16_t*)dvh;
+  const int ngroups = (L / 32 + NW_ROWS - 1) / NW_ROWS;
+  const int nitems = ngroups * nseq * H;
+  const dim3 grid((unsigned)(((nitems + 7) / 8) * 8)), block(NW_ROWS * 64);
+  if (tab) hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
+  int rc = ctclip_check_launch("attn2_bwd_dq");
+  if (rc) return rc;
+  if (tab) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
+  rc = ctclip_check_launch("attn2_bwd_dkv");
+  if (rc || !dtab) return rc;
+  const int ncls = (2 * bias_gh - 1) * (2 * bias_gw - 1);
+  p.nsplit = dbias_splits(nseq, H, L);
+  p.dbias_part = (float*)w; w += a256((int64_t)p.nsplit * H * L * L * 4);
+  float* bins = (float*)w;
+  const int nkb = L / 32;
+  hipLaunchKernelGGL(attn2_bwd_dbias_kernel, dim3((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, p.nsplit), dim3(512), 0, stream, p);
+  rc = ctclip_check_launch("attn2_bwd_dbias");
+  if (rc) return rc;
+  const int nblk = (int)cdiv(L, 16);
+  hipLaunchKernelGGL(dbias_bin_kernel, dim3((unsigned)nblk, H), dim3(256), 0, stream, (const float*)p.dbias_part, p.nsplit, bins, H, bias_gh, bias_gw);
+  hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)cdiv(ncls * H, 256)), dim3(256), 0, stream, (const float*)bins, nblk, dtab, H, ncls);
+  return ctclip_check_launch("attn2_dbias_fold");
+}
+
+extern "C" int64_t ctclip_attn2_unprep_workspace(void) { return (int64_t)UNPREP_BLOCKS * 2 * 32 * 4; }
+
+// l2norm backward (attention.py:152-154) + layout: head-planar dq^, dk^, dv -> row-major dq (M, lddq), dk (M, lddk), dv (M, lddv);
+// dq_scale, dk_scale (32) ACCUMULATED (either may be null).
+extern "C" int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv,
+                                   const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv,
+                                   int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace,
+                                   int64_t workspace_bytes, hipStream_t stream) {
+  if (!dqh || !dkh || !dvh || !qh || !kh || !qinv || !kinv || !q_scale || !k_scale || !dq || !dk || !dv || lddq % 8 || lddk % 8 || lddv % 8) { ctclip_set_error("attn2_unprep: bad args"); return CTCLIP_EBADARG; }
+  if (!workspace || workspace_bytes < ctclip_attn2_unprep_workspace()) { ctclip_set_error("attn2_unprep: workspace too small"); return CTCLIP_EWORKSPACE; }
+  int64_t nb = cdiv(M * H * 4, 256);
+  if (nb > UNPREP_BLOCKS) nb = UNPREP_BLOCKS;
+  hipLaunchKernelGGL(attn_unprep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dqh, (const bf16_t*)dkh, (const bf16_t*)dvh,
+                     (const bf16_t*)qh, (const bf16_t*)kh, qinv, kinv, q_scale, k_scale, scale * LOG2E, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq,
+                     lddk, lddv, (float*)workspace, M, H);
+  int rc = ctclip_check_launch("attn2_unprep");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scale_grad_sum_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, (int)nb, dq_scale, dk_scale);
+  return ctclip_check_launch("attn2_scale_grad");
+}

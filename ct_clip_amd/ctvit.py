@@ -150,8 +150,8 @@ class Transformer(nn.Module):
             xn, x_kv, x = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)   # the three consumers of x: LayerNorm, to_kv, residual
             q = Fn.linear(xn, attn.to_q.weight)
             kv = Fn.linear(x_kv, attn.to_kv.weight)
-            o = Fn.CosineAttnFn.apply(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
-                                      float(attn.scale), bias_grid)
+            o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
+                                    float(attn.scale), bias_grid)
             x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
             y, x = Fn.layer_norm_branch(x, ff[0].weight, ff[0].bias, 1)

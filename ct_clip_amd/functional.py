@@ -386,6 +386,54 @@ class CosineAttnFn(Function):
                 None, None, None, None, None, None)
 
 
+class CosineAttn2Fn(Function):
+    """The same operator on the second-generation kernels (csrc/attn2.hip): bf16, d_head 32, L % 32 == 0.  One prep pass writes the
+    head-planar q~ / k^ / v (l2norm, learned scale and the logit scale folded in), the attention kernels read the position-bias
+    table directly, and one un-prep pass applies the l2norm backward: no transposed copies, no separate qk-norm / delta kernels."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_scale, k_scale, tab, nseq, L, H, D, scale, bias_grid):
+        be = B()
+        HD = H * D
+        qs, ks = q_scale.detach(), k_scale.detach()
+        qh, kh, vh, qinv, kinv = be.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, scale, H)
+        tabc = tab.detach().contiguous() if tab is not None else None
+        o, lse2 = be.attn2_fwd(qh, kh, vh, tabc, bias_grid, qs, ks, scale, nseq, L)
+        ctx.save_for_backward(qh, kh, vh, qinv, kinv, o, lse2, tabc if tabc is not None else q.new_empty(0))
+        ctx.scales = (q_scale, k_scale)
+        ctx.dims = (nseq, L, H, D, scale, tab is not None, bias_grid, q.dtype)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        be = B()
+        qh, kh, vh, qinv, kinv, o, lse2, tab = ctx.saved_tensors
+        nseq, L, H, D, scale, has_tab, bias_grid, dtype = ctx.dims
+        q_scale, k_scale = ctx.scales
+        qs, ks = q_scale.detach(), k_scale.detach()
+        HD = H * D
+        do = do.contiguous()
+        dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L,
+                                           has_tab and ctx.needs_input_grad[4])
+        M = o.shape[0]
+        dq = torch.empty((M, HD), dtype=dtype, device=o.device)
+        dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)
+        qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
+        dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
+        dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
+        be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, scale, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
+        return (dq, dkv, None if qs_sink is not None else dqs, None if ks_sink is not None else dks, dtab,
+                None, None, None, None, None, None)
+
+
+def cosine_attention(q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid=None):
+    """attention.py:145-178 on whichever kernel generation serves the shape (bias: the (ncls, H) table when bias_grid is given)."""
+    table = bias is not None and bias_grid is not None
+    if (bias is None or table) and B().attn2_supported(q.dtype, H, L, D, bias_grid if table else None, table):
+        return CosineAttn2Fn.apply(q, kv, q_scale, k_scale, bias if table else None, nseq, L, H, D, scale, bias_grid if table else None)
+    return CosineAttnFn.apply(q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid)
+
+
 class SdpaFn(Function):
     """HF BertSelfAttention core: softmax(q k^T / sqrt(d) + mask) v; q, k, v are (M, H*D) activations."""
 

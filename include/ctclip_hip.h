@@ -41,6 +41,27 @@ int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L);
 /* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). */
 int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* TODO: document */
+int ctclip_attn2_supported(int H, int L, int D_, int bias_gh, int bias_gw, int has_bias);
+
+/* TODO: document */
+int ctclip_attn2_prep(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* q_scale, const float* k_scale, float scale, void* qh, void* kh, void* vh, float* qinv, float* kinv, int64_t M, int H, hipStream_t stream);
+
+/* TODO: document */
+int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, void* out, int64_t ldo, float* lse2, int nseq, int H, int L, hipStream_t stream);
+
+/* TODO: document */
+int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
+
+/* TODO: document */
+int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, void* dqh, void* dkh, void* dvh, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* TODO: document */
+int64_t ctclip_attn2_unprep_workspace(void);
+
+/* TODO: document */
+int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* thread-local message of the last failing call. */
 const char* ctclip_last_error(void);
 

@@ -179,6 +179,83 @@ class RefBackend:
     def _mult(word, p):
         return torch.where((word >> 8).to(torch.float32) * (1.0 / 16777216.0) >= torch.tensor(p, dtype=torch.float32), 1.0 / (1.0 - p), 0.0)
 
+    # ---- attention, second generation (head-planar operands; spec of csrc/attn2.hip)
+    LOG2E = 1.4426950408889634
+
+    def attn2_supported(self, dtype, H, L, D, bias_grid, has_bias):
+        if dtype != torch.bfloat16 or D != 32 or L % 32 or L < 64 or L > 1024:
+            return False
+        if has_bias:
+            gh, gw = bias_grid
+            return gh * gw == L and gw % 8 == 0 and (2 * gh - 1) * (2 * gw - 1) <= 4096
+        return True
+
+    def attn2_prep(self, q, k, v, q_scale, k_scale, scale, H):
+        M = q.shape[0]
+        c = scale * self.LOG2E
+
+        def nrm(x, sv, mul):
+            xf = _f(x).reshape(M, H, 32)
+            inv = 1.0 / xf.norm(dim=-1).clamp_min(1e-12)
+            return (xf * inv[..., None] * sv * mul).permute(1, 0, 2).contiguous().to(x.dtype), inv
+        qh, qinv = nrm(q, q_scale, c)
+        kh, kinv = nrm(k, k_scale, 1.0)
+        vh = v.reshape(M, H, 32).permute(1, 0, 2).contiguous()
+        return qh, kh, vh, qinv, kinv
+
+    def _z(self, qh, kh, tab, bias_grid, nseq, L):
+        H = qh.shape[0]
+        z = torch.einsum("hsid,hsjd->hsij", _f(qh).reshape(H, nseq, L, 32), _f(kh).reshape(H, nseq, L, 32))     # log2-domain logits
+        if tab is not None:
+            gh, gw = bias_grid
+            z = z + (tab.t()[:, self._cls(gh, gw, tab.device)] * self.LOG2E)[:, None]
+        return z
+
+    def attn2_fwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, nseq, L):
+        H, M, _ = qh.shape
+        z = self._z(qh, kh, tab, bias_grid, nseq, L)
+        lse2 = torch.logsumexp(z * (1.0 / self.LOG2E), dim=-1) * self.LOG2E
+        p = torch.exp2(z - lse2[..., None])
+        o = torch.einsum("hsij,hsjd->hsid", p, _f(vh).reshape(H, nseq, L, 32))
+        return o.permute(1, 2, 0, 3).reshape(M, H * 32).to(qh.dtype), lse2.reshape(H, M)
+
+    def attn2_bwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab):
+        H, M, _ = qh.shape
+        c = scale * self.LOG2E
+        z = self._z(qh, kh, tab, bias_grid, nseq, L)
+        p = torch.exp2(z - lse2.reshape(H, nseq, L)[..., None])
+        do = _f(dout).reshape(nseq, L, H, 32).permute(2, 0, 1, 3)
+        of = _f(o).reshape(nseq, L, H, 32).permute(2, 0, 1, 3)
+        v4, k4, q4 = (_f(t).reshape(H, nseq, L, 32) for t in (vh, kh, qh))
+        dp = torch.einsum("hsid,hsjd->hsij", do, v4)
+        delta = (do * of).sum(-1)
+        ds = p * (dp - delta[..., None])
+        dqh = scale * torch.einsum("hsij,hsjd->hsid", ds, k4)
+        dkh = (scale / c) * torch.einsum("hsij,hsid->hsjd", ds, q4)
+        dvh = torch.einsum("hsij,hsid->hsjd", p, do)
+        dtab = None
+        if want_dtab and tab is not None:
+            gh, gw = bias_grid
+            ncls = (2 * gh - 1) * (2 * gw - 1)
+            dtab = torch.zeros((ncls, H), dtype=torch.float32, device=qh.device)
+            dtab.index_add_(0, self._cls(gh, gw, qh.device).reshape(-1), ds.sum(1).reshape(H, L * L).t().contiguous())
+        return tuple(t.reshape(H, M, 32).to(qh.dtype) for t in (dqh, dkh, dvh)) + (dtab,)
+
+    def attn2_unprep(self, dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale):
+        H, M, _ = qh.shape
+        c = scale * self.LOG2E
+
+        def back(dxh, xh, inv, sv, mul, out, dsv):
+            g_hat = _f(dxh).permute(1, 0, 2)                       # (M, H, 32) gradient w.r.t. x^ = u * sv
+            u = _f(xh).permute(1, 0, 2) / (sv * mul)
+            if dsv is not None:
+                dsv += (g_hat * u).sum((0, 1))
+            g = g_hat * sv
+            out.copy_((inv[..., None] * (g - u * (u * g).sum(-1, keepdim=True))).reshape(M, H * 32).to(out.dtype))
+        back(dqh, qh, qinv, q_scale, c, dq, dq_scale)
+        back(dkh, kh, kinv, k_scale, 1.0, dk, dk_scale)
+        dv.copy_(dvh.permute(1, 0, 2).reshape(M, H * 32))
+
     def dropout(self, x, residual, p, seed, stream_id):
         n = x.numel()
         idx = torch.arange(n // 4, dtype=torch.int64)            # integer Philox on the CPU (no device JIT of int64 kernels)

@@ -96,3 +96,25 @@ def test_bert_train_mode_dropout(ref_backend):
     with torch.no_grad():   # eval mode = the HF module itself
         hf = model(input_ids=ids, attention_mask=mask)[0].reshape(-1, 64)
     torch.testing.assert_close(e1.detach(), hf, rtol=1e-4, atol=1e-4)
+
+
+def test_second_generation_attention_composition(ref_backend):
+    """ct_clip_amd.functional.CosineAttn2Fn (prep -> attention on head-planar operands -> un-prep) and CosineAttnFn (qk-norm,
+    transposes, attention) are the same operator: outputs and the gradients of q, kv, both scale vectors and the bias table."""
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(0)
+    nseq, H, gh, gw, D = 2, 2, 8, 8, 32
+    L, M = gh * gw, nseq * gh * gw
+    q, kv = torch.randn(M, H * D), torch.randn(M, 2 * H * D)
+    qs, ks = 1 + 0.2 * torch.randn(D), 1 + 0.2 * torch.randn(D)
+    tab = 0.5 * torch.randn((2 * gh - 1) * (2 * gw - 1), H)
+    do = torch.randn(M, H * D)
+    res = []
+    for fn in (Fn.CosineAttn2Fn, Fn.CosineAttnFn):
+        ins = [t.clone().requires_grad_(True) for t in (q, kv, qs, ks, tab)]
+        o = fn.apply(ins[0], ins[1], ins[2], ins[3], ins[4], nseq, L, H, D, 8.0, (gh, gw))
+        o.backward(do)
+        res.append([o] + [t.grad for t in ins])
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
+    assert Fn.B().attn2_supported(torch.bfloat16, H, L, D, (gh, gw), True) and not Fn.B().attn2_supported(torch.float32, H, L, D, (gh, gw), True)

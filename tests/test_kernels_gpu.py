@@ -408,6 +408,82 @@ def test_vq_kernels(hip, ref, dtype):
     close(cl, clr, rtol=1e-5, atol=1e-6); close(em, emr, rtol=1e-4, atol=1e-5)
 
 
+# ---------------------------------------------------------------- attention, second generation (csrc/attn2.hip)
+def _attn2_case(nseq, H, gh, gw, qk_gain, with_tab, seed=0):
+    L, D = gh * gw, 32
+    M = nseq * L
+    q, kv = rnd(M, H * D, dtype=torch.bfloat16, seed=seed + 1), rnd(M, 2 * H * D, dtype=torch.bfloat16, seed=seed + 2)
+    qs = (1.0 + 0.2 * rnd(D, seed=seed + 3)) * qk_gain
+    ks = (1.0 + 0.2 * rnd(D, seed=seed + 4)) * qk_gain
+    tab = rnd((2 * gh - 1) * (2 * gw - 1), H, seed=seed + 5, scale=0.5) if with_tab else None
+    return L, D, M, q, kv, qs, ks, tab
+
+
+@pytest.mark.parametrize("nseq,H,gh,gw,gain,with_tab", [(3, 8, 24, 24, 1.0, True), (2, 2, 4, 8, 1.0, True), (2, 4, 8, 16, 1.0, False),
+                                                         (2, 8, 24, 24, 3.5, True), (3, 2, 2, 32, 4.0, False)])
+def test_attn2_fwd_bwd(hip, ref, nseq, H, gh, gw, gain, with_tab):
+    """gain 1: the bounded-logit path (|q_scale||k_scale| small); gain >= 3.5: 2 c qs ks > 100 -> the online-softmax path."""
+    L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, gain, with_tab)
+    HD = H * D
+    grid = (gh, gw) if with_tab else None
+    assert hip.attn2_supported(torch.bfloat16, H, L, D, grid, with_tab)
+    outs = hip.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    outr = ref.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    for a, b in zip(outs[:3], outr[:3]):
+        close(a, b, rtol=1e-2, atol=2e-2 * gain)
+    close(outs[3], outr[3], rtol=1e-5, atol=0); close(outs[4], outr[4], rtol=1e-5, atol=0)
+    qh, kh, vh, qinv, kinv = outs
+    o, lse2 = hip.attn2_fwd(qh, kh, vh, tab, grid, qs, ks, 8.0, nseq, L)
+    orf, lser = ref.attn2_fwd(qh, kh, vh, tab, grid, qs, ks, 8.0, nseq, L)
+    close(lse2, lser, rtol=1e-4, atol=2e-3)
+    close(o, orf, rtol=2e-2, atol=2e-2)
+    do = rnd(M, HD, dtype=torch.bfloat16, seed=9)
+    dqh, dkh, dvh, dtab = hip.attn2_bwd(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, nseq, L, with_tab)
+    rq, rk, rv, rtab = ref.attn2_bwd(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, nseq, L, with_tab)
+    for name, a, b in (("dq", dqh, rq), ("dk", dkh, rk), ("dv", dvh, rv)):
+        err = (a.float() - b.float()).norm() / b.float().norm()
+        assert err < 2e-2, (name, float(err))
+        close(a, b, rtol=5e-2, atol=5e-2 * float(b.float().abs().max()))
+    if with_tab:
+        err = (dtab - rtab).norm() / rtab.norm()
+        assert err < 1e-2, float(err)
+        again = hip.attn2_bwd(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, nseq, L, True)[3]
+        assert torch.equal(dtab, again)                                  # no atomics: bit-identical
+    dq, dkv = torch.empty(M, HD, dtype=torch.bfloat16, device=DEV), torch.empty(M, 2 * HD, dtype=torch.bfloat16, device=DEV)
+    dqr, dkvr = torch.empty_like(dq), torch.empty_like(dkv)
+    dqs, dks, dqsr, dksr = (torch.ones(D, device=DEV) for _ in range(4))
+    hip.attn2_unprep(rq, rk, rv, qh, kh, qinv, kinv, qs, ks, 8.0, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
+    ref.attn2_unprep(rq, rk, rv, qh, kh, qinv, kinv, qs, ks, 8.0, dqr, dkvr[:, :HD], dkvr[:, HD:], dqsr, dksr)
+    close(dq, dqr, rtol=3e-2, atol=3e-2 * float(dqr.float().abs().max()))
+    close(dkv, dkvr, rtol=3e-2, atol=3e-2 * float(dkvr.float().abs().max()))
+    close(dqs, dqsr, rtol=1e-3, atol=1e-3 * float(dqsr.abs().max())); close(dks, dksr, rtol=1e-3, atol=1e-3 * float(dksr.abs().max()))
+    dqs2, dks2 = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    hip.attn2_unprep(rq, rk, rv, qh, kh, qinv, kinv, qs, ks, 8.0, dq, dkv[:, :HD], dkv[:, HD:], dqs2, dks2)
+    assert torch.equal(dqs, dqs2) and torch.equal(dks, dks2)
+
+
+def test_attn2_matches_first_generation_operator(hip):
+    """End to end through the autograd layer: the head-planar path and the round-1 path (separate qk-norm / transposes / attention)
+    are the same operator (attention.py:145-178) -- outputs and all five gradients."""
+    from ct_clip_amd import backend, functional as Fn
+    prev = backend.use(hip)
+    try:
+        nseq, H, gh, gw = 4, 8, 24, 24
+        L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, 1.0, True, seed=20)
+        res = []
+        for fn in (Fn.CosineAttn2Fn, Fn.CosineAttnFn):
+            ins = [t.clone().requires_grad_(True) for t in (q, kv, qs, ks, tab)]
+            o = fn.apply(ins[0], ins[1], ins[2], ins[3], ins[4], nseq, L, H, D, 8.0, (gh, gw))
+            do = rnd(M, H * D, dtype=torch.bfloat16, seed=30)
+            o.backward(do)
+            res.append([o] + [t.grad for t in ins])
+        for a, b in zip(*res):
+            err = (a.float() - b.float()).norm() / b.float().norm()
+            assert err < 2e-2, float(err)
+    finally:
+        backend.use(prev)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,d,nseg", [(5000, 512, 8192), (1024, 768, 30522), (3001, 64, 7), (40, 8, 1)])
 def test_segment_sum(hip, ref, dtype, M, d, nseg):

@@ -97,3 +97,72 @@ def test_relative_bias_classes_of_a_fragment_run_are_consecutive():
                 base = u(i) - u(j0) + c0
                 assert [cls(i, j0 + e) for e in range(8)] == [base - e for e in range(8)]
                 assert 0 <= base - 7 and base < (2 * gh - 1) * (2 * gw - 1)
+
+
+# ---------------------------------------------------------------------------------------------------- attn2.hip
+A2_SWZ = lambda row, chunk: row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)
+A2_PI32 = lambda c: (c & 3) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 16)
+
+
+def a2_image():
+    """loader of attn2.hip: thread (row, chunk) stores elements (row, 8 chunk + e) of a 32 x 32 bf16 tile at swz(row, chunk) + 2 e"""
+    lds = {}
+    for row, chunk, e in itertools.product(range(32), range(4), range(8)):
+        lds[A2_SWZ(row, chunk) + 2 * e] = (row, 8 * chunk + e)
+    assert len(lds) == 32 * 32
+    return lds
+
+
+def test_attn2_row_fragments_are_bank_conflict_free():
+    # attn2.hip lds_rows: two b128 reads at swz(row, half) and swz(row, 2 + half); row = pi32(lane & 31) (A operands) or lane & 31 (B)
+    for perm in (A2_PI32, lambda c: c):
+        for off in (0, 2):
+            for grp in B128_GROUPS:
+                addrs = [A2_SWZ(perm(l & 31), off + (l >> 5)) for l in grp]
+                assert len(set(slots16(addrs))) == 16
+
+
+def test_attn2_transposed_fragments():
+    # attn2.hip tr_offsets / lds_cols: lane (i = lane & 31, half) must receive tokens 8 half + e and 16 + 8 half + e of head dim pi32(i)
+    lds = a2_image()
+
+    def tr_off(lane):
+        t, grp, half = lane & 15, (lane >> 4) & 1, lane >> 5
+        sg = ((t & 1) << 1) | ((t >> 1) & 1)
+        return [A2_SWZ(8 * half + 4 * j0 + (t >> 2), 2 * grp + (sg >> 1)) + 8 * (sg & 1) for j0 in range(2)]
+    frag = {l: [] for l in range(64)}
+    for base in (0, 1024):
+        for j0 in range(2):
+            addr = {l: base + tr_off(l)[j0] for l in range(64)}
+            for hw in range(2):    # a half-wave must cover 32 distinct 8-byte slots of the 256-byte bank row
+                assert len({(addr[l] // 8) % 32 for l in range(hw * 32, hw * 32 + 32)}) == 32
+            got = tr_read(lds, addr)
+            for l in range(64):
+                frag[l] += got[l]
+    for l in range(64):
+        i, half = l & 31, l >> 5
+        assert frag[l] == [(8 * half + e, A2_PI32(i)) for e in range(8)] + [(16 + 8 * half + e, A2_PI32(i)) for e in range(8)]
+
+
+def test_attn2_bias_tile_addresses():
+    # attn2.hip bias_tile: rows = keys -> reversed table entry ncls - 1 - (u(q) - u(k0) + c0) + e ; rows = queries -> u(q0) - u(k) + c0 + e
+    for gh, gw in ((24, 24), (3, 8), (5, 16)):
+        u = lambda t: (t // gw) * (2 * gw - 1) + t % gw
+        c0 = (gh - 1) * (2 * gw - 1) + (gw - 1)
+        ncls = (2 * gh - 1) * (2 * gw - 1)
+        cls = lambda i, j: (i // gw - j // gw + gh - 1) * (2 * gw - 1) + (i % gw - j % gw + gw - 1)
+        L = gh * gw
+        for i in range(L):
+            for j0 in range(0, L, 8):
+                rbase = ncls - 1 - (u(i) - u(j0) + c0)
+                assert [ncls - 1 - cls(i, j0 + e) for e in range(8)] == [rbase + e for e in range(8)] and 0 <= rbase and rbase + 7 < ncls
+                fbase = u(j0) - u(i) + c0
+                assert [cls(j0 + e, i) for e in range(8)] == [fbase + e for e in range(8)] and 0 <= fbase and fbase + 7 < ncls
+
+
+def test_attn2_work_item_decode_covers_every_item_once():
+    # attn2.hip decode_item: workgroup b -> item (b & 7) * per + (b >> 3), per = ceil(nitems / 8); grid = 8 * per
+    for nitems in (1, 7, 8, 9, 4608, 4611):
+        per = (nitems + 7) >> 3
+        seen = [(b & 7) * per + (b >> 3) for b in range(8 * per)]
+        assert sorted(w for w in seen if w < nitems) == list(range(nitems))
