@@ -12,8 +12,12 @@ from .ctclip import CTCLIP  # noqa: F401
 from .trainer import CTClipTrainer, FusedAdam, hot_path_parameters  # noqa: F401
 
 
-def get_optimizer(params, lr=1e-4, wd=1e-4, betas=(0.9, 0.99), eps=1e-8, **kwargs):
-    """transformer_maskgit/optimizer.py:10-34 on the fused HIP Adam (params: iterable of (name, param) or params)."""
+def get_optimizer(params, lr=1e-4, wd=1e-4, betas=(0.9, 0.99), eps=1e-8, filter_by_requires_grad=False, group_wd_params=True,
+                  **kwargs):
+    """transformer_maskgit/optimizer.py:10-34 on the fused HIP Adam (params: iterable of (name, param) or params): wd == 0 is Adam,
+    otherwise AdamW; with group_wd_params the ndim < 2 parameters form a no-decay group; filter_by_requires_grad drops frozen ones."""
     params = list(params)
     named = params if params and isinstance(params[0], tuple) else [(f"p{i}", p) for i, p in enumerate(params)]
-    return FusedAdam(named, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    if filter_by_requires_grad:
+        named = [(n, p) for n, p in named if p.requires_grad]
+    return FusedAdam(named, lr=lr, betas=betas, eps=eps, weight_decay=wd, group_wd_params=group_wd_params)

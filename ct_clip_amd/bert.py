@@ -53,6 +53,7 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
         keymask = ((1.0 - attention_mask.to(device=dev, dtype=torch.float32)) * torch.finfo(torch.float32).min).contiguous()
     scale = 1.0 / math.sqrt(dh)
     for li, layer in enumerate(bert.encoder.layer):
+        x = Fn.grad_ready(x, layer)
         sa, so = layer.attention.self, layer.attention.output
         q = Fn.linear(x, sa.query.weight, sa.query.bias)
         k = Fn.linear(x, sa.key.weight, sa.key.bias)

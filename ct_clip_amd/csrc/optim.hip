@@ -37,17 +37,19 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                                   float bc1, float bc2_sqrt, float weight_decay, const float* __restrict__ clip) {
+                                                   float bc1, float bc2_sqrt, float weight_decay, const float* __restrict__ clip,
+                                                   const uint8_t* __restrict__ decay_mask4) {
   const float cs = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
     const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const bool decay = weight_decay != 0.f && (!decay_mask4 || decay_mask4[i]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gg = gv[e] * cs;
-      if (weight_decay != 0.f) pv[e] *= 1.f - lr * weight_decay;
+      if (decay) pv[e] *= 1.f - lr * weight_decay;
       mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
       vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
       pv[e] -= step * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
       const float gg = g[i] * cs;
       float pv = p[i];
-      if (weight_decay != 0.f) pv *= 1.f - lr * weight_decay;
+      if (weight_decay != 0.f && (!decay_mask4 || decay_mask4[i / 4])) pv *= 1.f - lr * weight_decay;
       m[i] = beta1 * m[i] + (1.f - beta1) * gg;
       v[i] = beta2 * v[i] + (1.f - beta2) * gg * gg;
       p[i] = pv - step * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
@@ -78,12 +80,14 @@ extern "C" int ctclip_grad_norm_clip(const float* g, int64_t n, const float* ext
   return ctclip_check_launch("grad_norm_clip");
 }
 // torch.optim.Adam / AdamW step over flat buffers; `clip` = the 2-float output of ctclip_grad_norm_clip (or null).
+// decay_mask4: one byte per group of FOUR consecutive parameters (ceil(n / 4) bytes), 0 = no weight decay for that group -- the
+// "ndim < 2 parameters are not decayed" grouping of transformer_maskgit/optimizer.py:3-8,27-32; null = decay everything.
 extern "C" int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                int step, float weight_decay, const float* clip, hipStream_t s) {
+                                int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s) {
   if (!p || !g || !m || !v || step < 1 || ((uintptr_t)p % 16) || ((uintptr_t)g % 16) || ((uintptr_t)m % 16) || ((uintptr_t)v % 16)) { ctclip_set_error("adam_step: bad args (16-B aligned flat buffers, step >= 1)"); return CTCLIP_EBADARG; }
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   int64_t nb = cdiv(n / 4 + 1, 256); if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, weight_decay, clip);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, weight_decay, clip, decay_mask4);
   return ctclip_check_launch("adam_step");
 }

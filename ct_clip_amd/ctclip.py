@@ -133,6 +133,8 @@ class CTCLIP(nn.Module):
         if return_encodings:
             return enc_text.view(Bt, T, -1), enc_image
         cls = enc_text.view(Bt, -1)[:, :self.dim_text]                                          # enc_text[:, 0, :] (ct_clip.py:762)
+        cls = Fn.grad_ready(cls, self.to_text_latent)
+        enc_image = Fn.grad_ready(enc_image, self.to_visual_latent)
         text_lat = Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)          # (Bt, Dl) f32, pre-l2norm
         image_lat = Fn.visual_latent(enc_image, self.to_visual_latent.weight)                   # (Bi, Dl) f32, pre-l2norm
         if return_latents:

@@ -143,7 +143,9 @@ class Transformer(nn.Module):
         """x: (nseq*L, dim) activation in compute dtype (flat view of the reference's (nseq, L, dim))."""
         b, t, h, w = video_shape
         d = x.shape[1]
-        for peg, attn, _, ff in self.layers:
+        for layer in self.layers:
+            peg, attn, _, ff = layer
+            x = Fn.grad_ready(x, layer)     # backward passing this point = the layer's parameter gradients are final
             # x = peg(x) + x  -- PEG sees the buffer flat-reinterpreted as (b, t, h, w, d) (attention.py:69-70)
             x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
             # x = attn(x) + x  -- q from LayerNorm(x), k/v from the RAW x (attention.py:139-143)

@@ -96,6 +96,45 @@ def vec_grad(param, compute):
     return None if sink is not None else dst
 
 
+# ------------------------------------------------------------------------------------------ gradient-ready notifications
+# Data-parallel training overlaps the gradient all-reduce with backward (distributed.GradReducer).  Weight gradients are written
+# straight into the flat gradient buffer by the kernels, so autograd's own parameter hooks never fire; instead the model marks
+# the INPUT activation of each block: when backward reaches the marker, every parameter used after it has its final gradient.
+
+_GRAD_READY_HOOK = None
+
+
+def set_grad_ready_hook(fn):
+    """fn(tag) is called from backward when the gradients of the parameters registered under `tag` are final; None = off."""
+    global _GRAD_READY_HOOK
+    prev, _GRAD_READY_HOOK = _GRAD_READY_HOOK, fn
+    return prev
+
+
+def notify_grad_ready(tag):
+    if _GRAD_READY_HOOK is not None:
+        _GRAD_READY_HOOK(tag)
+
+
+class _GradReadyFn(Function):
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        notify_grad_ready(ctx.tag)
+        return dy, None
+
+
+def grad_ready(x, tag):
+    """Identity; in backward, announces `tag` (no-op and no graph node unless a hook is installed and x carries gradient)."""
+    if _GRAD_READY_HOOK is None or not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return _GradReadyFn.apply(x, tag)
+
+
 # ------------------------------------------------------------------------------------------ Linear
 
 class LinearFn(Function):
@@ -662,6 +701,7 @@ class BertEmbedFn(Function):
         dp = ps if ps is not None else torch.zeros_like(pos)
         dt = ts if ts is not None else torch.zeros_like(typ)
         B().bert_embed_bwd(ids, dx.contiguous(), dw, dp, dt)   # dt row 0 only (token_type_ids are all zero)
+        notify_grad_ready(("bert_embeddings", id(word)))        # the last gradients of the text tower
         return None, (None if ws is not None else dw), (None if ps is not None else dp), (None if ts is not None else dt), None
 
 

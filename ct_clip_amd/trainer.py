@@ -30,10 +30,14 @@ def noop(*a, **k):
     pass
 
 
-def cycle(dl):
+def cycle(dl, sampler=None):
+    epoch = 0
     while True:
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         for data in dl:
             yield data
+        epoch += 1
 
 
 def hot_path_parameters(model):
@@ -43,9 +47,12 @@ def hot_path_parameters(model):
 
 
 class FusedAdam:
-    """Flat-buffer Adam/AdamW + global grad-norm clip on HIP kernels; minimal torch.optim-like surface."""
+    """Flat-buffer Adam/AdamW + global grad-norm clip on HIP kernels; minimal torch.optim-like surface.
 
-    def __init__(self, named_params, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+    weight_decay > 0 is AdamW with the reference's grouping (transformer_maskgit/optimizer.py:3-8,27-32): parameters with
+    ndim < 2 (LayerNorm gammas, biases, q/k scales, temperature) are not decayed (`group_wd_params`)."""
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, group_wd_params=True):
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -68,9 +75,31 @@ class FusedAdam:
                 p.grad = g
                 self.offsets.append(off)
                 off += sz
+        self.decay_mask4 = None
+        if weight_decay and group_wd_params:
+            mask = torch.zeros(total // 4, dtype=torch.uint8)
+            for p, off in zip(self.params, self.offsets):
+                if p.ndim >= 2:
+                    mask[off // 4:(off + p.numel() + 3) // 4] = 1
+            self.decay_mask4 = mask.to(dev)
+        wd_params = [p for p in self.params if p.ndim >= 2] if (weight_decay and group_wd_params) else self.params
+        no_wd = [p for p in self.params if p.ndim < 2] if (weight_decay and group_wd_params) else []
+        self.param_groups = [dict(params=wd_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        if no_wd:
+            self.param_groups.append(dict(params=no_wd, lr=lr, betas=betas, eps=eps, weight_decay=0.0))
         self.step_count = 0
         self.last_norm = None
         Fn.bump_weight_epoch()
+
+    def range_of(self, params):
+        """[start, end) of the flat buffers covered by `params` (must be a contiguous run in registration order)."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx:
+            return None
+        assert idx == list(range(idx[0], idx[-1] + 1)), "parameters of a gradient bucket must be contiguous in the flat buffer"
+        last = idx[-1]
+        return self.offsets[idx[0]], self.offsets[last] + (self.params[last].numel() + 3) // 4 * 4
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
@@ -81,7 +110,7 @@ class FusedAdam:
         clip = be.grad_norm_clip(self.flat_grad, max_grad_norm or 0.0, extra_sq)
         self.last_norm = clip
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                     self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None)
+                     self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4)
         Fn.bump_weight_epoch()
 
     def state_dict(self):
@@ -101,7 +130,7 @@ class CTClipTrainer(nn.Module):
                  lr=1.25e-6, wd=0.0, max_grad_norm=0.5, save_results_every=1, save_model_every=1,
                  results_folder="./ctclip/", num_workers=8, accelerate_kwargs: dict = dict(),
                  train_dataset=None, valid_dataset=None, evaluate=True, checkpoint=True, max_text_len=512,
-                 sync_loss_every=1, device=None):
+                 sync_loss_every=1, device=None, grad_comm_dtype=None, overlap_grad_reduce=True, data_seed=0):
         super().__init__()
         if "RANK" in os.environ and "WORLD_SIZE" in os.environ and not _dist.is_on() and int(os.environ["WORLD_SIZE"]) > 1:
             torch.distributed.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
@@ -127,15 +156,27 @@ class CTClipTrainer(nn.Module):
 
         self.optim = FusedAdam(hot_path_parameters(self.CTClip), lr=lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
         gather = getattr(self.CTClip, "gather_negatives", True)
-        self.reducer = _dist.GradReducer(self.optim.flat_grad, op="sum" if gather else "mean")
+        if grad_comm_dtype is None:      # bf16 buckets in performance mode, f32 in parity mode (CTCLIP_GRAD_COMM_DTYPE overrides)
+            env = os.environ.get("CTCLIP_GRAD_COMM_DTYPE", "").lower()
+            cdt = getattr(self.CTClip, "compute_dtype", torch.float32)
+            grad_comm_dtype = torch.float32 if env in ("f32", "fp32", "float32") else torch.bfloat16 if env in ("bf16", "bfloat16") else cdt
+        self.reducer = _dist.GradReducer(self.optim, op="sum" if gather else "mean", comm_dtype=grad_comm_dtype,
+                                         overlap=overlap_grad_reduce).install(self.CTClip)
         Fn.VqFn.stat_sync = staticmethod(_dist.sync_vq_stats)
 
         if train_dataset is None:
             from data import CTReportDataset  # the reference's scripts/data.py, when run from its scripts directory
             train_dataset = CTReportDataset(data_folder=data_train, reports_file=reports_file_train, meta_file=train_meta_file)
         self.ds = train_dataset
-        self.dl = DataLoader(self.ds, num_workers=num_workers, batch_size=self.batch_size, shuffle=True)
-        self.dl_iter = cycle(self.dl)
+        # one process per GPU: every rank must draw DIFFERENT samples (with gathered negatives identical batches would be scored as
+        # negatives of themselves) -- a DistributedSampler partitions each epoch's permutation across the ranks
+        self.sampler = None
+        if _dist.world_size() > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            self.sampler = DistributedSampler(self.ds, num_replicas=_dist.world_size(), rank=_dist.rank(), shuffle=True, seed=data_seed)
+        self.dl = DataLoader(self.ds, num_workers=num_workers, batch_size=self.batch_size, shuffle=self.sampler is None,
+                             sampler=self.sampler)
+        self.dl_iter = cycle(self.dl, self.sampler)
         self.evaluate = evaluate
         if evaluate:
             if valid_dataset is None:
@@ -185,8 +226,8 @@ class CTClipTrainer(nn.Module):
     def forward_backward(self, video, text_tokens):
         """fwd + bwd + gradient all-reduce; returns the (device) loss."""
         loss = self.CTClip(text_tokens, video, return_loss=True, device=self.device)
-        loss.backward()
-        self.reducer.reduce()
+        loss.backward()          # announces finished layers to the reducer as it goes (functional.grad_ready)
+        self.reducer.finish()
         return loss
 
     def train_step(self):

@@ -189,7 +189,7 @@ int64_t ctclip_grad_norm_workspace(void);
 int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, float max_norm, float* out, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* torch.optim.Adam(lr, betas=(0.9,0.99), eps=1e-8).step() over a flat buffer (optimizer.py:24; CTCLIPTrainer.py:262). */
-int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, hipStream_t s);
+int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s);
 
 /* TODO: document */
 int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);

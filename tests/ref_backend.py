@@ -457,10 +457,14 @@ class RefBackend:
         coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) if max_norm else torch.ones_like(norm)
         return torch.stack([norm, coef])
 
-    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None):
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None, decay_mask4=None):
         gg = g * (clip[1] if clip is not None else 1.0)
         if weight_decay:
-            p.mul_(1 - lr * weight_decay)
+            if decay_mask4 is None:
+                p.mul_(1 - lr * weight_decay)
+            else:
+                keep = decay_mask4.to(torch.bool).repeat_interleave(4)[:p.numel()]
+                p.mul_(torch.where(keep, torch.full_like(p, 1 - lr * weight_decay), torch.ones_like(p)))
         m.mul_(beta1).add_(gg, alpha=1 - beta1)
         v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
         bc1 = 1 - beta1 ** step

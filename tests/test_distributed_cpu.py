@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, out):
+def _worker(rank, world, port, name, out, mode="overlap"):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -39,30 +39,46 @@ def _worker(rank, world, port, name, out):
     clip = build_model(g["config"], g["state_dict"], torch.device("cpu"), torch.float32)
     clip.train()
     opt = FusedAdam(hot_path_parameters(clip), lr=1e-3)
+    red = D.GradReducer(opt, op="sum", comm_dtype=torch.bfloat16 if mode == "overlap_bf16" else torch.float32, min_bucket_bytes=1,
+                        overlap=mode != "serial").install(clip)
     loss = clip(TextBatch(g["input_ids"][sl], g["attention_mask"][sl]), g["video"][sl], return_loss=True, device=torch.device("cpu"))
     loss.backward()
-    D.GradReducer(opt.flat_grad, op="sum").reduce()
+    during_backward = len(red.log)          # collectives launched from inside backward (overlap) vs. none (serial)
+    red.finish()
+    cover = sorted(red.log)
+    assert cover[0][0] == 0 and cover[-1][1] == opt.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), \
+        "every element of the flat gradient buffer must be reduced exactly once"
+    Fn.set_grad_ready_hook(None)
     if rank == 0:
         grads = {n: p.grad.detach().clone() for n, p in hot_path_parameters(clip)}
         vq = {k: v.clone() for k, v in clip.state_dict().items() if "vq._codebook" in k}
-        torch.save(dict(loss=loss.detach(), grads=grads, vq=vq), out)
+        torch.save(dict(loss=loss.detach(), grads=grads, vq=vq, during_backward=during_backward, launches=len(red.log)), out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["tiny"])
-def test_two_ranks_match_single_process_global_batch(golden, tmp_path, name):
+@pytest.mark.parametrize("name,mode", [("tiny", "overlap"), ("tiny", "serial"), ("tiny", "overlap_bf16")])
+def test_two_ranks_match_single_process_global_batch(golden, tmp_path, name, mode):
+    """overlap: the all-reduce of a layer's gradients is launched from inside backward as soon as they are final; serial: one
+    reduction after backward.  Both must give the single-process global-batch gradients (bf16 buckets: to bf16 rounding)."""
     from tests.helpers import check_grad
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), name, out, mode), nprocs=2, join=True)
     res = torch.load(out, weights_only=False)
     g = golden(name)
     torch.testing.assert_close(res["loss"], g["loss"], rtol=1e-4, atol=1e-5)
+    if mode == "serial":
+        assert res["during_backward"] == 0
+    else:
+        assert res["during_backward"] >= 4 and res["launches"] > res["during_backward"]
     n = 0
     for k, rec in g["grads"].items():
         if rec["value"].numel() == 0 or k not in res["grads"]:
             continue
-        check_grad(rec, res["grads"][k], rtol=2e-3, atol_rel=2e-4, floor=1e-9 * float(g["grad_norm"]))
+        if mode == "overlap_bf16":
+            check_grad(rec, res["grads"][k], rtol=2e-2, atol_rel=1e-2, floor=1e-9 * float(g["grad_norm"]))
+        else:
+            check_grad(rec, res["grads"][k], rtol=2e-3, atol_rel=2e-4, floor=1e-9 * float(g["grad_norm"]))
         n += 1
     assert n > 40
     for k, v in g["vq_after"].items():

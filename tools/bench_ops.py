@@ -69,6 +69,31 @@ if what in ("attn", "all"):
     for name, (fn, fl) in cases.items():
         us = timeit(fn)
         out[name] = dict(avg_us=round(us, 1), tflops=round(fl / us / 1e6, 1))
+if what in ("attn2", "all"):
+    # second-generation spatial attention (csrc/attn2.hip) at the bench shape: prep, forward, backward (+ dBias), un-prep
+    nseq, H, gh, gw, D = 192, 8, 24, 24, 32
+    L, HD = gh * gw, H * D
+    M = nseq * L
+    q, kv, do = rnd(M, HD), rnd(M, 2 * HD), rnd(M, HD)
+    qs, ks = 1 + 0.1 * rnd(D, dt=torch.float32), 1 + 0.1 * rnd(D, dt=torch.float32)
+    tab = rnd((2 * gh - 1) * (2 * gw - 1), H, dt=torch.float32)
+    flops_f = 4.0 * nseq * H * L * L * D
+    qh, kh, vh, qinv, kinv = be.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    o, lse2 = be.attn2_fwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, nseq, L)
+    dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, nseq, L, True)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dqs, dks = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    cases = {
+        "attn2_prep (q, kv -> head-planar)": (lambda: be.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H), 0.0),
+        "attn2_fwd spatial, table bias": (lambda: be.attn2_fwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, nseq, L), flops_f),
+        "attn2_fwd spatial, no bias": (lambda: be.attn2_fwd(qh, kh, vh, None, None, qs, ks, 8.0, nseq, L), flops_f),
+        "attn2_bwd spatial (dq + dkv)": (lambda: be.attn2_bwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, nseq, L, False), 3.5 * flops_f),
+        "attn2_bwd spatial + dbias": (lambda: be.attn2_bwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, nseq, L, True), 4.5 * flops_f),
+        "attn2_unprep": (lambda: be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, 8.0, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks), 0.0),
+    }
+    for name, (fn, fl) in cases.items():
+        us = timeit(fn)
+        out[name] = dict(avg_us=round(us, 1), tflops=round(fl / us / 1e6, 1))
 if what in ("tattn", "all"):
     # temporal attention of the CTViT: 4608 sequences of 24 tokens, 8 heads x 32, no bias
     nseq, H, L, D = 8 * 576, 8, 24, 32
