@@ -8,13 +8,18 @@ gathered-negatives CLIP loss, backward, gradient all-reduce (N > 1), global grad
 already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- the GEMM shape with the largest total time in the timed steps (round 1: the weight-gradient GEMM M=1365 N=512
-                  K=110592 on gemm_tn_kernel): algorithmic FLOPs per launch / mean launch duration measured with events on the
-                  launch stream around every launch, vs the 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch of the
-                  same kernel and shape from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), top5 = the
-                  other shapes.
-  cpu_baseline -- the CPU oracle (a restatement of the reference, kind "port") timed on the host cores on a bounded sample
-                  (one volume of the same configuration, one training step).
+  roofline     -- the GEMM shape with the largest total time in the timed steps: algorithmic FLOPs per launch / mean launch duration
+                  measured with events on the launch stream around every launch, vs the 2.5 PFLOP/s dense bf16 peak; top5 = the other
+                  shapes.  `traffic` = HBM bytes per launch of that kernel at that shape MEASURED in this run: after the timed region
+                  rank 0 re-runs the one GEMM under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, FETCH_SIZE x2
+                  for gfx950 as MI355X_MICROARCH.md prescribes); null with a reason when rocprofv3 is unavailable (--no-pmc skips it).
+  attn_block   -- the second half of BASELINE.json's metric ("CTViT MFMA util %"): one spatial attention block (LayerNorm, to_q / to_kv
+                  projections, cosine attention with position bias, to_out + residual; attention.py:127-181) at the bench batch, timed
+                  with event pairs around the block, forward and forward+backward; FLOPs per SURVEY.md 8(d) (22.65 GF / volume / layer
+                  forward, backward = 2x), utilisation against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline -- the CPU oracle (a restatement of the reference, kind "port") timed on the host cores on a bounded sample: one
+                  training step on ONE volume at the bench's own depth (same configuration as `value`), and B=2 at the reference scripts'
+                  4+4 layers when the time bound allows.
 """
 import argparse
 import json
@@ -93,45 +98,42 @@ def algorithmic_flops_per_volume(args, T):
 
 
 def cpu_baseline(args, T):
-    """Time the CPU oracle (oracle/ctclip_oracle.py, a restatement of the reference path) on ONE volume of the same configuration."""
+    """Time the CPU oracle (oracle/ctclip_oracle.py, a restatement of the reference path): one training step on `cpu_batch` volumes
+    with `cpu_spatial_depth`+`cpu_temporal_depth` layers.  Prints one CPU_BASELINE line per finished sample (the parent keeps the
+    last complete ones if the wall-clock bound cuts a later sample short)."""
     from oracle import ctclip_oracle as O
     from transformers import BertConfig, BertModel
     import ct_clip_amd
-    torch.manual_seed(0)
     cores = min(args.cpu_threads, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
     torch.set_num_threads(cores)     # more threads than ~32 only adds synchronisation overhead to torch's CPU kernels
-    sd_small = args.cpu_spatial_depth
-    enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
-                            temporal_patch_size=FULL["tpatch"], spatial_depth=sd_small, temporal_depth=args.cpu_temporal_depth,
-                            dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=torch.float32)
-    bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
     hw = args.image // FULL["patch"]
-    sd = {"temperature": torch.tensor(1.0)}
-    sd.update({"visual_transformer." + k: v for k, v in enc.state_dict().items()})
-    sd.update({"text_transformer." + k: v for k, v in bert.state_dict().items()})
-    sd["to_text_latent.weight"] = torch.randn(FULL["dim_latent"], 768) * 0.02
-    sd["to_visual_latent.weight"] = torch.randn(FULL["dim_latent"], hw * hw * FULL["dim"]) * 0.002
-    cfg = O.OracleConfig(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
-                         temporal_patch_size=FULL["tpatch"], spatial_depth=sd_small, temporal_depth=args.cpu_temporal_depth,
-                         dim_head=FULL["dim_head"], heads=FULL["heads"], bert_layers=12, bert_heads=12, dim_latent=FULL["dim_latent"])
-    g = torch.Generator().manual_seed(1234)
-    nb = args.cpu_batch
-    video = torch.rand(nb, 1, args.frames, args.image, args.image, generator=g) * 2 - 1
-    ids, mask = synth_text(nb, T, g, "cpu")
-    t0 = time.time()
-    loss, *_ = O.train_step_reference(sd, cfg, ids, mask, video)
-    dt = time.time() - t0
-    full_flops, _ = algorithmic_flops_per_volume(args, T)
-    small = argparse.Namespace(**vars(args))
-    small.spatial_depth, small.temporal_depth = sd_small, args.cpu_temporal_depth
-    small_flops, _ = algorithmic_flops_per_volume(small, T)
-    return dict(value=round(nb / dt, 5), unit="volumes/s", cores=cores, kind="port",
-                sample=f"oracle/ctclip_oracle.train_step_reference (fwd+bwd+grad-clip+Adam, f32, torch CPU kernels, {cores} threads) on {nb} "
-                       f"volume(s) {args.image}x{args.image}x{args.frames} with {sd_small}+{args.cpu_temporal_depth} transformer layers "
-                       f"(the reference's own depth, run_train.py:17-27), T={T}: {dt:.1f} s wall",
-                value_scaled_to_bench_config=round(nb / dt * small_flops / full_flops, 5),
-                scaling_note=f"the GPU workload has {args.spatial_depth}+{args.temporal_depth} layers: {full_flops / small_flops:.2f}x the algorithmic "
-                             "FLOPs per volume; value_scaled_to_bench_config divides the measured rate by that ratio")
+
+    def sample(nb, sdepth, tdepth):
+        torch.manual_seed(0)
+        enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                                temporal_patch_size=FULL["tpatch"], spatial_depth=sdepth, temporal_depth=tdepth,
+                                dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=torch.float32)
+        bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+        sd = {"temperature": torch.tensor(1.0)}
+        sd.update({"visual_transformer." + k: v for k, v in enc.state_dict().items()})
+        sd.update({"text_transformer." + k: v for k, v in bert.state_dict().items()})
+        sd["to_text_latent.weight"] = torch.randn(FULL["dim_latent"], 768) * 0.02
+        sd["to_visual_latent.weight"] = torch.randn(FULL["dim_latent"], hw * hw * FULL["dim"]) * 0.002
+        cfg = O.OracleConfig(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                             temporal_patch_size=FULL["tpatch"], spatial_depth=sdepth, temporal_depth=tdepth,
+                             dim_head=FULL["dim_head"], heads=FULL["heads"], bert_layers=12, bert_heads=12, dim_latent=FULL["dim_latent"])
+        g = torch.Generator().manual_seed(1234)
+        video = torch.rand(nb, 1, args.frames, args.image, args.image, generator=g) * 2 - 1
+        ids, mask = synth_text(nb, T, g, "cpu")
+        t0 = time.time()
+        O.train_step_reference(sd, cfg, ids, mask, video)
+        dt = time.time() - t0
+        return dict(value=round(nb / dt, 5), unit="volumes/s", cores=cores, kind="port", batch=nb, layers=f"{sdepth}+{tdepth}", seconds=round(dt, 1),
+                    sample=f"oracle/ctclip_oracle.train_step_reference (fwd+bwd+grad-clip+Adam, f32, torch CPU kernels, {cores} threads) on {nb} "
+                           f"volume(s) {args.image}x{args.image}x{args.frames}, {sdepth}+{tdepth} transformer layers, T={T}: {dt:.1f} s wall")
+    print("CPU_BASELINE " + json.dumps(dict(tag="bench_depth", **sample(args.cpu_batch, args.spatial_depth, args.temporal_depth))), flush=True)
+    if (args.cpu_spatial_depth, args.cpu_temporal_depth) != (args.spatial_depth, args.temporal_depth) or args.cpu_batch != 2:
+        print("CPU_BASELINE " + json.dumps(dict(tag="reference_depth_b2", **sample(2, args.cpu_spatial_depth, args.cpu_temporal_depth))), flush=True)
 
 
 def run_cpu_baseline_bounded(args, sdepth, tdepth):
@@ -145,24 +147,158 @@ def run_cpu_baseline_bounded(args, sdepth, tdepth):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     t0 = time.time()
+    out, err, timed_out = "", "", False
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
-        for line in res.stdout.splitlines():
-            if line.startswith("CPU_BASELINE "):
-                return json.loads(line[len("CPU_BASELINE "):])
-        return dict(value=None, unit="volumes/s", kind="port", sample="CPU baseline failed: " + res.stderr[-300:])
-    except subprocess.TimeoutExpired:
-        dt = time.time() - t0
+        out, err = res.stdout, res.stderr
+    except subprocess.TimeoutExpired as e:
+        timed_out = True
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    samples = {}
+    for line in out.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            rec = json.loads(line[len("CPU_BASELINE "):])
+            samples[rec.pop("tag")] = rec
+    if "bench_depth" in samples:
+        res = samples["bench_depth"]
+        if "reference_depth_b2" in samples:
+            res["reference_depth_b2"] = samples["reference_depth_b2"]
+        elif timed_out:
+            res["reference_depth_b2"] = f"not finished within the {args.cpu_timeout:.0f} s bound"
+        return res
+    dt = time.time() - t0
+    if timed_out:
         return dict(value=None, unit="volumes/s", kind="port", cores=args.cpu_threads, upper_bound=round(args.cpu_batch / dt, 5),
-                    sample=f"oracle train step on {args.cpu_batch} volume(s), {args.cpu_spatial_depth}+{args.cpu_temporal_depth} layers did not finish "
-                           f"within the {args.cpu_timeout:.0f} s bound: rate < upper_bound")
+                    sample=f"oracle train step on {args.cpu_batch} volume(s), {sdepth}+{tdepth} layers did not finish within the {args.cpu_timeout:.0f} s "
+                           "bound: rate < upper_bound")
+    return dict(value=None, unit="volumes/s", kind="port", sample="CPU baseline failed: " + err[-300:])
+
+
+# ----------------------------------------------------------------------------------------------------------------- PMC companion
+def gemm_probe(spec, iters=6):
+    """Child mode: run ONE GEMM shape through the C ABI a few times (under rocprofv3 --pmc).  spec = 'NT|NN|TN M N K'."""
+    from ct_clip_amd import backend
+    be = backend.get()
+    layout, M, N, K = spec.split()
+    M, N, K = int(M), int(N), int(K)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *sh: (torch.rand(*sh, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+    if layout == "NT":
+        a, b = rnd(M, K), rnd(N, K)
+        fn = lambda: be.gemm(a, b)
+    elif layout == "NN":
+        a, b = rnd(M, K), rnd(K, N)
+        fn = lambda: be.gemm(a, b, a_kc=True, b_kc=False)
+    else:
+        a, b = rnd(K, (M + 7) // 8 * 8), rnd(K, N)
+        out = torch.zeros(M, N, device="cuda")
+        fn = lambda: be.gemm(a[:, :M], b, a_kc=False, b_kc=False, out=out, accumulate=True, split_k=0, M=M, N=N, K=K)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+
+
+def measure_traffic(kernel_label, timeout=150.0):
+    """HBM bytes per launch of the dominant GEMM, from two rocprofv3 --pmc passes over `bench.py --gemm-probe` (rank 0, N = 1)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    m = __import__("re").match(r"gemm_kernel<\w+,(\w+)> M=(\d+) N=(\d+) K=(\d+)", kernel_label)
+    if not m:
+        return None, "dominant kernel is not a GEMM"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    spec = " ".join(m.groups())
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    per = {}
+    root = tempfile.mkdtemp(prefix="ctclip_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(root, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gemm-probe", spec]
+            try:
+                subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout:.0f} s"
+            vals = {}
+            for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if r.get("Counter_Name") == counter and r["Kernel_Name"].split("(")[0].find("gemm") >= 0 and "reduce" not in r["Kernel_Name"]:
+                        vals.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for a gemm kernel in the rocprofv3 output"
+            name = max(vals, key=lambda k: sum(vals[k]))          # the GEMM kernel proper (not its split-K reduce)
+            per[counter] = (name, sum(vals[name]) / len(vals[name]))
+        fetch = per["FETCH_SIZE"][1] * 1024 * 2      # KiB units; gfx950 reports half of the bytes of wide coalesced reads
+        write = per["WRITE_SIZE"][1] * 1024
+        return dict(bytes=fetch + write, fetch_bytes=fetch, write_bytes=write, device_kernel=per["FETCH_SIZE"][0].replace("void ", ""),
+                    source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --gemm-probe` in this run; "
+                           "FETCH_SIZE x2 (gfx950), units of 1024 B"), None
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------- attention block
+def attention_block_util(args, device, dtype, iters=10):
+    """One spatial attention block of the CTViT at the bench batch: x -> x + to_out(attn(to_q(LN(x)), to_kv(x))) with the position
+    bias (attention.py:127-181, 322-325), timed with event pairs around the block on the launch stream."""
+    import ct_clip_amd
+    from ct_clip_amd import functional as Fn
+    from ct_clip_amd.ctvit import Attention, ContinuousPositionBias
+    torch.manual_seed(0)
+    hw = args.image // FULL["patch"]
+    t = args.frames // FULL["tpatch"]
+    nseq, L = args.batch * t, hw * hw
+    attn = Attention(dim=FULL["dim"], dim_head=FULL["dim_head"], heads=FULL["heads"]).to(device)
+    cpb = ContinuousPositionBias(dim=FULL["dim"], heads=FULL["heads"]).to(device)
+    gd = torch.Generator(device=device).manual_seed(7)
+    x = (torch.randn(nseq * L, FULL["dim"], device=device, generator=gd)).to(dtype).requires_grad_(True)
+    dy = (torch.randn(nseq * L, FULL["dim"], device=device, generator=gd) * 0.1).to(dtype)
+
+    def block():
+        tab = cpb(hw, hw)
+        xn, x_kv, xr = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)
+        q = Fn.linear(xn, attn.to_q.weight)
+        kv = Fn.linear(x_kv, attn.to_kv.weight)
+        o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, tab, nseq, L, attn.heads, attn.dim_head, float(attn.scale), (hw, hw))
+        return Fn.linear(o, attn.to_out.weight, residual=xr)
+    for _ in range(2):
+        block().backward(dy)
+        x.grad = None
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+    for e0, e1, e2 in ev:
+        e0.record()
+        y = block()
+        e1.record()
+        y.backward(dy)
+        e2.record()
+        x.grad = None
+    torch.cuda.synchronize()
+    fwd = sum(a.elapsed_time(b) for a, b, _ in ev) / iters * 1e3
+    tot = sum(a.elapsed_time(c) for a, _, c in ev) / iters * 1e3
+    inner = FULL["heads"] * FULL["dim_head"]
+    n = nseq * L
+    flops_fwd = 2.0 * n * FULL["dim"] * 3 * inner + 2.0 * n * inner * FULL["dim"] + 4.0 * n * L * inner     # 22.65 GF / volume
+    peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+    return dict(what="CTViT spatial attention block (LN + to_q/to_kv + cosine attention with position bias + to_out + residual), "
+                     f"{nseq} sequences x {L} tokens, 8 heads x 32", fwd_us=round(fwd, 1), fwd_bwd_us=round(tot, 1),
+                gflop_fwd=round(flops_fwd / 1e9, 1), gflop_fwd_bwd=round(3 * flops_fwd / 1e9, 1),
+                tflops_fwd=round(flops_fwd / fwd / 1e6, 1), tflops_fwd_bwd=round(3 * flops_fwd / tot / 1e6, 1),
+                mfma_util_fwd=round(flops_fwd / fwd / 1e6 / peak, 4), mfma_util_fwd_bwd=round(3 * flops_fwd / tot / 1e6 / peak, 4),
+                peak_tflops=peak, note="event pairs on the launch stream; includes the position-bias MLP on its 2209 distinct offsets and every "
+                                       "layout / normalisation kernel between the projections and the attention core")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="volumes per GPU")
     ap.add_argument("--text-len", type=int, default=128)
     ap.add_argument("--spatial-depth", type=int, default=12, help="12+12 = the '24 layers' BASELINE.json names; reference scripts use 4+4")
@@ -177,12 +313,18 @@ def main():
     ap.add_argument("--cpu-temporal-depth", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--cpu-timeout", type=float, default=150.0, help="wall-clock bound (s) for the CPU baseline subprocess")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc companion passes that measure roofline.traffic")
+    ap.add_argument("--no-attn-block", action="store_true", help="skip the attention-block MFMA utilisation measurement")
+    ap.add_argument("--gemm-probe", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help="additionally time the reference-true 4+4-layer model")
     args = ap.parse_args()
 
-    if args.cpu_baseline_worker:      # child process: time the oracle and print its JSON
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(args, args.text_len)), flush=True)
+    if args.cpu_baseline_worker:      # child process: time the oracle and print its JSON lines
+        cpu_baseline(args, args.text_len)
+        return
+    if args.gemm_probe:               # child process under rocprofv3 --pmc
+        gemm_probe(args.gemm_probe)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,7 +397,7 @@ def main():
     train_flops, _ = algorithmic_flops_per_volume(args, args.text_len)
 
     out = {
-        "metric": "CT volumes/sec/node (480x480x240, bs=8/GPU), full training step",
+        "metric": "CT volumes/sec/node (480x480x240, bs=8/GPU), full training step + CTViT MFMA util % (attn_block)",
         "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (uniform [-1,1] volumes generated on device, random token ids; random-init weights)",
@@ -271,19 +413,23 @@ def main():
         "peak_mem_gib": round(peak_mem, 1),
     }
     if timing:
-        # HBM traffic of the same kernel at the same shape from the committed PMC passes (collected off-line: --pmc cannot be combined
-        # with the timed run); None when that shape was not profiled
-        try:
-            table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-            m = __import__("re").match(r"gemm_kernel<\w+,(\w+)> (M=\d+ N=\d+ K=\d+)", timing["kernel"])
-            ent = table.get(f"{m.group(1)} {m.group(2)}") if m else None
-            if ent:
-                timing["traffic"] = ent["fetch_bytes"] + ent["write_bytes"]
-                timing["traffic_source"] = "profiles/r01_pmc_gemm_nt_tn.md (FETCH_SIZE x2-corrected + WRITE_SIZE, bytes per launch)"
-                timing["device_kernel"] = ent["kernel"]
-        except Exception:
-            pass
+        timing["traffic"] = None
+        if rank == 0 and world == 1 and not args.no_pmc:
+            tr, why = measure_traffic(timing["kernel"])
+            if tr is not None:
+                timing["traffic"] = tr.pop("bytes")
+                timing["traffic_detail"] = tr
+                timing["traffic_over_algorithmic"] = round(timing["traffic"] / timing["algorithmic_bytes_per_launch"], 3)
+            else:
+                timing["traffic_note"] = why
+        elif world > 1:
+            timing["traffic_note"] = "measured at N = 1 only"
         out["roofline"] = timing
+    if not args.no_attn_block and rank == 0:
+        try:
+            out["attn_block"] = attention_block_util(args, device, dtype)
+        except Exception as e:      # never lose the headline number to the auxiliary measurement
+            out["attn_block"] = {"error": repr(e)[:300]}
     if args.also_reference_depth:
         dt2, loss2, _, _ = run_config(4, 4, args.steps, max(1, args.warmup), False)
         out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps / dt2, 3), "unit": "volumes/s",

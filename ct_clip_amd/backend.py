@@ -500,6 +500,31 @@ class HipBackend:
         _lib.check(self.lib.ctclip_scale_by_scalar(_p(x), _p(scalar), x.numel(), _stream()), "ctclip_scale_by_scalar")
         return x
 
+    # ------------------------------------------------------------------ fine-tuning heads (csrc/finetune.hip)
+    def relu_dropout(self, x, dy, p, seed, stream_id):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
+        out = torch.empty_like(x)
+        _lib.check(self.lib.ctclip_relu_dropout(_p(x), _p(dy), _p(out), x.numel(), float(p), int(seed), int(stream_id), _stream()),
+                   "ctclip_relu_dropout")
+        return out
+
+    def bce_logits(self, logits, targets, pos_weight):
+        Bn, C = logits.shape
+        assert logits.dtype == torch.float32 and targets.dtype == torch.float32
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        _lib.check(self.lib.ctclip_bce_logits(_p(logits), _p(targets), _p(pos_weight), _p(loss), _p(dlogits), Bn, C, _stream()),
+                   "ctclip_bce_logits")
+        return loss, dlogits
+
+    def pair_softmax_mse(self, sims):
+        n = sims.shape[0]
+        assert sims.dtype == torch.float32 and sims.shape[1] == 2
+        loss = torch.empty(1, dtype=torch.float32, device=sims.device)
+        dsims = torch.empty_like(sims)
+        _lib.check(self.lib.ctclip_pair_softmax_mse(_p(sims), _p(loss), _p(dsims), n, _stream()), "ctclip_pair_softmax_mse")
+        return loss, dsims
+
     # ------------------------------------------------------------------ optimiser
     def grad_norm_clip(self, g, max_norm, extra_sq=None):
         out = torch.empty(2, dtype=torch.float32, device=g.device)

@@ -26,6 +26,7 @@
 // 16-lane service group of the b128 fragment reads then touches 16 distinct 16-B slots, and a transposing read (four rows x 64 B
 // per half-wave) covers one whole 256-B bank row (tests/test_layouts_cpu.py restates and checks this arithmetic).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -95,9 +96,11 @@ __device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
 }
 __device__ __forceinline__ Frag lds_cols(const char* tile, const TrOff& tr) {
   const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
-  const u32x2 a0 = tr_read(base + tr.o[0]), a1 = tr_read(base + tr.o[1]);
-  const u32x2 b0 = tr_read(base + 1024 + tr.o[0]), b1 = tr_read(base + 1024 + tr.o[1]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  u32x2 a0 = tr_read(base + tr.o[0]), a1 = tr_read(base + tr.o[1]);
+  u32x2 b0 = tr_read(base + 1024 + tr.o[0]), b1 = tr_read(base + 1024 + tr.o[1]);
+  // the compiler does not know that the asm reads above are asynchronous: the wait must CARRY the registers ("+v"), otherwise the
+  // consumer (an MFMA) may be scheduled in front of it -- first hardware run: forward row sums right, outputs garbage
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
   Frag f;
   f.v[0] = __builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
   f.v[1] = __builtin_bit_cast(bf16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
@@ -124,16 +127,20 @@ struct Params {
 
 // ---- per-workgroup preamble: stage the bias table of head h (log2 domain) and the token -> offset-class index, and derive the
 // logit bound.  All threads of the workgroup must call it.  Returns M2 (log2-domain bound folded into the staged table when safe).
-struct Rel {
-  float tab[MAXCLS];
-  __attribute__((aligned(16))) uint16_t u[MAXL];
+template <int NC, int NL>
+struct RelT {
+  float tab[NC];
+  __attribute__((aligned(16))) uint16_t u[NL];
   float red[2][16];
   float m2; int safe;
 };
+using Rel = RelT<MAXCLS, MAXL>;
+constexpr int SLAB_MAXCLS = 2304, SLAB_MAXL = 576;          // 24 x 24 tokens: 47^2 = 2209 classes
+using RelS = RelT<SLAB_MAXCLS, SLAB_MAXL>;
 // REVERSED: entry i holds class ncls - 1 - i, so that the descending classes of a key run are ASCENDING addresses and land in
 // consecutive registers without moves (the kernels whose tile rows are keys); the key pass keeps the natural order.
-template <bool REVERSED>
-__device__ __forceinline__ void stage_rel(Rel& rel, const Params& p, int h) {
+template <bool REVERSED, class R>
+__device__ __forceinline__ void stage_rel(R& rel, const Params& p, int h) {
   const int ncls = p.tab ? (2 * p.gh - 1) * (2 * p.gw - 1) : 0;
   const int nth = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
   float mx = -INFINITY, mn = INFINITY;
@@ -171,8 +178,8 @@ __device__ __forceinline__ void stage_rel(Rel& rel, const Params& p, int h) {
 
 // offset-class gather of one 32 x 32 tile as the MFMA accumulator input.  Rows (registers) are KEYS, lane = query: class of key
 // run (8 consecutive tokens of one image row; needs gw % 8 == 0) descends by one per key.  Rows are QUERIES, lane = key: ascends.
-template <bool ROWS_ARE_KEYS, bool TAB>
-__device__ __forceinline__ f32x16 bias_tile(const Rel& rel, const Params& p, int ucol, int row_base, int half) {
+template <bool ROWS_ARE_KEYS, bool TAB, class R>
+__device__ __forceinline__ f32x16 bias_tile(const R& rel, const Params& p, int ucol, int row_base, int half) {
   f32x16 cb;
   if (!TAB) {
     const float t = rel.tab[0];
@@ -317,6 +324,190 @@ __global__ __launch_bounds__(NW * 64) void attn2_fwd_kernel(Params p) {
   if (!ok) return;                                                       // workgroup-uniform
   if (rel.safe) fwd_body<NW, true, TAB>(p, rel, ring, seq, h, grp);
   else fwd_body<NW, false, TAB>(p, rel, ring, seq, h, grp);
+}
+
+// ================================================================================================================== forward, slab-resident
+// PERSISTENT variant for sequences whose K^ and V slabs (L x 64 B each) fit in LDS twice (L <= 576): one workgroup of nine waves per
+// CU walks a contiguous run of (sequence, head) items.  The whole K^ / V slab of the current item sits in LDS, so the tile loop has NO
+// barrier: waves drift apart and one wave's softmax overlaps another's MFMAs (the ring kernels above synchronise every 32 keys, which
+// keeps all waves of a SIMD in the same phase: first hardware run 196 us against 40 us of VALU + MFMA issue time).  While item k is
+// computed, every thread copies its share of item k+1's slabs into the other LDS buffer (one 16-byte chunk per thread and step);
+// one barrier per item.  A wave owns two query blocks (w and w + 9): two independent MFMA / softmax chains that share the K^ and V
+// fragment reads and give the in-order issue something to overlap.
+constexpr int SLAB_WAVES = 9;
+// dynamic LDS: RelS (padded to 256 B) followed by slabs[buffer][K^ | V][L * 64]
+__host__ __device__ __forceinline__ int slab_bytes(int L) { return L * 64; }
+constexpr int SLAB_REL_BYTES = (int)((sizeof(RelS) + 255) / 256 * 256);
+
+template <bool SAFE, bool TAB>
+__device__ __forceinline__ void fwd_slab_item(const Params& p, RelS& rel, const char* kslab, const char* vslab, char* next_k, const char* gnext,
+                                              int64_t vdelta, int nchunk_next, int seq, int h, int wave, int lane, Frag (&qf)[2],
+                                              const bf16_t* qnext) {
+  const int L = p.L, nkb = L / 32;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const TrOff tr = tr_offsets(lane);
+  int qi[2]; bool act[2]; int ucol[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    const int qb_raw = wave + ch * SLAB_WAVES;
+    act[ch] = qb_raw < nkb;
+    qi[ch] = (act[ch] ? qb_raw : nkb - 1) * 32 + c;
+    ucol[ch] = rel.u[qi[ch]];
+  }
+  drain_vmem();       // the query fragments (loaded at the end of the previous item) have landed: see drain_vmem
+  float ls[2][4], m[2] = {-INFINITY, -INFINITY};
+  f32x16 oacc[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ls[ch][e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[ch][r] = 0.f;
+  }
+  const int nth = SLAB_WAVES * 64;
+  for (int t = 0; t < nkb; ++t) {
+    // copy of the next item's slabs: chunk t * nth + tid (16 B), issued now, written to the other buffer at the end of the step
+    const int chunk = t * nth + (int)threadIdx.x;
+    const bool ld = chunk < nchunk_next;
+    const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per;      // (tensor, 16-byte piece of its slab)
+    u32x4 st{};
+    if (ld) st = *reinterpret_cast<const u32x4*>(gnext + (tens ? vdelta : 0) + (int64_t)rc * 16);
+    const char* ktile = kslab + t * TILE;
+    const char* vtile = vslab + t * TILE;
+    const Frag kf = lds_rows(ktile, ar, half);
+    f32x16 s[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) s[ch] = bias_tile<true, TAB>(rel, p, ucol[ch], t * 32, half);
+    // the two chains' dependent MFMA pairs interleaved: a0 b0 a1 b1
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) s[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[0], qf[ch].v[0], s[ch], 0, 0, 0);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) s[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[1], qf[ch].v[1], s[ch], 0, 0, 0);
+    const Frag vf = lds_cols(vtile, tr);
+    Frag pf[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      float pr[16];
+      if (SAFE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[ch][r]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) { ls[ch][0] += pr[r]; ls[ch][1] += pr[r + 1]; ls[ch][2] += pr[r + 2]; ls[ch][3] += pr[r + 3]; }
+      } else {
+        float mx = s[ch][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[ch][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m[ch], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[ch] - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(s[ch][r] - mnew); ps += pr[r]; }
+        ls[ch][0] = ls[ch][0] * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[ch][r] *= alpha;
+        m[ch] = mnew;
+      }
+      pf[ch] = pack(pr);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) oacc[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[0], pf[ch].v[0], oacc[ch], 0, 0, 0);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) oacc[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[1], pf[ch].v[1], oacc[ch], 0, 0, 0);
+    if (ld) {
+      // piece -> (row, position) -> swizzled place inside its 32-row tile of the other buffer
+      const int row = rc >> 2, pc = rc & 3;
+      *reinterpret_cast<u32x4*>(next_k + tens * slab_bytes(L) + (row >> 5) * TILE + swz(row & 31, pc)) = st;
+    }
+  }
+  if (qnext) {        // query rows of the NEXT item: in flight across the epilogue and the item barrier
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) qf[ch] = global_row(qnext + (int64_t)qi[ch] * D, half);
+  }
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    float lsum = (ls[ch][0] + ls[ch][1]) + (ls[ch][2] + ls[ch][3]);
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    if (act[ch]) {
+      const float inv = 1.f / l;
+      bf16_t* O = p.out + ((int64_t)seq * L + qi[ch]) * p.ldo + h * D;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = oacc[ch][8 * g + e] * inv;
+        store8(O + 16 * g + 8 * half, o8);
+      }
+      if (half == 0 && p.lse2) p.lse2[(int64_t)h * p.M + (int64_t)seq * L + qi[ch]] = (SAFE ? rel.m2 : m[ch]) + __log2f(l);
+    }
+  }
+}
+
+template <bool TAB>
+__global__ __launch_bounds__(SLAB_WAVES * 64) void attn2_fwd_slab_kernel(Params p, int items_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  RelS& rel = *reinterpret_cast<RelS*>(dyn);
+  char* slabs = dyn + SLAB_REL_BYTES;
+  const int L = p.L, sb = slab_bytes(L);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nitems = p.nseq * p.H;
+  const int first = blockIdx.x * items_per_wg;
+  const int last = min(first + items_per_wg, nitems);
+  if (first >= last) return;
+  // item i = (head, sequence) with the head as the SLOW index: a workgroup's run of items stays on one head for as long as possible
+  auto item = [&](int i, int& seq, int& h) { h = i / p.nseq; seq = i % p.nseq; };
+  auto gsrc = [&](int seq, int h) { return reinterpret_cast<const char*>(p.kh + ((int64_t)h * p.M + (int64_t)seq * L) * D); };
+  const int64_t vdelta = reinterpret_cast<const char*>(p.vh) - reinterpret_cast<const char*>(p.kh);
+  const int nchunk = 2 * L * 4;
+  int seq, h;
+  item(first, seq, h);
+  // prologue: slabs of the first item
+  {
+    const char* gk = gsrc(seq, h);
+    constexpr int NTH = SLAB_WAVES * 64, MAXPER = (2 * SLAB_MAXL * 4 + NTH - 1) / NTH;     // <= 8 pieces per thread: all loads first
+    u32x4 v[MAXPER];
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      const int chunk = k * NTH + (int)threadIdx.x;
+      const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per;
+      v[k] = u32x4{0, 0, 0, 0};
+      if (chunk < nchunk) v[k] = *reinterpret_cast<const u32x4*>(gk + (tens ? vdelta : 0) + (int64_t)rc * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      const int chunk = k * NTH + (int)threadIdx.x;
+      const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per, row = rc >> 2, pc = rc & 3;
+      if (chunk < nchunk) *reinterpret_cast<u32x4*>(slabs + tens * sb + (row >> 5) * TILE + swz(row & 31, pc)) = v[k];
+    }
+  }
+  Frag qf[2];
+  {
+    const int nkb = L / 32, c = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int qb_raw = wave + ch * SLAB_WAVES;
+      const int qi = (qb_raw < nkb ? qb_raw : nkb - 1) * 32 + c;
+      qf[ch] = global_row(p.qh + ((int64_t)h * p.M + (int64_t)seq * L + qi) * D, half);
+    }
+  }
+  int staged_h = -1;
+  for (int i = first; i < last; ++i) {
+    item(i, seq, h);
+    // every wave is done with the previous item (its slab buffer becomes the copy target, its table may be replaced) and the
+    // copies of this item's slabs are complete
+    __syncthreads();
+    if (h != staged_h) { stage_rel<true>(rel, p, h); staged_h = h; }       // (ends with a barrier; workgroup-uniform)
+    const int buf = (i - first) & 1;
+    char* cur = slabs + buf * 2 * sb;
+    char* nxt = slabs + (buf ^ 1) * 2 * sb;
+    int nseq2 = seq, nh = h;
+    const bool more = i + 1 < last;
+    if (more) item(i + 1, nseq2, nh);
+    const char* gnext = gsrc(nseq2, nh);          // K^ slab of the next item; its V slab is `vdelta` bytes further
+    const bf16_t* qnext = more ? p.qh + ((int64_t)nh * p.M + (int64_t)nseq2 * L) * D : nullptr;
+    if (rel.safe) fwd_slab_item<true, TAB>(p, rel, cur, cur + sb, nxt, gnext, vdelta, more ? nchunk : 0, seq, h, wave, lane, qf, qnext);
+    else fwd_slab_item<false, TAB>(p, rel, cur, cur + sb, nxt, gnext, vdelta, more ? nchunk : 0, seq, h, wave, lane, qf, qnext);
+  }
 }
 
 // ================================================================================================================== dQ pass
@@ -721,35 +912,37 @@ __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restri
                                                           float c, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t lddq,
                                                           int64_t lddk, int64_t lddv, float* __restrict__ part, int64_t M, int H) {
   __shared__ float red[2][8][32];
-  const int j = threadIdx.x & 3;
+  const int j = threadIdx.x & 3, rl = threadIdx.x >> 2;      // 16-byte chunk of the head row, row of the 64-row block
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float rqs[8], rks[8], accq[8], acck[8];
+  float qsc[8], ksc[8], rqs[8], rks[8], accq[8], acck[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float qs = q_scale[8 * j + e] * c, ks = k_scale[8 * j + e];
+    qsc[e] = q_scale[8 * j + e]; ksc[e] = k_scale[8 * j + e];
+    const float qs = qsc[e] * c, ks = ksc[e];
     rqs[e] = fabsf(qs) > 1e-30f ? 1.f / qs : 0.f;      // u = x~ / (scale c); a scale of exactly zero has no recoverable direction
     rks[e] = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
     accq[e] = 0.f; acck[e] = 0.f;
   }
-  const int64_t total = M * H * 4;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t - threadIdx.x + 0 < total; t += (int64_t)gridDim.x * 256) {
-    const bool ok = t < total;
-    const int64_t tt = ok ? t : total - 1;
-    const int64_t mh = tt >> 2;
-    const int h = (int)(mh % H);
-    const int64_t m = mh / H;
-    const int64_t src = ((int64_t)h * M + m) * D + 8 * j;
+  // work item = (head, block of 64 tokens): the five head-planar reads are 4-KB contiguous runs; the row-major stores are 64-byte
+  // pieces (the mirror image of attn_prep_kernel)
+  const int64_t nmb = (M + 63) / 64, nitems = nmb * H;
+  for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int h = (int)(it / nmb);
+    const int64_t m = (it % nmb) * 64 + rl;
+    const bool ok = m < M;
+    const int64_t mm = ok ? m : M - 1;
+    const int64_t src = ((int64_t)h * M + mm) * D + 8 * j;
     float gq[8], xq[8], gk[8], xk[8];
     load8(dqh + src, gq); load8(qh + src, xq);
     load8(dkh + src, gk); load8(kh + src, xk);
     const u32x4 vv = *reinterpret_cast<const u32x4*>(dvh + src);
-    const float iq = qinv[m * H + h], ik = kinv[m * H + h];
+    const float iq = qinv[mm * H + h], ik = kinv[mm * H + h];
     float dotq = 0.f, dotk = 0.f, uq[8], uk[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       uq[e] = xq[e] * rqs[e]; uk[e] = xk[e] * rks[e];
       if (ok) { accq[e] += gq[e] * uq[e]; acck[e] += gk[e] * uk[e]; }
-      gq[e] *= q_scale[8 * j + e]; gk[e] *= k_scale[8 * j + e];
+      gq[e] *= qsc[e]; gk[e] *= ksc[e];
       dotq += uq[e] * gq[e]; dotk += uk[e] * gk[e];
     }
     dotq += __shfl_xor(dotq, 1, 64); dotq += __shfl_xor(dotq, 2, 64);
@@ -805,6 +998,19 @@ int dbias_splits(int nseq, int H, int L) {
   return ns < 1 ? 1 : ns;
 }
 inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
+int num_cus() {
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+  return ncu;
+}
+// the slab-resident kernels need both operand slabs twice in LDS next to the bias table
+bool slab_ok(int L, int gh, int gw, const float* tab) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("CTCLIP_ATTN_SLAB"); use = (e && e[0] == '0') ? 0 : 1; }
+  if (!use || L > SLAB_MAXL || L / 32 > 2 * SLAB_WAVES) return false;
+  if (tab && (2 * gh - 1) * (2 * gw - 1) > SLAB_MAXCLS) return false;
+  return SLAB_REL_BYTES + 4 * slab_bytes(L) <= 160 * 1024;
+}
 
 }  // namespace
 
@@ -837,6 +1043,22 @@ extern "C" int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, 
   p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
   p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = (int64_t)nseq * L; p.c = scale * LOG2E;
   p.out = (bf16_t*)out; p.ldo = ldo; p.lse2 = lse2;
+  if (slab_ok(L, bias_gh, bias_gw, tab)) {
+    // persistent, slab-resident: one workgroup per CU, contiguous runs of (head, sequence) items
+    const int ncu = num_cus(), total = nseq * H;
+    const int ipw = (total + ncu - 1) / ncu;
+    const int nwg = (total + ipw - 1) / ipw;
+    const size_t shm = (size_t)SLAB_REL_BYTES + 4 * (size_t)slab_bytes(L);
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)attn2_fwd_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)attn2_fwd_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { ctclip_set_error("attn2_fwd: cannot raise the LDS limit"); return CTCLIP_EBADARG; }
+      raised = true;
+    }
+    if (tab) hipLaunchKernelGGL(attn2_fwd_slab_kernel<true>, dim3((unsigned)nwg), dim3(SLAB_WAVES * 64), shm, stream, p, ipw);
+    else hipLaunchKernelGGL(attn2_fwd_slab_kernel<false>, dim3((unsigned)nwg), dim3(SLAB_WAVES * 64), shm, stream, p, ipw);
+    return ctclip_check_launch("attn2_fwd (slab)");
+  }
   const int ngroups = (L / 32 + NW_ROWS - 1) / NW_ROWS;
   const int nitems = ngroups * nseq * H;
   const dim3 grid((unsigned)(((nitems + 7) / 8) * 8)), block(NW_ROWS * 64);
@@ -909,7 +1131,7 @@ extern "C" int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void*
                                    int64_t workspace_bytes, hipStream_t stream) {
   if (!dqh || !dkh || !dvh || !qh || !kh || !qinv || !kinv || !q_scale || !k_scale || !dq || !dk || !dv || lddq % 8 || lddk % 8 || lddv % 8) { ctclip_set_error("attn2_unprep: bad args"); return CTCLIP_EBADARG; }
   if (!workspace || workspace_bytes < ctclip_attn2_unprep_workspace()) { ctclip_set_error("attn2_unprep: workspace too small"); return CTCLIP_EWORKSPACE; }
-  int64_t nb = cdiv(M * H * 4, 256);
+  int64_t nb = cdiv(M, 64) * H;
   if (nb > UNPREP_BLOCKS) nb = UNPREP_BLOCKS;
   hipLaunchKernelGGL(attn_unprep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dqh, (const bf16_t*)dkh, (const bf16_t*)dvh,
                      (const bf16_t*)qh, (const bf16_t*)kh, qinv, kinv, q_scale, k_scale, scale * LOG2E, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq,

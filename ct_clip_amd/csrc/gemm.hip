@@ -301,7 +301,7 @@ __global__ void argmax_reduce_kernel(const float* __restrict__ pv, const int32_t
     const float v = pv[row * nparts + i]; const int ix = pi[row * nparts + i];
     if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; }
   }
-  out[row] = bidx;
+  out[row] = bidx == 0x7fffffff ? 0 : bidx;       // a row of NaNs compares false everywhere: keep the index in range for the gather that follows
   if (out_val) out_val[row] = best;
 }
 

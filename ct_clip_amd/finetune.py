@@ -1,0 +1,204 @@
+"""The two fine-tuning loops built on the CT-CLIP towers (BASELINE.json configs[3], configs[4]).
+
+* ClassFine / CT-LiPro -- ``ImageLatentsClassifier`` (scripts/ct_lipro_train.py:17-38): frozen CT-CLIP -> image latents -> ReLU ->
+  Dropout(0.3) -> Linear(512, 18); ``LiProTrainer.train_step`` = BCEWithLogitsLoss(pos_weight) + clip_grad_norm_(1.0) + AdamW with
+  the cosine schedule (ct_lipro_train.py:79-107, src/models/utils.py:15-32); ``predict`` = sigmoid(logits)
+  (ct_lipro_inference.py:44-93).  The reference runs the (unused) text tower on the prompt " " for every batch
+  (ct_lipro_train.py:99-102); here ``skip_text=True`` (default) runs the image tower only -- the logits do not depend on the text.
+* VocabFine -- ``VocabFineTrainer.train_step`` (scripts/ct_vocabfine_train.py:77-123): for each of 3 groups of 6 pathologies, one
+  (present, absent) prompt pair per pathology ordered by the label, similarity of both prompts with the volume (CTCLIP.forward
+  without return_loss, ct_clip.py:805-807), softmax over the pair, MSE against (1, 0), one backward per group, one AdamW step per
+  volume.  Every parameter trains ("Fine-tuning end-to-end", ct_vocabfine_train.py:44-51).
+
+The heads run on HIP kernels (csrc/finetune.hip) behind the same C ABI as the rest of the path.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import backend as _be
+from . import functional as Fn
+from .trainer import FusedAdam
+
+PATHOLOGIES = ['Medical material', 'Arterial wall calcification', 'Cardiomegaly', 'Pericardial effusion',
+               'Coronary artery wall calcification', 'Hiatal hernia', 'Lymphadenopathy', 'Emphysema', 'Atelectasis', 'Lung nodule',
+               'Lung opacity', 'Pulmonary fibrotic sequela', 'Pleural effusion', 'Mosaic attenuation pattern',
+               'Peribronchial thickening', 'Consolidation', 'Bronchiectasis', 'Interlobular septal thickening']
+# ct_lipro_train.py:79-83
+LIPRO_POS_WEIGHT = [9.211362733, 2.384068466, 8.295479204, 32.8629776, 2.992233613, 6.064870808, 3.176470588, 4.187083754,
+                    3.022222222, 1.216071737, 1.677849552, 3.152851834, 7.123261694, 18.16629381, 13.8480647, 6.335045662,
+                    10.81701149, 13.40695067]
+
+
+def cosine_lr(optimizer, base_lrs, warmup_length, steps):
+    """src/models/utils.py:15-32: linear warm-up then half-cosine decay, applied to optimizer.param_groups."""
+    if not isinstance(base_lrs, list):
+        base_lrs = [base_lrs for _ in optimizer.param_groups]
+    assert len(base_lrs) == len(optimizer.param_groups)
+
+    def _lr_adjuster(step):
+        for group, base_lr in zip(optimizer.param_groups, base_lrs):
+            if step < warmup_length:
+                lr = base_lr * (step + 1) / warmup_length
+            else:
+                e, es = step - warmup_length, steps - warmup_length
+                lr = 0.5 * (1 + math.cos(math.pi * e / es)) * base_lr
+            group["lr"] = lr
+    return _lr_adjuster
+
+
+class ReluDropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, stream_id):
+        ctx.save_for_backward(x)
+        ctx.args = (p, seed, stream_id)
+        return _be.get().relu_dropout(x.contiguous(), None, p, seed, stream_id)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, seed, stream_id = ctx.args
+        return _be.get().relu_dropout(x.contiguous(), dy.contiguous(), p, seed, stream_id), None, None, None
+
+
+class BceLogitsFn(Function):
+    """torch.nn.BCEWithLogitsLoss(pos_weight) (mean), forward and gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, pos_weight):
+        loss, dlogits = _be.get().bce_logits(logits.contiguous(), targets.contiguous(), pos_weight)
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss, None, None
+
+
+class PairSoftmaxMseFn(Function):
+    @staticmethod
+    def forward(ctx, sims):
+        loss, dsims = _be.get().pair_softmax_mse(sims.contiguous())
+        ctx.save_for_backward(dsims)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dsims,) = ctx.saved_tensors
+        return dsims * dloss
+
+
+class ImageLatentsClassifier(nn.Module):
+    """scripts/ct_lipro_train.py:17-38, same constructor / forward / save / load and the same state_dict keys
+    (``trained_model.*``, ``classifier.weight``, ``classifier.bias``)."""
+
+    def __init__(self, trained_model, latent_dim, num_classes, dropout_prob=0.3, skip_text=True):
+        super().__init__()
+        self.trained_model = trained_model
+        for param in self.trained_model.parameters():
+            param.requires_grad = False
+        self.dropout = nn.Dropout(dropout_prob)        # container for p (the fused ReLU + dropout kernel does the work)
+        self.relu = nn.ReLU()
+        self.classifier = nn.Linear(latent_dim, num_classes)
+        self.skip_text = skip_text
+
+    def image_latents(self, *args, **kwargs):
+        if self.skip_text:
+            image = args[1] if len(args) > 1 else kwargs["image"]
+            with torch.no_grad():
+                return self.trained_model.encode_image(image)
+        kwargs["return_latents"] = True
+        with torch.no_grad():
+            _, lat, _ = self.trained_model(*args, **kwargs)
+        return lat
+
+    def forward(self, *args, **kwargs):
+        kwargs.pop("return_latents", None)
+        lat = self.image_latents(*args, **kwargs)                                   # (B, latent_dim) f32, l2-normalised
+        p = float(self.dropout.p) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        h = ReluDropoutFn.apply(lat, p, seed, 0)
+        return Fn.linear(h, self.classifier.weight, self.classifier.bias, out_dtype=torch.float32)
+
+    def save(self, file_path):
+        torch.save(self.state_dict(), file_path)
+
+    def load(self, file_path):
+        self.load_state_dict(torch.load(file_path))
+
+
+class LiProTrainer:
+    """One optimisation step of scripts/ct_lipro_train.py:92-107 on device-resident tensors."""
+
+    def __init__(self, classifier, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pos_weight=None, max_grad_norm=1.0):
+        self.model = classifier
+        dev = classifier.classifier.weight.device
+        pw = LIPRO_POS_WEIGHT if pos_weight is None else pos_weight
+        self.pos_weight = torch.tensor(pw, dtype=torch.float32, device=dev)
+        named = [(n, p) for n, p in classifier.named_parameters() if p.requires_grad]      # the 18 x 512 head and its bias
+        self.optim = FusedAdam(named, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, group_wd_params=False)   # torch.optim.AdamW defaults
+        self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
+        self.max_grad_norm = max_grad_norm
+        self.step = 0
+
+    def train_step(self, text_tokens, volumes, labels):
+        self.model.train()
+        dev = self.pos_weight.device
+        logits = self.model(text_tokens, volumes, device=dev)
+        loss = BceLogitsFn.apply(logits, labels.to(device=dev, dtype=torch.float32), self.pos_weight)
+        self.optim.zero_grad()
+        loss.backward()
+        self.optim.step(self.max_grad_norm)
+        self.scheduler(self.step)                       # ct_lipro_train.py:107: the schedule is applied AFTER the step
+        self.step += 1
+        return loss.detach(), logits.detach()
+
+    @torch.no_grad()
+    def predict(self, text_tokens, volumes):
+        """ct_lipro_inference.py:62-66: sigmoid of the logits in eval mode."""
+        self.model.eval()
+        return torch.sigmoid(self.model(text_tokens, volumes, device=self.pos_weight.device))
+
+
+def vocabfine_prompts(pathology, label):
+    """ct_vocabfine_train.py:100-109: the first prompt is the TRUE statement."""
+    if int(label) == 1:
+        return [f"{pathology} is present. ", f"{pathology} is not present. "]
+    return [f"{pathology} is not present. ", f"{pathology} is present. "]
+
+
+class VocabFineTrainer:
+    """scripts/ct_vocabfine_train.py:77-123 for one volume per step.  `tokenize(list_of_two_strings)` must return an object with
+    .input_ids / .attention_mask on the model's device (the reference pads to 512 tokens)."""
+
+    def __init__(self, model, tokenize, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pathologies=None, group_size=6):
+        from .trainer import hot_path_parameters
+        self.model, self.tokenize = model, tokenize
+        self.pathologies = list(pathologies or PATHOLOGIES)
+        self.group_size = group_size
+        self.optim = FusedAdam(hot_path_parameters(model), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, group_wd_params=False)
+        self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
+        self.step = 0
+
+    def train_step(self, volume, labels):
+        """volume: (1, 1, F, H, W); labels: (n_pathologies,) 0/1.  Returns the per-group losses."""
+        model = self.model
+        model.train()
+        dev = model.temperature.device
+        self.scheduler(self.step)                       # ct_vocabfine_train.py:82: the schedule is applied BEFORE the step
+        self.optim.zero_grad()
+        losses = []
+        for k in range(0, len(self.pathologies), self.group_size):
+            sims = []
+            for name, lab in zip(self.pathologies[k:k + self.group_size], labels[k:k + self.group_size]):
+                tokens = self.tokenize(vocabfine_prompts(name, lab))
+                sims.append(model(tokens, volume, device=dev))             # (2,) similarities: true prompt first
+            loss = PairSoftmaxMseFn.apply(torch.stack(sims))
+            loss.backward()                                                 # one backward per group, gradients accumulate
+            losses.append(loss.detach())
+        self.optim.step(None)
+        self.step += 1
+        return losses

@@ -109,6 +109,7 @@ class FusedAdam:
         self.step_count += 1
         clip = be.grad_norm_clip(self.flat_grad, max_grad_norm or 0.0, extra_sq)
         self.last_norm = clip
+        self.lr = self.param_groups[0]["lr"]          # learning-rate schedules write param_groups (finetune.cosine_lr)
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                      self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4)
         Fn.bump_weight_epoch()

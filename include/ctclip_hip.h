@@ -77,6 +77,15 @@ int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, in
 /* backward of the above; dw (C,27) / db (C) ACCUMULATED, may be NULL. */
 int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
+/* TODO: document */
+int ctclip_relu_dropout(const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
+
+/* TODO: document */
+int ctclip_bce_logits(const float* logits, const float* targets, const float* pos_weight, float* loss, float* dlogits, int B, int C, hipStream_t s);
+
+/* TODO: document */
+int ctclip_pair_softmax_mse(const float* sims, float* loss, float* dsims, int n, hipStream_t s);
+
 /* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
 int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 

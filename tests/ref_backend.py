@@ -449,6 +449,32 @@ class RefBackend:
         return x
 
     # ---- optimiser
+    def relu_dropout(self, x, dy, p, seed, stream_id):
+        n4 = x.numel() // 4
+        if p > 0:
+            idx = torch.arange(n4, dtype=torch.int64, device=x.device)
+            w = torch.stack(self.philox(torch.full_like(idx, seed), idx, stream_id), dim=1).reshape(-1)
+            keep = self._mult(w, p).reshape(x.shape)
+        else:
+            keep = torch.ones_like(x)
+        return (torch.relu(x) * keep) if dy is None else (dy * keep * (x > 0))
+
+    def bce_logits(self, logits, targets, pos_weight):
+        lg = logits.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            loss = F.binary_cross_entropy_with_logits(lg, targets, pos_weight=pos_weight)
+            (g,) = torch.autograd.grad(loss, lg)
+        return loss.detach().reshape(1), g
+
+    def pair_softmax_mse(self, sims):
+        s = sims.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            p = torch.softmax(s, dim=1)
+            target = torch.tensor([1.0, 0.0], device=s.device).expand_as(p)
+            loss = F.mse_loss(p.reshape(-1), target.reshape(-1))
+            (g,) = torch.autograd.grad(loss, s)
+        return loss.detach().reshape(1), g
+
     def grad_norm_clip(self, g, max_norm, extra_sq=None):
         sq = (g.double() ** 2).sum()
         if extra_sq is not None:

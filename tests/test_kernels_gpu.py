@@ -462,6 +462,19 @@ def test_attn2_fwd_bwd(hip, ref, nseq, H, gh, gw, gain, with_tab):
     assert torch.equal(dqs, dqs2) and torch.equal(dks, dks2)
 
 
+def test_attn2_fwd_persistent_runs_across_items_and_heads(hip, ref):
+    """The slab-resident forward keeps one workgroup per CU on a run of (head, sequence) items: more items than CUs, and a run
+    that crosses a head boundary (the bias table is re-staged)."""
+    nseq, H, gh, gw = 70, 8, 24, 24
+    L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, 1.0, True, seed=40)
+    HD = H * D
+    qh, kh, vh, _, _ = hip.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    o, lse2 = hip.attn2_fwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, nseq, L)
+    orf, lser = ref.attn2_fwd(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, nseq, L)
+    close(lse2, lser, rtol=1e-4, atol=2e-3)
+    close(o, orf, rtol=2e-2, atol=2e-2)
+
+
 def test_attn2_matches_first_generation_operator(hip):
     """End to end through the autograd layer: the head-planar path and the round-1 path (separate qk-norm / transposes / attention)
     are the same operator (attention.py:145-178) -- outputs and all five gradients."""
