@@ -25,204 +25,11 @@
 // double-buffered LDS ring.  LDS rows are 64 B; the four 16-byte chunks of row r sit at position chunk ^ ((r >> 2) & 3): every
 // 16-lane service group of the b128 fragment reads then touches 16 distinct 16-B slots, and a transposing read (four rows x 64 B
 // per half-wave) covers one whole 256-B bank row (tests/test_layouts_cpu.py restates and checks this arithmetic).
-#include "common.h"
-#include <stdlib.h>
+#include "attn2_common.h"
 
 namespace {
 
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-constexpr int D = 32;                       // head dim
-constexpr int TILE = 32 * 64;               // bytes of one 32-row operand tile
-constexpr int MAXCLS = 4096, MAXL = 1024;
-constexpr float SAFE_SPAN = 100.f;          // log2 units: exp2(-100) ~ 8e-31 is a normal f32 / bf16 number
-
-__device__ __forceinline__ int pi32(int c) { return (c & 3) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 16); }
-__device__ __forceinline__ int slot_index(int r, int half) { return 16 * (r >> 3) + 8 * half + (r & 7); }
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-struct Frag { bf16x8 v[2]; };               // 32 contraction slots of one lane: slots 8 half + e (v[0]) and 16 + 8 half + e (v[1])
-
-__device__ __forceinline__ f32x16 mma(f32x16 acc, const Frag& a, const Frag& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
-}
-__device__ __forceinline__ Frag pack(const float (&p)[16]) {
-  Frag f;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    u32x4 w;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = pack2bf(p[8 * g + 2 * e], p[8 * g + 2 * e + 1]);
-    f.v[g] = __builtin_bit_cast(bf16x8, w);
-  }
-  return f;
-}
-// row-major fragment of LDS tile row `row` (64 B, swizzled): contraction slots = the lane's 16 head dims 8 half + e, 16 + 8 half + e
-__device__ __forceinline__ Frag lds_rows(const char* tile, int row, int half) {
-  Frag f;
-  f.v[0] = *reinterpret_cast<const bf16x8*>(tile + swz(row, half));
-  f.v[1] = *reinterpret_cast<const bf16x8*>(tile + swz(row, 2 + half));
-  return f;
-}
-// the same from global memory: the lane's own token row of a head-planar operand (64 B)
-__device__ __forceinline__ Frag global_row(const bf16_t* row, int half) {
-  Frag f;
-  f.v[0] = *reinterpret_cast<const bf16x8*>(row + 8 * half);
-  f.v[1] = *reinterpret_cast<const bf16x8*>(row + 16 + 8 * half);
-  return f;
-}
-// Transposed fragment of a row-major LDS tile [token][32 dims] with ds_read_b64_tr_b16: output row (MFMA A row) i = lane & 31 is
-// head dim pi32(i), contraction slots are the tile's tokens 8 half + e (v[0]) and 16 + 8 half + e (v[1]).  Measured semantics
-// (tools/tr_probe.hip): in each 16-lane group, output lane t element j = element t & 3 of the 8 bytes addressed by lane
-// 4 j + (t >> 2).  Lane t' therefore points at token k0 + (t' >> 2), dims cbase + 4 sigma(t' & 3) .. + 3 (sigma swaps 1 and 2, which
-// realises pi32 inside the group), cbase = 16 * ((lane >> 4) & 1).  troff[j0] = the lane's byte offset for k0 = 8 half + 4 j0; the second
-// half of the tile (tokens 16..31) is 1024 B further on and has the same swizzle phase.
-struct TrOff { uint32_t o[2]; };
-__device__ __forceinline__ TrOff tr_offsets(int lane) {
-  const int t = lane & 15, grp = (lane >> 4) & 1, half = lane >> 5;
-  const int sg = ((t & 1) << 1) | ((t >> 1) & 1);          // sigma(t & 3)
-  TrOff r;
-#pragma unroll
-  for (int j0 = 0; j0 < 2; ++j0) {
-    const int row = 8 * half + 4 * j0 + (t >> 2);
-    r.o[j0] = (uint32_t)(swz(row, 2 * grp + (sg >> 1)) + 8 * (sg & 1));
-  }
-  return r;
-}
-__device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ Frag lds_cols(const char* tile, const TrOff& tr) {
-  const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
-  u32x2 a0 = tr_read(base + tr.o[0]), a1 = tr_read(base + tr.o[1]);
-  u32x2 b0 = tr_read(base + 1024 + tr.o[0]), b1 = tr_read(base + 1024 + tr.o[1]);
-  // the compiler does not know that the asm reads above are asynchronous: the wait must CARRY the registers ("+v"), otherwise the
-  // consumer (an MFMA) may be scheduled in front of it -- first hardware run: forward row sums right, outputs garbage
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) :: "memory");
-  Frag f;
-  f.v[0] = __builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
-  f.v[1] = __builtin_bit_cast(bf16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
-  return f;
-}
-
-struct Params {
-  const bf16_t *qh, *kh, *vh;              // head-planar [H][M][32]: q~, k^, v
-  const float* tab;                        // (ncls, H) position-bias table (natural units), or null
-  const float *q_scale, *k_scale;          // (32) learned scales (for the logit bound)
-  int gh, gw, H, L, nseq;
-  int64_t M;                               // nseq * L
-  float c;                                 // scale * log2 e (already folded into q~)
-  // forward
-  bf16_t* out; int64_t ldo;                // (M, >= H*32) row-major
-  float* lse2;                             // [H][M] log2-domain log-sum-exp
-  // backward
-  const bf16_t* o; const bf16_t* dout; int64_t lddo;
-  bf16_t* dop;                             // [H][M][32]: dO' = w dO (written by the query pass, read by the key pass and dBias)
-  float* deltap;                           // [H][M]: delta' = w delta
-  bf16_t *dqh, *dkh, *dvh;                 // head-planar gradients
-  float* dbias_part; int nsplit;           // dBias slabs [nsplit][H][L][L]
-};
-
-// ---- per-workgroup preamble: stage the bias table of head h (log2 domain) and the token -> offset-class index, and derive the
-// logit bound.  All threads of the workgroup must call it.  Returns M2 (log2-domain bound folded into the staged table when safe).
-template <int NC, int NL>
-struct RelT {
-  float tab[NC];
-  __attribute__((aligned(16))) uint16_t u[NL];
-  float red[2][16];
-  float m2; int safe;
-};
-using Rel = RelT<MAXCLS, MAXL>;
-constexpr int SLAB_MAXCLS = 2304, SLAB_MAXL = 576;          // 24 x 24 tokens: 47^2 = 2209 classes
-using RelS = RelT<SLAB_MAXCLS, SLAB_MAXL>;
-// REVERSED: entry i holds class ncls - 1 - i, so that the descending classes of a key run are ASCENDING addresses and land in
-// consecutive registers without moves (the kernels whose tile rows are keys); the key pass keeps the natural order.
-template <bool REVERSED, class R>
-__device__ __forceinline__ void stage_rel(R& rel, const Params& p, int h) {
-  const int ncls = p.tab ? (2 * p.gh - 1) * (2 * p.gw - 1) : 0;
-  const int nth = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
-  float mx = -INFINITY, mn = INFINITY;
-  for (int i = tid; i < ncls; i += nth) {
-    const float t = p.tab[(int64_t)(REVERSED ? ncls - 1 - i : i) * p.H + h] * LOG2E;
-    rel.tab[i] = t;
-    mx = fmaxf(mx, t); mn = fminf(mn, t);
-  }
-  if (ncls == 0) { mx = 0.f; mn = 0.f; if (tid == 0) rel.tab[0] = 0.f; }
-  for (int i = tid; i < p.L; i += nth) rel.u[i] = p.tab ? (uint16_t)((i / p.gw) * (2 * p.gw - 1) + i % p.gw) : (uint16_t)0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
-  if (lane == 0) { rel.red[0][wave] = mx; rel.red[1][wave] = mn; }
-  __syncthreads();
-  if (wave == 0) {
-    float a = lane < 32 ? fabsf(p.q_scale[lane]) : fabsf(p.k_scale[lane - 32]);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));     // lanes 0-31: max|q_scale|, 32-63: max|k_scale|
-    const float qk = a * __shfl_xor(a, 32, 64) * p.c;
-    float tmx = -INFINITY, tmn = INFINITY;
-    for (int w = 0; w < nw; ++w) { tmx = fmaxf(tmx, rel.red[0][w]); tmn = fminf(tmn, rel.red[1][w]); }
-    if (lane == 0) {
-      const float span = 2.f * qk + (tmx - tmn);
-      rel.safe = (span <= SAFE_SPAN && span == span) ? 1 : 0;
-      rel.m2 = qk + tmx;
-    }
-  }
-  __syncthreads();
-  if (rel.safe) {
-    const float m2 = rel.m2;
-    for (int i = tid; i < (ncls ? ncls : 1); i += nth) rel.tab[i] -= m2;
-    __syncthreads();
-  }
-}
-
-// offset-class gather of one 32 x 32 tile as the MFMA accumulator input.  Rows (registers) are KEYS, lane = query: class of key
-// run (8 consecutive tokens of one image row; needs gw % 8 == 0) descends by one per key.  Rows are QUERIES, lane = key: ascends.
-template <bool ROWS_ARE_KEYS, bool TAB, class R>
-__device__ __forceinline__ f32x16 bias_tile(const R& rel, const Params& p, int ucol, int row_base, int half) {
-  f32x16 cb;
-  if (!TAB) {
-    const float t = rel.tab[0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cb[r] = t;
-    return cb;
-  }
-  const int c0 = (p.gh - 1) * (2 * p.gw - 1) + (p.gw - 1);
-  const int ncls = (2 * p.gh - 1) * (2 * p.gw - 1);
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int urow0 = rel.u[row_base + 16 * g + 8 * half];
-    // keys: class(e) = ucol - urow0 + c0 - e, stored reversed at ncls - 1 - class; queries: class(e) = urow0 - ucol + c0 + e
-    const float* b = rel.tab + (ROWS_ARE_KEYS ? ncls - 1 - (ucol - urow0 + c0) : urow0 - ucol + c0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cb[8 * g + e] = b[e];
-  }
-  return cb;
-}
-
-// work item of a workgroup: XCD-aware decode.  Hardware places workgroup b on XCD b % 8; the `per` consecutive items handled by one
-// XCD are the row-block groups of the same (sequence, head), which then share their operand slab through that XCD's L2.
-__device__ __forceinline__ bool decode_item(int ngroups, int nitems, int& grp, int& sh) {
-  const int per = (nitems + 7) >> 3;
-  const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (w >= nitems) return false;
-  sh = w / ngroups; grp = w % ngroups;
-  return true;
-}
-
-// loader: thread `lt` of the 256 loader threads moves 16 B of a pair of tiles per step: tile (lt >> 7), row (lt & 127) >> 2,
-// source chunk lt & 3  ->  LDS position swz(row, chunk).
-struct Loader {
-  const char* src;          // global address of this thread's chunk of tile 0 (advance by TILE bytes per tile)
-  int dst;                  // byte offset inside a ring slot
-};
-
 // ================================================================================================================== forward
-// every global load issued so far has landed (s_waitcnt vmcnt(0), lgkmcnt / expcnt untouched).  Placed in front of the tile loops: the
-// loop-invariant operand fragments come from global loads, and without a visible wait the compiler re-waits for them -- vmcnt(0),
-// i.e. for the tile prefetches too -- in front of the first MFMA of EVERY step.
-__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-
 template <int NW, bool SAFE, bool TAB>
 __device__ __forceinline__ void fwd_body(const Params& p, Rel& rel, char (*ring)[2][TILE], int seq, int h, int grp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,190 +131,6 @@ __global__ __launch_bounds__(NW * 64) void attn2_fwd_kernel(Params p) {
   if (!ok) return;                                                       // workgroup-uniform
   if (rel.safe) fwd_body<NW, true, TAB>(p, rel, ring, seq, h, grp);
   else fwd_body<NW, false, TAB>(p, rel, ring, seq, h, grp);
-}
-
-// ================================================================================================================== forward, slab-resident
-// PERSISTENT variant for sequences whose K^ and V slabs (L x 64 B each) fit in LDS twice (L <= 576): one workgroup of nine waves per
-// CU walks a contiguous run of (sequence, head) items.  The whole K^ / V slab of the current item sits in LDS, so the tile loop has NO
-// barrier: waves drift apart and one wave's softmax overlaps another's MFMAs (the ring kernels above synchronise every 32 keys, which
-// keeps all waves of a SIMD in the same phase: first hardware run 196 us against 40 us of VALU + MFMA issue time).  While item k is
-// computed, every thread copies its share of item k+1's slabs into the other LDS buffer (one 16-byte chunk per thread and step);
-// one barrier per item.  A wave owns two query blocks (w and w + 9): two independent MFMA / softmax chains that share the K^ and V
-// fragment reads and give the in-order issue something to overlap.
-constexpr int SLAB_WAVES = 9;
-// dynamic LDS: RelS (padded to 256 B) followed by slabs[buffer][K^ | V][L * 64]
-__host__ __device__ __forceinline__ int slab_bytes(int L) { return L * 64; }
-constexpr int SLAB_REL_BYTES = (int)((sizeof(RelS) + 255) / 256 * 256);
-
-template <bool SAFE, bool TAB>
-__device__ __forceinline__ void fwd_slab_item(const Params& p, RelS& rel, const char* kslab, const char* vslab, char* next_k, const char* gnext,
-                                              int64_t vdelta, int nchunk_next, int seq, int h, int wave, int lane, Frag (&qf)[2],
-                                              const bf16_t* qnext) {
-  const int L = p.L, nkb = L / 32;
-  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
-  const TrOff tr = tr_offsets(lane);
-  int qi[2]; bool act[2]; int ucol[2];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    const int qb_raw = wave + ch * SLAB_WAVES;
-    act[ch] = qb_raw < nkb;
-    qi[ch] = (act[ch] ? qb_raw : nkb - 1) * 32 + c;
-    ucol[ch] = rel.u[qi[ch]];
-  }
-  drain_vmem();       // the query fragments (loaded at the end of the previous item) have landed: see drain_vmem
-  float ls[2][4], m[2] = {-INFINITY, -INFINITY};
-  f32x16 oacc[2];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ls[ch][e] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[ch][r] = 0.f;
-  }
-  const int nth = SLAB_WAVES * 64;
-  for (int t = 0; t < nkb; ++t) {
-    // copy of the next item's slabs: chunk t * nth + tid (16 B), issued now, written to the other buffer at the end of the step
-    const int chunk = t * nth + (int)threadIdx.x;
-    const bool ld = chunk < nchunk_next;
-    const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per;      // (tensor, 16-byte piece of its slab)
-    u32x4 st{};
-    if (ld) st = *reinterpret_cast<const u32x4*>(gnext + (tens ? vdelta : 0) + (int64_t)rc * 16);
-    const char* ktile = kslab + t * TILE;
-    const char* vtile = vslab + t * TILE;
-    const Frag kf = lds_rows(ktile, ar, half);
-    f32x16 s[2];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) s[ch] = bias_tile<true, TAB>(rel, p, ucol[ch], t * 32, half);
-    // the two chains' dependent MFMA pairs interleaved: a0 b0 a1 b1
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) s[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[0], qf[ch].v[0], s[ch], 0, 0, 0);
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) s[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[1], qf[ch].v[1], s[ch], 0, 0, 0);
-    const Frag vf = lds_cols(vtile, tr);
-    Frag pf[2];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      float pr[16];
-      if (SAFE) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(s[ch][r]);
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) { ls[ch][0] += pr[r]; ls[ch][1] += pr[r + 1]; ls[ch][2] += pr[r + 2]; ls[ch][3] += pr[r + 3]; }
-      } else {
-        float mx = s[ch][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[ch][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m[ch], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m[ch] - mnew);
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(s[ch][r] - mnew); ps += pr[r]; }
-        ls[ch][0] = ls[ch][0] * alpha + ps;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[ch][r] *= alpha;
-        m[ch] = mnew;
-      }
-      pf[ch] = pack(pr);
-    }
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) oacc[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[0], pf[ch].v[0], oacc[ch], 0, 0, 0);
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) oacc[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[1], pf[ch].v[1], oacc[ch], 0, 0, 0);
-    if (ld) {
-      // piece -> (row, position) -> swizzled place inside its 32-row tile of the other buffer
-      const int row = rc >> 2, pc = rc & 3;
-      *reinterpret_cast<u32x4*>(next_k + tens * slab_bytes(L) + (row >> 5) * TILE + swz(row & 31, pc)) = st;
-    }
-  }
-  if (qnext) {        // query rows of the NEXT item: in flight across the epilogue and the item barrier
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) qf[ch] = global_row(qnext + (int64_t)qi[ch] * D, half);
-  }
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    float lsum = (ls[ch][0] + ls[ch][1]) + (ls[ch][2] + ls[ch][3]);
-    const float l = lsum + __shfl_xor(lsum, 32, 64);
-    if (act[ch]) {
-      const float inv = 1.f / l;
-      bf16_t* O = p.out + ((int64_t)seq * L + qi[ch]) * p.ldo + h * D;
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        float o8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = oacc[ch][8 * g + e] * inv;
-        store8(O + 16 * g + 8 * half, o8);
-      }
-      if (half == 0 && p.lse2) p.lse2[(int64_t)h * p.M + (int64_t)seq * L + qi[ch]] = (SAFE ? rel.m2 : m[ch]) + __log2f(l);
-    }
-  }
-}
-
-template <bool TAB>
-__global__ __launch_bounds__(SLAB_WAVES * 64) void attn2_fwd_slab_kernel(Params p, int items_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) char dyn[];
-  RelS& rel = *reinterpret_cast<RelS*>(dyn);
-  char* slabs = dyn + SLAB_REL_BYTES;
-  const int L = p.L, sb = slab_bytes(L);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nitems = p.nseq * p.H;
-  const int first = blockIdx.x * items_per_wg;
-  const int last = min(first + items_per_wg, nitems);
-  if (first >= last) return;
-  // item i = (head, sequence) with the head as the SLOW index: a workgroup's run of items stays on one head for as long as possible
-  auto item = [&](int i, int& seq, int& h) { h = i / p.nseq; seq = i % p.nseq; };
-  auto gsrc = [&](int seq, int h) { return reinterpret_cast<const char*>(p.kh + ((int64_t)h * p.M + (int64_t)seq * L) * D); };
-  const int64_t vdelta = reinterpret_cast<const char*>(p.vh) - reinterpret_cast<const char*>(p.kh);
-  const int nchunk = 2 * L * 4;
-  int seq, h;
-  item(first, seq, h);
-  // prologue: slabs of the first item
-  {
-    const char* gk = gsrc(seq, h);
-    constexpr int NTH = SLAB_WAVES * 64, MAXPER = (2 * SLAB_MAXL * 4 + NTH - 1) / NTH;     // <= 8 pieces per thread: all loads first
-    u32x4 v[MAXPER];
-#pragma unroll
-    for (int k = 0; k < MAXPER; ++k) {
-      const int chunk = k * NTH + (int)threadIdx.x;
-      const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per;
-      v[k] = u32x4{0, 0, 0, 0};
-      if (chunk < nchunk) v[k] = *reinterpret_cast<const u32x4*>(gk + (tens ? vdelta : 0) + (int64_t)rc * 16);
-    }
-#pragma unroll
-    for (int k = 0; k < MAXPER; ++k) {
-      const int chunk = k * NTH + (int)threadIdx.x;
-      const int per = L * 4, tens = chunk >= per ? 1 : 0, rc = chunk - tens * per, row = rc >> 2, pc = rc & 3;
-      if (chunk < nchunk) *reinterpret_cast<u32x4*>(slabs + tens * sb + (row >> 5) * TILE + swz(row & 31, pc)) = v[k];
-    }
-  }
-  Frag qf[2];
-  {
-    const int nkb = L / 32, c = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const int qb_raw = wave + ch * SLAB_WAVES;
-      const int qi = (qb_raw < nkb ? qb_raw : nkb - 1) * 32 + c;
-      qf[ch] = global_row(p.qh + ((int64_t)h * p.M + (int64_t)seq * L + qi) * D, half);
-    }
-  }
-  int staged_h = -1;
-  for (int i = first; i < last; ++i) {
-    item(i, seq, h);
-    // every wave is done with the previous item (its slab buffer becomes the copy target, its table may be replaced) and the
-    // copies of this item's slabs are complete
-    __syncthreads();
-    if (h != staged_h) { stage_rel<true>(rel, p, h); staged_h = h; }       // (ends with a barrier; workgroup-uniform)
-    const int buf = (i - first) & 1;
-    char* cur = slabs + buf * 2 * sb;
-    char* nxt = slabs + (buf ^ 1) * 2 * sb;
-    int nseq2 = seq, nh = h;
-    const bool more = i + 1 < last;
-    if (more) item(i + 1, nseq2, nh);
-    const char* gnext = gsrc(nseq2, nh);          // K^ slab of the next item; its V slab is `vdelta` bytes further
-    const bf16_t* qnext = more ? p.qh + ((int64_t)nh * p.M + (int64_t)nseq2 * L) * D : nullptr;
-    if (rel.safe) fwd_slab_item<true, TAB>(p, rel, cur, cur + sb, nxt, gnext, vdelta, more ? nchunk : 0, seq, h, wave, lane, qf, qnext);
-    else fwd_slab_item<false, TAB>(p, rel, cur, cur + sb, nxt, gnext, vdelta, more ? nchunk : 0, seq, h, wave, lane, qf, qnext);
-  }
 }
 
 // ================================================================================================================== dQ pass
@@ -972,17 +595,26 @@ __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restri
     part[((int64_t)blockIdx.x * 2 + which) * 32 + d] = red[which][0][d] + red[which][1][d] + red[which][2][d] + red[which][3][d];
   }
 }
-__global__ void scale_grad_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dqs, float* __restrict__ dks) {
-  const int which = threadIdx.x >> 5, d = threadIdx.x & 31;
-  if (threadIdx.x >= 64) return;
+// part[blocks][2][32] -> dq_scale / dk_scale (+=).  1024 threads: output o = t & 63, sixteen interleaved slices of the blocks summed in
+// parallel, then the slices in a fixed order (the first version walked all 2048 partials from ONE wave: 550 us of dependent L2 loads).
+__global__ __launch_bounds__(1024) void scale_grad_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dqs, float* __restrict__ dks) {
+  __shared__ float red[16][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += part[((int64_t)b * 2 + which) * 32 + d];
-  float* dst = which ? dks : dqs;
-  if (dst) dst[d] += t;
+  for (int b = sl; b < nblk; b += 16) t += part[(int64_t)b * 64 + o];
+  red[sl][o] = t;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red[i][o];
+    float* dst = (o >> 5) ? dks : dqs;
+    if (dst) dst[o & 31] += a;
+  }
 }
 
 constexpr int NW_ROWS = 6;               // row blocks (waves) per workgroup of the three main kernels
-constexpr int UNPREP_BLOCKS = 2048;
+constexpr int UNPREP_BLOCKS = 1024;
 
 bool shape_ok(int H, int L, int gh, int gw, const float* tab) {
   if (L % 32 || L < 64 || L > MAXL) return false;
@@ -1003,15 +635,6 @@ int num_cus() {
   if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
   return ncu;
 }
-// the slab-resident kernels need both operand slabs twice in LDS next to the bias table
-bool slab_ok(int L, int gh, int gw, const float* tab) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("CTCLIP_ATTN_SLAB"); use = (e && e[0] == '0') ? 0 : 1; }
-  if (!use || L > SLAB_MAXL || L / 32 > 2 * SLAB_WAVES) return false;
-  if (tab && (2 * gh - 1) * (2 * gw - 1) > SLAB_MAXCLS) return false;
-  return SLAB_REL_BYTES + 4 * slab_bytes(L) <= 160 * 1024;
-}
-
 }  // namespace
 
 // 1 when ctclip_attn2_* serve this shape (bf16, d_head 32): L % 32 == 0, 64 <= L <= 1024; with a bias table gw % 8 == 0.
@@ -1043,21 +666,9 @@ extern "C" int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, 
   p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
   p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = (int64_t)nseq * L; p.c = scale * LOG2E;
   p.out = (bf16_t*)out; p.ldo = ldo; p.lse2 = lse2;
-  if (slab_ok(L, bias_gh, bias_gw, tab)) {
-    // persistent, slab-resident: one workgroup per CU, contiguous runs of (head, sequence) items
-    const int ncu = num_cus(), total = nseq * H;
-    const int ipw = (total + ncu - 1) / ncu;
-    const int nwg = (total + ipw - 1) / ipw;
-    const size_t shm = (size_t)SLAB_REL_BYTES + 4 * (size_t)slab_bytes(L);
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute((const void*)attn2_fwd_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute((const void*)attn2_fwd_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { ctclip_set_error("attn2_fwd: cannot raise the LDS limit"); return CTCLIP_EBADARG; }
-      raised = true;
-    }
-    if (tab) hipLaunchKernelGGL(attn2_fwd_slab_kernel<true>, dim3((unsigned)nwg), dim3(SLAB_WAVES * 64), shm, stream, p, ipw);
-    else hipLaunchKernelGGL(attn2_fwd_slab_kernel<false>, dim3((unsigned)nwg), dim3(SLAB_WAVES * 64), shm, stream, p, ipw);
-    return ctclip_check_launch("attn2_fwd (slab)");
+  {
+    const int rc = attn2_slab_fwd(p, stream);       // persistent slab-resident kernel when the slabs fit in LDS (L <= 576)
+    if (rc != 1) return rc;
   }
   const int ngroups = (L / 32 + NW_ROWS - 1) / NW_ROWS;
   const int nitems = ngroups * nseq * H;
@@ -1099,13 +710,19 @@ extern "C" int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, 
   const int ngroups = (L / 32 + NW_ROWS - 1) / NW_ROWS;
   const int nitems = ngroups * nseq * H;
   const dim3 grid((unsigned)(((nitems + 7) / 8) * 8)), block(NW_ROWS * 64);
-  if (tab) hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
-  int rc = ctclip_check_launch("attn2_bwd_dq");
+  int rc = attn2_slab_bwd_dq(p, stream);
+  if (rc == 1) {
+    if (tab) hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn2_bwd_dq_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
+    rc = ctclip_check_launch("attn2_bwd_dq");
+  }
   if (rc) return rc;
-  if (tab) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
-  rc = ctclip_check_launch("attn2_bwd_dkv");
+  rc = attn2_slab_bwd_dkv(p, stream);
+  if (rc == 1) {
+    if (tab) hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NW_ROWS, false>), grid, block, 0, stream, p);
+    rc = ctclip_check_launch("attn2_bwd_dkv");
+  }
   if (rc || !dtab) return rc;
   const int ncls = (2 * bias_gh - 1) * (2 * bias_gw - 1);
   p.nsplit = dbias_splits(nseq, H, L);
@@ -1138,6 +755,6 @@ extern "C" int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void*
                      lddk, lddv, (float*)workspace, M, H);
   int rc = ctclip_check_launch("attn2_unprep");
   if (rc) return rc;
-  hipLaunchKernelGGL(scale_grad_sum_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, (int)nb, dq_scale, dk_scale);
+  hipLaunchKernelGGL(scale_grad_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, (int)nb, dq_scale, dk_scale);
   return ctclip_check_launch("attn2_scale_grad");
 }

@@ -144,13 +144,18 @@ class LiProTrainer:
         self.max_grad_norm = max_grad_norm
         self.step = 0
 
-    def train_step(self, text_tokens, volumes, labels):
+    def forward_backward(self, text_tokens, volumes, labels):
+        """logits, BCEWithLogitsLoss(pos_weight), backward into the head's gradients (ct_lipro_train.py:103-105)."""
         self.model.train()
         dev = self.pos_weight.device
         logits = self.model(text_tokens, volumes, device=dev)
         loss = BceLogitsFn.apply(logits, labels.to(device=dev, dtype=torch.float32), self.pos_weight)
         self.optim.zero_grad()
         loss.backward()
+        return loss, logits
+
+    def train_step(self, text_tokens, volumes, labels):
+        loss, logits = self.forward_backward(text_tokens, volumes, labels)
         self.optim.step(self.max_grad_norm)
         self.scheduler(self.step)                       # ct_lipro_train.py:107: the schedule is applied AFTER the step
         self.step += 1
@@ -183,22 +188,28 @@ class VocabFineTrainer:
         self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
         self.step = 0
 
-    def train_step(self, volume, labels):
-        """volume: (1, 1, F, H, W); labels: (n_pathologies,) 0/1.  Returns the per-group losses."""
+    def forward_backward(self, volume, token_pairs):
+        """token_pairs: one (true prompt, false prompt) token batch per pathology.  One backward per group of `group_size`
+        pathologies, gradients accumulate (ct_vocabfine_train.py:88-121).  Returns (losses, similarities)."""
         model = self.model
         model.train()
         dev = model.temperature.device
-        self.scheduler(self.step)                       # ct_vocabfine_train.py:82: the schedule is applied BEFORE the step
         self.optim.zero_grad()
-        losses = []
-        for k in range(0, len(self.pathologies), self.group_size):
-            sims = []
-            for name, lab in zip(self.pathologies[k:k + self.group_size], labels[k:k + self.group_size]):
-                tokens = self.tokenize(vocabfine_prompts(name, lab))
-                sims.append(model(tokens, volume, device=dev))             # (2,) similarities: true prompt first
-            loss = PairSoftmaxMseFn.apply(torch.stack(sims))
-            loss.backward()                                                 # one backward per group, gradients accumulate
+        losses, sims_all = [], []
+        for k in range(0, len(token_pairs), self.group_size):
+            sims = [model(tokens, volume, device=dev) for tokens in token_pairs[k:k + self.group_size]]     # (2,) each: true prompt first
+            st = torch.stack(sims)
+            loss = PairSoftmaxMseFn.apply(st)
+            loss.backward()
             losses.append(loss.detach())
+            sims_all.append(st.detach())
+        return losses, sims_all
+
+    def train_step(self, volume, labels):
+        """volume: (1, 1, F, H, W); labels: (n_pathologies,) 0/1.  Returns the per-group losses."""
+        self.scheduler(self.step)                       # ct_vocabfine_train.py:82: the schedule is applied BEFORE the step
+        pairs = [self.tokenize(vocabfine_prompts(name, lab)) for name, lab in zip(self.pathologies, labels)]
+        losses, _ = self.forward_backward(volume, pairs)
         self.optim.step(None)
         self.step += 1
         return losses

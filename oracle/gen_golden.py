@@ -252,10 +252,91 @@ def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000)
           f"({os.path.getsize(path) / 1e6:.1f} MB)")
 
 
+def run_finetune_case(name="finetune_tiny", base="tiny"):
+    """Fixtures for the two fine-tuning loops on the REAL reference towers, tiny configuration
+    (same seed / weights / volumes as tiny.pt, which the tests load next to this file).
+
+    * ClassFine / CT-LiPro: the head of scripts/ct_lipro_train.py:17-38 is three torch modules around `trained_model(...,
+      return_latents=True)`; the script itself cannot be imported (it pulls the NIfTI dataset stack at import time), so the
+      four lines of its forward are restated here -- ReLU, Dropout (p = 0 for a deterministic fixture), Linear -- on the real
+      reference CTCLIP in train mode, with BCEWithLogitsLoss(pos_weight) as at ct_lipro_train.py:79-84,104.
+    * VocabFine: the inner loop of scripts/ct_vocabfine_train.py:88-121 (softmax over each prompt pair, MSE against (1, 0), one
+      backward per group) on the real reference CTCLIP in train mode, with synthetic token ids standing in for the tokenizer.
+    """
+    import torch.nn.functional as F
+    c = CASES[base]
+    out = {"config": c}
+    video, ids, mask = synth_inputs(c)
+    dev = torch.device("cpu")
+
+    # ---- ClassFine / LiPro
+    clip, _, _ = build(c)
+    g = torch.Generator().manual_seed(7)
+    ncls = 18
+    W = torch.randn(ncls, c["dim_latent"], generator=g) * 0.2
+    bvec = torch.randn(ncls, generator=g) * 0.1
+    labels = (torch.rand(c["batch"], ncls, generator=g) < 0.3).float()
+    pos_weight = torch.rand(ncls, generator=g) * 8 + 1
+    blank = ref_shim.TextBatch(ids[:1], mask[:1])                    # the script feeds the prompt " " (ct_lipro_train.py:99)
+    for prm in clip.parameters():
+        prm.requires_grad = False                                    # ct_lipro_train.py:20-21
+    Wp, bp = W.clone().requires_grad_(True), bvec.clone().requires_grad_(True)
+    clip.train()
+    _, lat, _ = clip(blank, video, device=dev, return_latents=True)  # ct_lipro_train.py:31-32
+    logits = F.linear(F.dropout(F.relu(lat), 0.0), Wp, bp)            # :33-36 with dropout_prob = 0
+    loss = F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pos_weight)
+    loss.backward()
+    sd1 = clip.state_dict()
+    out["lipro"] = dict(W=W, b=bvec, labels=labels, pos_weight=pos_weight, latents=lat.detach().clone(), logits=logits.detach().clone(),
+                        loss=loss.detach().clone(), dW=Wp.grad.clone(), db=bp.grad.clone(),
+                        vq_after={k: sd1[k].detach().clone() for k in sd1 if "vq._codebook" in k})
+    clip, _, _ = build(c)
+    clip.eval()
+    with torch.no_grad():
+        _, lat, _ = clip(blank, video, device=dev, return_latents=True)
+        out["lipro"]["eval_probs"] = torch.sigmoid(F.linear(F.relu(lat), W, bvec))        # ct_lipro_inference.py:62-66
+
+    # ---- VocabFine
+    clip, _, _ = build(c)
+    clip.train()
+    npath, group = 4, 2
+    T = c["T"]
+    pid = torch.randint(3, c["vocab"], (npath, 2, T), generator=g)
+    plen = torch.randint(T // 2, T + 1, (npath, 2), generator=g)
+    pmask = (torch.arange(T)[None, None, :] < plen[..., None]).long()
+    pid = pid * pmask
+    pid[..., 0] = 1
+    vol = video[:1]
+    losses, sims_all = [], []
+    for k in range(0, npath, group):
+        sims = []
+        for l in range(k, k + group):
+            outp = clip(ref_shim.TextBatch(pid[l], pmask[l]), vol, device=dev)      # ct_vocabfine_train.py:110 (2,) similarities
+            sims.append(outp)
+        probs = [F.softmax(o, dim=0) for o in sims]                                  # :112
+        target = torch.tensor([1.0, 0.0]).repeat(len(probs))                         # :113-118
+        loss = F.mse_loss(torch.cat(probs, dim=0), target)                           # :120
+        loss.backward()                                                              # :121
+        losses.append(loss.detach().clone())
+        sims_all.append(torch.stack([o.detach() for o in sims]))
+    grads = {k: subsample(p.grad) for k, p in clip.named_parameters() if p.grad is not None}
+    grad_sq = sum(float((p.grad.double() ** 2).sum()) for p in clip.parameters() if p.grad is not None)
+    sd1 = clip.state_dict()
+    out["vocabfine"] = dict(prompt_ids=pid, prompt_mask=pmask, group=group, sims=sims_all, losses=losses, grads=grads,
+                            grad_norm=torch.tensor(grad_sq).sqrt().float(),
+                            vq_after={k: sd1[k].detach().clone() for k in sd1 if "vq._codebook" in k})
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: lipro loss {float(out['lipro']['loss']):.6f}, vocabfine losses {[round(float(x), 6) for x in losses]} -> {path} "
+          f"({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(CASES)
     for name in which:
         if name == "full1":
             run_full_case()
+        elif name == "finetune_tiny":
+            run_finetune_case()
         else:
             run_case(name, CASES[name])

@@ -419,7 +419,7 @@ def _attn2_case(nseq, H, gh, gw, qk_gain, with_tab, seed=0):
     return L, D, M, q, kv, qs, ks, tab
 
 
-@pytest.mark.parametrize("nseq,H,gh,gw,gain,with_tab", [(3, 8, 24, 24, 1.0, True), (2, 2, 4, 8, 1.0, True), (2, 4, 8, 16, 1.0, False),
+@pytest.mark.parametrize("nseq,H,gh,gw,gain,with_tab", [(3, 8, 24, 24, 1.0, True), (2, 2, 8, 8, 1.0, True), (2, 4, 8, 16, 1.0, False),
                                                          (2, 8, 24, 24, 3.5, True), (3, 2, 2, 32, 4.0, False)])
 def test_attn2_fwd_bwd(hip, ref, nseq, H, gh, gw, gain, with_tab):
     """gain 1: the bounded-logit path (|q_scale||k_scale| small); gain >= 3.5: 2 c qs ks > 100 -> the online-softmax path."""
@@ -561,6 +561,34 @@ def test_clip_loss(hip, ref, G, Dl):
     outr, lr, dtlr, dilr, dtr = ref.clip_loss(tl, il, temp, want_logits=True)
     close(out, outr, rtol=1e-5, atol=1e-5); close(logits, lr, rtol=1e-4, atol=1e-5)
     close(dtl, dtlr, rtol=1e-3, atol=1e-6); close(dil, dilr, rtol=1e-3, atol=1e-6); close(dtemp, dtr, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_finetune_head_kernels(hip, ref, p):
+    x = rnd(16, 512, seed=1)
+    y, yr = hip.relu_dropout(x, None, p, 1234567, 3), ref.relu_dropout(x, None, p, 1234567, 3)
+    close(y, yr, rtol=0, atol=0)
+    dy = rnd(16, 512, seed=2)
+    close(hip.relu_dropout(x, dy, p, 1234567, 3), ref.relu_dropout(x, dy, p, 1234567, 3), rtol=0, atol=0)
+    logits, tgt, pw = rnd(8, 18, seed=3, scale=3.0), (rnd(8, 18, seed=4) > 0.5).float(), rnd(18, seed=5).abs() * 5 + 1
+    (l, dl), (lr, dlr) = hip.bce_logits(logits, tgt, pw), ref.bce_logits(logits, tgt, pw)
+    close(l, lr, rtol=1e-5, atol=1e-6); close(dl, dlr, rtol=1e-4, atol=1e-7)
+    (l, dl), (lr, dlr) = hip.bce_logits(logits, tgt, None), ref.bce_logits(logits, tgt, None)
+    close(l, lr, rtol=1e-5, atol=1e-6); close(dl, dlr, rtol=1e-4, atol=1e-7)
+    sims = rnd(6, 2, seed=6, scale=2.0)
+    (l, ds), (lr, dsr) = hip.pair_softmax_mse(sims), ref.pair_softmax_mse(sims)
+    close(l, lr, rtol=1e-5, atol=1e-7); close(ds, dsr, rtol=1e-4, atol=1e-7)
+
+
+def test_adam_weight_decay_mask(hip, ref):
+    n = 4096 + 36
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.01)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    mask = (torch.arange((n + 3) // 4) % 3 == 0).to(torch.uint8).to(DEV)
+    hip.adam_step(p, g, m, v, 1e-3, 0.9, 0.99, 1e-8, 1, 0.1, None, mask)
+    ref.adam_step(pr, g, mr, vr, 1e-3, 0.9, 0.99, 1e-8, 1, 0.1, None, mask)
+    close(p, pr, rtol=1e-6, atol=1e-7)
 
 
 def test_grad_norm_and_adam(hip, ref):
