@@ -31,10 +31,12 @@ SIGNATURES = {
     "ctclip_segment_sum_workspace": (_L, [_L, _I]),
     "ctclip_segment_sum": (_I, [_P, _I, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "ctclip_peg_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
-    "ctclip_peg_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "ctclip_peg_bwd_workspace": (_L, [_L, _I, _I, _I]),
+    "ctclip_peg_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
     "ctclip_head_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "ctclip_qk_norm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _I, _P]),
-    "ctclip_qk_norm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _P]),
+    "ctclip_qk_norm_bwd_workspace": (_L, [_L, _I, _I]),
+    "ctclip_qk_norm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _P, _L, _P]),
     "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
     "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
@@ -53,7 +55,8 @@ SIGNATURES = {
     "ctclip_gelu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
     "ctclip_leaky_relu_fwd": (_I, [_P, _P, _L, _F, _P]),
     "ctclip_leaky_relu_bwd": (_I, [_P, _P, _P, _L, _F, _P]),
-    "ctclip_colsum": (_I, [_P, _P, _L, _I, _L, _I, _P]),
+    "ctclip_colsum_workspace": (_L, [_L, _I]),
+    "ctclip_colsum": (_I, [_P, _P, _L, _I, _L, _I, _P, _L, _P]),
     "ctclip_permute0213": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "ctclip_transpose2d": (_I, [_P, _P, _I, _I, _L, _L, _I, _P]),
     "ctclip_pool_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),
@@ -62,11 +65,10 @@ SIGNATURES = {
     "ctclip_cpb_expand": (_I, [_P, _P, _I, _I, _I, _P]),
     "ctclip_cpb_reduce": (_I, [_P, _P, _I, _I, _I, _P]),
     "ctclip_bert_embed_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
-    "ctclip_bert_embed_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ctclip_vq_gather": (_I, [_P, _P, _P, _L, _I, _I, _P]),
-    "ctclip_vq_ema_accum": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "ctclip_vq_ema_update": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
-    "ctclip_visual_latent_fwd": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),
+    "ctclip_visual_latent_fwd_workspace": (_L, [_I, _I, _L]),
+    "ctclip_visual_latent_fwd": (_I, [_P, _P, _P, _I, _I, _L, _I, _P, _L, _P]),
     "ctclip_visual_latent_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "ctclip_clip_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ctclip_scale_by_scalar": (_I, [_P, _P, _L, _P]),

@@ -208,7 +208,9 @@ class HipBackend:
         B, D1, D2, D3, C = x.shape
         assert dy.is_contiguous() and x.is_contiguous()
         dx = torch.empty_like(x)
-        rc = self.lib.ctclip_peg_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, D1, D2, D3, C, dcode(x.dtype), _stream())
+        ws = self.workspace(x.device, self.lib.ctclip_peg_bwd_workspace(B, D1, D2, C)) if dw is not None else None
+        rc = self.lib.ctclip_peg_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, D1, D2, D3, C, dcode(x.dtype), _p(ws),
+                                     ws.numel() if ws is not None else 0, _stream())
         _lib.check(rc, "ctclip_peg_bwd")
         return dx
 
@@ -232,8 +234,10 @@ class HipBackend:
 
     def qk_norm_bwd(self, dy, x, inv, scale_vec, dx, dscale, H, D):
         M = x.shape[0]
+        ws = self.workspace(x.device, self.lib.ctclip_qk_norm_bwd_workspace(M, H, D)) if dscale is not None else None
         rc = self.lib.ctclip_qk_norm_bwd(_p(dy), _p(x), _p(inv), _p(scale_vec), _p(dx), _p(dscale), M, H, D, _rowmajor(dy, "dy"),
-                                         _rowmajor(x, "x"), _rowmajor(dx, "dx"), dcode(x.dtype), _stream())
+                                         _rowmajor(x, "x"), _rowmajor(dx, "dx"), dcode(x.dtype), _p(ws), ws.numel() if ws is not None else 0,
+                                         _stream())
         _lib.check(rc, "ctclip_qk_norm_bwd")
         return dx
 
@@ -365,7 +369,8 @@ class HipBackend:
     def colsum(self, x, out, N=None):
         M = x.shape[0]
         N = x.shape[1] if N is None else N
-        _lib.check(self.lib.ctclip_colsum(_p(x), _p(out), M, N, _rowmajor(x, "colsum x"), dcode(x.dtype), _stream()),
+        ws = self.workspace(x.device, self.lib.ctclip_colsum_workspace(M, N))
+        _lib.check(self.lib.ctclip_colsum(_p(x), _p(out), M, N, _rowmajor(x, "colsum x"), dcode(x.dtype), _p(ws), ws.numel(), _stream()),
                    "ctclip_colsum")
         return out
 
@@ -463,10 +468,11 @@ class HipBackend:
         Bm, K = x.shape
         N = w.shape[0]
         assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
-        y = torch.zeros((Bm, N), dtype=torch.float32, device=x.device)
+        y = torch.empty((Bm, N), dtype=torch.float32, device=x.device)
+        ws = self.workspace(x.device, self.lib.ctclip_visual_latent_fwd_workspace(min(8, Bm), N, K))
         for b0 in range(0, Bm, 8):
             nb = min(8, Bm - b0)
-            rc = self.lib.ctclip_visual_latent_fwd(_p(x[b0:]), _p(w), _p(y[b0:]), nb, N, K, dcode(x.dtype), _stream())
+            rc = self.lib.ctclip_visual_latent_fwd(_p(x[b0:]), _p(w), _p(y[b0:]), nb, N, K, dcode(x.dtype), _p(ws), ws.numel(), _stream())
             _lib.check(rc, "ctclip_visual_latent_fwd")
         return y
 

@@ -353,7 +353,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
       const float dpr = p.drop_p > 0.f ? dp[r] * attn_drop(p, seq, h, qic, kj < L ? kj : L - 1) : dp[r];   // d(dropout(P)) / dP
       ds[r] = pr * (dpr - delta);
-      if (p.dbias && qi < L && kj < L) atomicAdd(p.dbias + ((int64_t)h * L + qi) * L + kj, ds[r]);
     }
     Frag<T, 32> dsf;
     frag_from_regs(dsf, ds);
@@ -456,31 +455,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dbias_kernel(AttnParams p, float
       if (kj < L) dst[kj] = acc[r];
     }
   }
-}
-
-// Relative-position mode: sum the per-split slabs AND fold (H, L, L) into the (nclass, H) table in one pass.  A workgroup takes 16
-// query rows of one head, bins its L x 16 elements in an LDS copy of the table (LDS float atomics are slow -- ~1 lane per 3 clk --
-// but this is 9 K of them per workgroup, not 500 M) and flushes the non-zero bins with global atomics.  Replaces
-// dbias_reduce_kernel + cpb_reduce_kernel (one thread per class walking up to 576 strided elements: 163 us).
-__global__ __launch_bounds__(256) void dbias_fold_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ dtab, int H,
-                                                         int gh, int gw) {
-  __shared__ float bins[REL_MAXCLS];
-  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), h = blockIdx.y;
-  for (int i = threadIdx.x; i < ncls; i += 256) bins[i] = 0.f;
-  __syncthreads();
-  const int64_t n = (int64_t)H * L * L;
-  const int q0 = blockIdx.x * 16;
-  for (int i = threadIdx.x; i < 16 * L; i += 256) {
-    const int qi = q0 + i / L, kj = i % L;
-    if (qi >= L) break;
-    const int64_t off = ((int64_t)h * L + qi) * L + kj;
-    float t = 0.f;
-    for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + off];
-    atomicAdd(&bins[(qi / gw - kj / gw + gh - 1) * (2 * gw - 1) + (qi % gw - kj % gw + gw - 1)], t);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ncls; i += 256)
-    if (bins[i] != 0.f) atomicAdd(dtab + (int64_t)i * H + h, bins[i]);
 }
 
 __global__ void dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nsplit, int64_t n, int accumulate) {
@@ -1128,10 +1102,10 @@ __global__ void qk_norm_fwd_kernel(const T* __restrict__ x, const float* __restr
 template <typename T, int D>
 __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ inv_in, const float* __restrict__ scale_vec,
-                                                          T* __restrict__ dx, float* __restrict__ dscale, int64_t M, int H,
+                                                          T* __restrict__ dx, float* __restrict__ dscale_part, int64_t M, int H,
                                                           int64_t lddy, int64_t ldx, int64_t lddx) {
   constexpr int G = D / 8;
-  __shared__ float red[D];
+  __shared__ float red[4][D];
   const int HG = H * G;
   // each thread keeps a fixed column group (grid stride is a multiple of HG)
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -1169,13 +1143,36 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const T* __restrict__ 
       store8(dx + row * lddx + hc * 8, o);
     }
   }
-  if (!dscale) return;
-  if (threadIdx.x < D) red[threadIdx.x] = 0.f;
-  __syncthreads();
+  if (!dscale_part) return;
+  // deterministic: lanes that share a column group (equal lane mod G) by a fixed xor tree, the four waves in order, one partial
+  // row per workgroup (summed in block order by qk_scale_sum_kernel)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomicAdd(&red[d0 + e], acc[e]);
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][d0 + e] = acc[e];          // lanes 0 .. G-1 hold the G distinct column groups
+  }
   __syncthreads();
-  if (threadIdx.x < D) atomicAdd(dscale + threadIdx.x, red[threadIdx.x]);
+  if (threadIdx.x < D) dscale_part[(int64_t)blockIdx.x * D + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <int D>
+__global__ void qk_scale_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dscale) {
+  __shared__ float red[16][D];
+  const int d = threadIdx.x % D, sl = threadIdx.x / D;      // blockDim = 16 * D
+  float t = 0.f;
+  for (int b = sl; b < nblk; b += 16) t += part[(int64_t)b * D + d];
+  red[sl][d] = t;
+  __syncthreads();
+  if (sl == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red[i][d];
+    dscale[d] += a;
+  }
 }
 
 template <typename T, int D>
@@ -1261,24 +1258,35 @@ extern "C" int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y
   return ctclip_check_launch("qk_norm_fwd");
 }
 
-extern "C" int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale,
-                                  int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, hipStream_t stream) {
-  if (!dy || !x || !dx || !inv || !scale_vec || bad_ld(lddy) || bad_ld(ldx) || bad_ld(lddx)) { ctclip_set_error("qk_norm_bwd: bad args"); return CTCLIP_EBADARG; }
+static int64_t qk_norm_bwd_blocks(int64_t M, int H, int D) {
   const int HG = H * (D / 8);
+  const int64_t want_rows = M < 4096 ? M : 4096;
+  int64_t nblocks = cdiv(want_rows * HG, 256);
+  while ((nblocks * 256) % HG) ++nblocks;      // the grid stride must be a multiple of HG so that each thread keeps its column group
+  return nblocks;
+}
+extern "C" int64_t ctclip_qk_norm_bwd_workspace(int64_t M, int H, int D) { return qk_norm_bwd_blocks(M, H, D) * D * 4; }
+
+// dscale (D) is ACCUMULATED (two stages, fixed summation order; workspace >= ctclip_qk_norm_bwd_workspace when dscale is given).
+extern "C" int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale,
+                                  int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, void* workspace,
+                                  int64_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !dx || !inv || !scale_vec || bad_ld(lddy) || bad_ld(ldx) || bad_ld(lddx)) { ctclip_set_error("qk_norm_bwd: bad args"); return CTCLIP_EBADARG; }
   if (256 % (D / 8) != 0) return CTCLIP_EUNSUPPORTED;
-  // grid stride must be a multiple of HG so that each thread keeps its column group: use lcm via blocks multiple
-  int64_t want_rows = M < 4096 ? M : 4096;
-  int64_t nthreads = want_rows * HG;
-  int64_t nblocks = cdiv(nthreads, 256);
-  // make nblocks*256 a multiple of HG
-  while ((nblocks * 256) % HG) ++nblocks;
+  if (dscale && (!workspace || workspace_bytes < ctclip_qk_norm_bwd_workspace(M, H, D))) { ctclip_set_error("qk_norm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int64_t nblocks = qk_norm_bwd_blocks(M, H, D);
   dim3 grid((unsigned)nblocks);
-  if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((qk_norm_bwd_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, inv, scale_vec, (bf16_t*)dx, dscale, M, H, lddy, ldx, lddx);
-  else if (dtype == DT_BF16 && D == 64) hipLaunchKernelGGL((qk_norm_bwd_kernel<bf16_t, 64>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, inv, scale_vec, (bf16_t*)dx, dscale, M, H, lddy, ldx, lddx);
-  else if (dtype == DT_F32 && D == 32) hipLaunchKernelGGL((qk_norm_bwd_kernel<float, 32>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, inv, scale_vec, (float*)dx, dscale, M, H, lddy, ldx, lddx);
-  else if (dtype == DT_F32 && D == 64) hipLaunchKernelGGL((qk_norm_bwd_kernel<float, 64>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, inv, scale_vec, (float*)dx, dscale, M, H, lddy, ldx, lddx);
+  float* part = dscale ? (float*)workspace : nullptr;
+  if (dtype == DT_BF16 && D == 32) hipLaunchKernelGGL((qk_norm_bwd_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, inv, scale_vec, (bf16_t*)dx, part, M, H, lddy, ldx, lddx);
+  else if (dtype == DT_BF16 && D == 64) hipLaunchKernelGGL((qk_norm_bwd_kernel<bf16_t, 64>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, inv, scale_vec, (bf16_t*)dx, part, M, H, lddy, ldx, lddx);
+  else if (dtype == DT_F32 && D == 32) hipLaunchKernelGGL((qk_norm_bwd_kernel<float, 32>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, inv, scale_vec, (float*)dx, part, M, H, lddy, ldx, lddx);
+  else if (dtype == DT_F32 && D == 64) hipLaunchKernelGGL((qk_norm_bwd_kernel<float, 64>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, inv, scale_vec, (float*)dx, part, M, H, lddy, ldx, lddx);
   else { ctclip_set_error("qk_norm: head dim must be 32 or 64"); return CTCLIP_EUNSUPPORTED; }
-  return ctclip_check_launch("qk_norm_bwd");
+  int rc = ctclip_check_launch("qk_norm_bwd");
+  if (rc || !dscale) return rc;
+  if (D == 32) hipLaunchKernelGGL(qk_scale_sum_kernel<32>, dim3(1), dim3(16 * 32), 0, stream, (const float*)part, (int)nblocks, dscale);
+  else hipLaunchKernelGGL(qk_scale_sum_kernel<64>, dim3(1), dim3(16 * 64), 0, stream, (const float*)part, (int)nblocks, dscale);
+  return ctclip_check_launch("qk_scale_sum");
 }
 
 // softmax(scale * q k^T + bias[h] + keymask[seq]) v   (attention.py:156-178 / HF BertSelfAttention).
@@ -1330,6 +1338,7 @@ static int dbias_nsplit(int nseq, int H, int L) {
 // (+ one slab for the full (H, L, L) gradient that the relative-position mode folds into the table)
 extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)(dbias_nsplit(nseq, H, L) + 1) * H * L * L * 4; }
 extern "C" int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
+int ctclip_dbias_fold(const float* part, int nsplit, float* bins_ws, float* dtab, int H, int gh, int gw, hipStream_t stream);   // attn2.hip
 
 // Backward.  Needs the transposed copies qt, kt (of q, k) and dot (of dout) and delta = rowsum(dO*O) (computed here
 // into `delta`, (nseq,H,L) f32 scratch).  dbias (H,L,L) f32 is ACCUMULATED when non-null; in the relative-position mode
@@ -1383,10 +1392,8 @@ extern "C" int ctclip_attn_bwd(const void* q, const void* k, const void* v, cons
     const int64_t n = (int64_t)H * L * L;
     int64_t nb = cdiv(n, 256); if (nb > 4096) nb = 4096;
     if (p.bias_tab) {   // table mode: slabs -> (nclass, H) in one pass (overwrites dbias)
-      const int ncls = (2 * p.gh - 1) * (2 * p.gw - 1);
-      if (hipMemsetAsync(dbias, 0, (size_t)ncls * H * 4, stream) != hipSuccess) { ctclip_set_error("attn_bwd: memset failed"); return CTCLIP_EBADARG; }
-      hipLaunchKernelGGL(dbias_fold_kernel, dim3((unsigned)cdiv(L, 16), H), dim3(256), 0, stream, (const float*)workspace, ns, dbias, H, p.gh, p.gw);
-      rc = ctclip_check_launch("dbias_fold");
+      // deterministic class bins (attn2.hip dbias_bin / dbias_sum); the bins live in the spare slab behind the ns partial slabs
+      rc = ctclip_dbias_fold((const float*)workspace, ns, (float*)workspace + (int64_t)ns * n, dbias, H, p.gh, p.gw, stream);
     } else {
       hipLaunchKernelGGL(dbias_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)workspace, dbias, ns, n, 1);
       rc = ctclip_check_launch("dbias_reduce");

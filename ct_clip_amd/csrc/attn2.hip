@@ -623,7 +623,7 @@ bool shape_ok(int H, int L, int gh, int gw, const float* tab) {
 }
 int dbias_splits(int nseq, int H, int L) {
   const int nkb = L / 32;
-  const int blocks = ((nkb + 1) / 2) * ((nkb + 3) / 4) * H;
+  const int blocks = ((nkb + 3) / 4) * ((nkb + 3) / 4) * H;       // workgroup tiles of the dBias kernels (4 x 4 blocks; the ring version 2 x 4)
   int ns = (1024 + blocks - 1) / blocks;
   if (ns > nseq) ns = nseq;
   if (ns > 8) ns = 8;
@@ -636,6 +636,15 @@ int num_cus() {
   return ncu;
 }
 }  // namespace
+
+// slabs [nsplit][H][L][L] -> table gradient (ncls, H), deterministic; bins_ws: cdiv(L, 16) * H * ncls floats of scratch
+int ctclip_dbias_fold(const float* part, int nsplit, float* bins_ws, float* dtab, int H, int gh, int gw, hipStream_t stream) {
+  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), nblk = (int)cdiv(L, 16);
+  if (ncls > MAXCLS) { ctclip_set_error("dbias_fold: too many offset classes"); return CTCLIP_EUNSUPPORTED; }
+  hipLaunchKernelGGL(dbias_bin_kernel, dim3((unsigned)nblk, H), dim3(256), 0, stream, part, nsplit, bins_ws, H, gh, gw);
+  hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)cdiv(ncls * H, 256)), dim3(256), 0, stream, (const float*)bins_ws, nblk, dtab, H, ncls);
+  return ctclip_check_launch("dbias_fold");
+}
 
 // 1 when ctclip_attn2_* serve this shape (bf16, d_head 32): L % 32 == 0, 64 <= L <= 1024; with a bias table gw % 8 == 0.
 extern "C" int ctclip_attn2_supported(int H, int L, int D_, int bias_gh, int bias_gw, int has_bias) {
@@ -729,13 +738,14 @@ extern "C" int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, 
   p.dbias_part = (float*)w; w += a256((int64_t)p.nsplit * H * L * L * 4);
   float* bins = (float*)w;
   const int nkb = L / 32;
-  hipLaunchKernelGGL(attn2_bwd_dbias_kernel, dim3((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, p.nsplit), dim3(512), 0, stream, p);
-  rc = ctclip_check_launch("attn2_bwd_dbias");
+  rc = attn2_slab_bwd_dbias(p, stream);
+  if (rc == 1) {
+    hipLaunchKernelGGL(attn2_bwd_dbias_kernel, dim3((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, p.nsplit), dim3(512), 0, stream, p);
+    rc = ctclip_check_launch("attn2_bwd_dbias");
+  }
   if (rc) return rc;
-  const int nblk = (int)cdiv(L, 16);
-  hipLaunchKernelGGL(dbias_bin_kernel, dim3((unsigned)nblk, H), dim3(256), 0, stream, (const float*)p.dbias_part, p.nsplit, bins, H, bias_gh, bias_gw);
-  hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)cdiv(ncls * H, 256)), dim3(256), 0, stream, (const float*)bins, nblk, dtab, H, ncls);
-  return ctclip_check_launch("attn2_dbias_fold");
+  (void)ncls;
+  return ctclip_dbias_fold(p.dbias_part, p.nsplit, bins, dtab, H, bias_gh, bias_gw, stream);
 }
 
 extern "C" int64_t ctclip_attn2_unprep_workspace(void) { return (int64_t)UNPREP_BLOCKS * 2 * 32 * 4; }

@@ -208,3 +208,4 @@ __device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70
 int attn2_slab_fwd(const ctclip_attn2::Params& p, hipStream_t stream);
 int attn2_slab_bwd_dq(const ctclip_attn2::Params& p, hipStream_t stream);
 int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream);
+int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream);

@@ -562,6 +562,124 @@ __global__ __launch_bounds__(NTH) void dkv_slab_kernel(Params p, Geo g, int item
   }
 }
 
+// ================================================================================================================== dBias
+// dBias[h][i][j] = sum over sequences of dS.  A workgroup of eight waves owns 4 query blocks x 4 key blocks of one head; wave (a, b)
+// holds the two tile pairs {2a, 2a+1} x {b} (shared K^ / V fragments, 32 accumulators) and walks a strided subset of the sequences.
+// Per sequence the 16 operand tiles (Q~, dO', K^, V of the four blocks each: 32 KB) are staged once, double-buffered, one barrier per
+// sequence and two independent tile pairs per wave between barriers.  (The first version: one pair per wave and barrier,
+// SQ_WAIT_ANY 61 %, 302 us.  128 registers -- two workgroups per CU -- spill: 300 B per lane.)
+constexpr int DB_W = 8, DB_NTH = DB_W * 64, DB_G = 4;
+constexpr int DB_TILES = 4 * DB_G;                                  // Q~ x4, dO' x4, K^ x4, V x4
+constexpr int DB_PIECES = (DB_TILES * 128 + DB_NTH - 1) / DB_NTH;   // 16-byte pieces per thread and sequence (128 per tile)
+
+template <bool SAFE>
+__device__ __forceinline__ void dbias_item(const Params& p, const SRel& rel, const Geo& g, char* tiles, float* stats, int h, int qg, int kg, int split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = p.L, nkb = L / 32;
+  const int wa = wave >> 2, wb = wave & 3;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  int qb[2]; bool qok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int qr = qg * DB_G + 2 * wa + i; qok[i] = qr < nkb; qb[i] = qok[i] ? qr : nkb - 1; }
+  const int kr = kg * DB_G + wb;
+  const bool kok = kr < nkb;
+  const int kb = kok ? kr : nkb - 1;
+  const int ucol[2] = {g.u(qb[0] * 32 + c), g.u(qb[1] * 32 + c)};
+  float acc[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // staging: piece = (tile, row, 16-byte chunk); tiles 0..3 Q~, 4..7 dO', 8..11 K^, 12..15 V of blocks group * 4 + (tile % 4)
+  const int64_t hbase = (int64_t)h * p.M * D;
+  auto piece_src = [&](int pc, int seq) -> const u32x4* {
+    const int tile = pc >> 7, row = (pc >> 2) & 31, chunk = pc & 3;
+    const int kind = tile / DB_G, blk = tile % DB_G;
+    const bf16_t* base = kind == 0 ? p.qh : kind == 1 ? p.dop : kind == 2 ? p.kh : p.vh;
+    int b = (kind < 2 ? qg : kg) * DB_G + blk;
+    b = b < nkb ? b : nkb - 1;
+    return reinterpret_cast<const u32x4*>(base + hbase + ((int64_t)seq * L + b * 32 + row) * D + chunk * 8);
+  };
+  auto piece_dst = [&](int pc) { const int tile = pc >> 7, row = (pc >> 2) & 31, chunk = pc & 3; return tile * TILE + swz(row, chunk); };
+  // statistics: threads 0 .. 4*64-1: [query block][lse2 | delta'][32]
+  const bool sth = (int)threadIdx.x < DB_G * 64;
+  auto stat_src = [&](int seq) {
+    int b = qg * DB_G + ((int)threadIdx.x >> 6);
+    b = b < nkb ? b : nkb - 1;
+    return (((int)threadIdx.x & 32) ? p.deltap : p.lse2) + (int64_t)h * p.M + (int64_t)seq * L + b * 32 + (threadIdx.x & 31);
+  };
+  int seq = split;
+  u32x4 st[DB_PIECES];
+  float sv = 0.f;
+#pragma unroll
+  for (int k = 0; k < DB_PIECES; ++k) st[k] = *piece_src(k * DB_NTH + (int)threadIdx.x, seq);
+  if (sth) sv = *stat_src(seq);
+#pragma unroll
+  for (int k = 0; k < DB_PIECES; ++k) *reinterpret_cast<u32x4*>(tiles + piece_dst(k * DB_NTH + (int)threadIdx.x)) = st[k];
+  if (sth) stats[threadIdx.x] = sv;
+  __syncthreads();
+  for (int it = 0; seq < p.nseq; seq += p.nsplit, ++it) {
+    const int buf = it & 1;
+    const int sn = seq + p.nsplit < p.nseq ? seq + p.nsplit : seq;
+#pragma unroll
+    for (int k = 0; k < DB_PIECES; ++k) st[k] = *piece_src(k * DB_NTH + (int)threadIdx.x, sn);
+    if (sth) sv = *stat_src(sn);
+    const char* tb = tiles + buf * DB_TILES * TILE;
+    const float* sb = stats + buf * DB_G * 64;
+    const Frag kf = lds_rows(tb + (2 * DB_G + wb) * TILE, ar, half);
+    const Frag vf = lds_rows(tb + (3 * DB_G + wb) * TILE, ar, half);
+    f32x16 s[2], dp[2];
+    Frag qf[2], dof[2];
+    float lse2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qt = 2 * wa + i;
+      qf[i] = lds_rows(tb + qt * TILE, c, half);                               // B operands: the lane's own query row
+      dof[i] = lds_rows(tb + (DB_G + qt) * TILE, c, half);
+      lse2[i] = sb[qt * 64 + c];
+      const float deltap = sb[qt * 64 + 32 + c];
+      s[i] = sbias<true, true>(rel, g, ucol[i], kb * 32, half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[i][r] = -deltap;
+    }
+    // four independent dependent-pairs of MFMAs, interleaved
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[0], qf[i].v[0], s[i], 0, 0, 0); dp[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[0], dof[i].v[0], dp[i], 0, 0, 0); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[1], qf[i].v[1], s[i], 0, 0, 0); dp[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v[1], dof[i].v[1], dp[i], 0, 0, 0); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = fmaf(__builtin_amdgcn_exp2f(SAFE ? s[i][r] : s[i][r] - lse2[i]), dp[i][r], acc[i][r]);
+    char* tn = tiles + (buf ^ 1) * DB_TILES * TILE;
+#pragma unroll
+    for (int k = 0; k < DB_PIECES; ++k) *reinterpret_cast<u32x4*>(tn + piece_dst(k * DB_NTH + (int)threadIdx.x)) = st[k];
+    if (sth) stats[(buf ^ 1) * DB_G * 64 + threadIdx.x] = sv;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!(qok[i] && kok)) continue;
+    float* dst = p.dbias_part + (((int64_t)split * p.H + h) * L + qb[i] * 32 + c) * L + kb * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[slot_index(r, half)] = acc[i][r];
+  }
+}
+
+__global__ __launch_bounds__(DB_NTH, 2) void dbias_slab_kernel(Params p, Geo g) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  SRel& rel = *reinterpret_cast<SRel*>(dyn);
+  float* stats = reinterpret_cast<float*>(dyn + SREL_BYTES);                       // [2][4][lse2 | delta'][32]
+  char* tiles = dyn + SREL_BYTES + 2 * DB_G * 64 * 4;                              // [2][16][TILE]
+  const int nkb = p.L / 32, ngrp = (nkb + DB_G - 1) / DB_G;
+  const int qg = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
+  stage_srel<true>(rel, p, g, h);                                                  // (NTH == DB_NTH)
+  if (split >= p.nseq) return;
+  if (rel.safe) dbias_item<true>(p, rel, g, tiles, stats, h, qg, kg, split);
+  else dbias_item<false>(p, rel, g, tiles, stats, h, qg, kg, split);
+}
+
 int num_cus() {
   static int ncu = 0;
   if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
@@ -608,3 +726,18 @@ bool raise_lds(K kern) { return hipFuncSetAttribute((const void*)kern, hipFuncAt
 int attn2_slab_fwd(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(fwd_slab_kernel, 0, "attn2_fwd (slab)") }
 int attn2_slab_bwd_dq(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(dq_slab_kernel, 0, "attn2_bwd_dq (slab)") }
 int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(dkv_slab_kernel, 2 * SL_MAX * 4, "attn2_bwd_dkv (slab)") }
+
+// dBias slabs (p.dbias_part, p.nsplit must be set): returns 1 when the shape is not eligible
+int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream) {
+  Geo g; size_t shm0;
+  if (!p.tab || !make_geo(p, g, 0, shm0)) return 1;
+  const size_t shm = (size_t)SREL_BYTES + 2 * DB_G * 64 * 4 + 2 * (size_t)DB_TILES * TILE;
+  static bool raised = false;
+  if (!raised) {
+    if (!raise_lds(dbias_slab_kernel)) { ctclip_set_error("attn2_bwd_dbias (slab): cannot raise the LDS limit"); return CTCLIP_EBADARG; }
+    raised = true;
+  }
+  const int nkb = p.L / 32, ngrp = (nkb + DB_G - 1) / DB_G;
+  hipLaunchKernelGGL(dbias_slab_kernel, dim3((unsigned)(ngrp * ngrp), p.H, p.nsplit), dim3(DB_NTH), shm, stream, p, g);
+  return ctclip_check_launch("attn2_bwd_dbias (slab)");
+}

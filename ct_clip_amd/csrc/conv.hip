@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256, PEG_MINB) void peg_kernel(const T* __restrict_
 // (taps d3 = 0, 1, 2), which are kept in a three-value register window.
 constexpr int WG_ROWS = 4;   // grid rows per thread
 template <typename T>
-__global__ __launch_bounds__(256) void peg_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw,
-                                                        float* __restrict__ db, int64_t nrows, int D1, int D2, int D3, int C) {
-  __shared__ float red[10][CCH];
+__global__ __launch_bounds__(256) void peg_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
+                                                        int64_t nrows, int D1, int D2, int D3, int C) {
+  __shared__ float red[16][10][CCH];        // [row lane][tap | bias][channel]: summed in a fixed order (no atomics)
   const int nchunk = (C + CCH - 1) / CCH;                 // channel chunk fastest (see peg_kernel)
   const int c0 = (int)(blockIdx.x % nchunk) * CCH, d1 = (int)((blockIdx.x / nchunk) % 3);
   const int64_t rgroup = blockIdx.x / (nchunk * 3);
@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) void peg_wgrad_kernel(const T* __restrict__ dy
     for (int e = 0; e < 4; ++e) tot[t][e] = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) totb[e] = 0.f;
-  for (int i = threadIdx.x; i < 10 * CCH; i += 256) red[i / CCH][i % CCH] = 0.f;
 
   if (ch < C) {
     for (int ri = 0; ri < WG_ROWS; ++ri) {
@@ -230,24 +229,39 @@ __global__ __launch_bounds__(256) void peg_wgrad_kernel(const T* __restrict__ dy
       for (int e = 0; e < 4; ++e) totb[e] += accb[e];
     }
   }
-  __syncthreads();
-  if (ch < C) {
+  {
+    const int rl = threadIdx.x >> 4;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[t][cl + e], tot[t][e]);
-    if (d1 == 2) {                                        // d1 = 2 is the plane a itself: every row is visited exactly once there
+      for (int e = 0; e < 4; ++e) red[rl][t][cl + e] = tot[t][e];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[9][cl + e], totb[e]);
-    }
+    for (int e = 0; e < 4; ++e) red[rl][9][cl + e] = totb[e];
   }
   __syncthreads();
+  // part[rgroup][channel][28]: taps d1*9 .. d1*9+8 from this block, the bias gradient (slot 27) from the d1 = 2 block only
+  // (d1 = 2 is the plane a itself: every row is visited exactly once there)
   for (int i = threadIdx.x; i < 10 * CCH; i += 256) {
     const int t = i / CCH, cc = i % CCH;
     if (c0 + cc >= C) continue;
-    if (t < 9) atomicAdd(dw + (int64_t)(c0 + cc) * 27 + d1 * 9 + t, red[t][cc]);
-    else if (d1 == 2 && db) atomicAdd(db + c0 + cc, red[9][cc]);
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r][t][cc];
+    float* dst = part + ((int64_t)rgroup * C + c0 + cc) * 28;
+    if (t < 9) dst[d1 * 9 + t] = v;
+    else if (d1 == 2) dst[27] = v;
   }
+}
+
+// dw[c][tap] += sum over row groups (in order) of part ; db[c] += ... slot 27
+__global__ __launch_bounds__(256) void peg_wgrad_reduce_kernel(const float* __restrict__ part, int nrg, int C, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 28) return;
+  const int c = i / 28, t = i % 28;
+  float v = 0.f;
+  for (int r = 0; r < nrg; ++r) v += part[((int64_t)r * C + c) * 28 + t];
+  if (t < 27) dw[(int64_t)c * 27 + t] += v;
+  else if (db) db[c] += v;
 }
 
 }  // namespace
@@ -264,19 +278,25 @@ extern "C" int ctclip_peg_fwd(const void* x, const float* w, const float* bias, 
   return ctclip_check_launch("peg_fwd");
 }
 
-// dx = dy + conv^T(dy) ; dw (C,27) and db (C) f32 are ACCUMULATED (+=) when non-null.
+// bytes of workspace ctclip_peg_bwd needs when dw is requested (per-row-group partial weight gradients)
+extern "C" int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C) { return cdiv(B * D1 * D2, 16 * WG_ROWS) * C * 28 * 4; }
+
+// dx = dy + conv^T(dy) ; dw (C,27) and db (C) f32 are ACCUMULATED (+=) when non-null (two stages, fixed summation order).
 extern "C" int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2,
-                              int D3, int C, int dtype, hipStream_t stream) {
+                              int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !w || !dx || C % 8) { ctclip_set_error("peg_bwd: bad args"); return CTCLIP_EBADARG; }
+  if (dw && (!workspace || workspace_bytes < ctclip_peg_bwd_workspace(B, D1, D2, C))) { ctclip_set_error("peg_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
   const int64_t nrows = B * D1 * D2;
   dim3 grid((unsigned)(cdiv(nrows, 16) * cdiv(C, CCH)));
   dim3 gridw((unsigned)(cdiv(nrows, 16 * WG_ROWS) * cdiv(C, CCH) * 3));
   if (dtype == DT_F32) {
     hipLaunchKernelGGL((peg_kernel<float, -1>), grid, dim3(256), 0, stream, (const float*)dy, w, nullptr, (float*)dx, nrows, D1, D2, D3, C);
-    if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<float>, gridw, dim3(256), 0, stream, (const float*)dy, (const float*)x, dw, db, nrows, D1, D2, D3, C);
+    if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<float>, gridw, dim3(256), 0, stream, (const float*)dy, (const float*)x, (float*)workspace, nrows, D1, D2, D3, C);
   } else if (dtype == DT_BF16) {
     hipLaunchKernelGGL((peg_kernel<bf16_t, -1>), grid, dim3(256), 0, stream, (const bf16_t*)dy, w, nullptr, (bf16_t*)dx, nrows, D1, D2, D3, C);
-    if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<bf16_t>, gridw, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, dw, db, nrows, D1, D2, D3, C);
+    if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<bf16_t>, gridw, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, nrows, D1, D2, D3, C);
   } else return CTCLIP_EUNSUPPORTED;
+  if (dw) hipLaunchKernelGGL(peg_wgrad_reduce_kernel, dim3((unsigned)cdiv(C * 28, 256)), dim3(256), 0, stream, (const float*)workspace,
+                             (int)cdiv(nrows, 16 * WG_ROWS), C, dw, db);
   return ctclip_check_launch("peg_bwd");
 }

@@ -47,6 +47,7 @@ struct GemmParams {
   const void* A; const void* B; void* C; const float* bias; const void* residual;
   int64_t M, N, K, lda, ldb, ldc, ldr;
   int out_dtype, res_dtype, accumulate, atomic_out;
+  float* slab;      // split-K partial results [split][M][N] (deterministic reduce afterwards); null = f32 atomics into C
   float alpha;
   int k_per_split;  // multiple of the k-tile
   int ntm, ntn;
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
           }
           if (p.out_dtype == DT_F32) {
             float* c = reinterpret_cast<float*>(p.C) + row * p.ldc + col;
-            if (p.atomic_out) atomicAdd(c, v);
+            if (p.slab) p.slab[((int64_t)blockIdx.y * p.M + row) * p.N + col] = v;
+            else if (p.atomic_out) atomicAdd(c, v);
             else *c = p.accumulate ? (*c + v) : v;
           } else {
             bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col;
@@ -303,6 +305,34 @@ __global__ void argmax_reduce_kernel(const float* __restrict__ pv, const int32_t
   }
   out[row] = bidx == 0x7fffffff ? 0 : bidx;       // a row of NaNs compares false everywhere: keep the index in range for the gather that follows
   if (out_val) out_val[row] = best;
+}
+
+// C (+)= sum over splits (in order) of slab[split]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ C, int64_t ldc,
+                                                            int64_t M, int64_t N, int accumulate) {
+  const int64_t n = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += slab[(int64_t)s * n + i];
+    float* c = C + (i / N) * ldc + i % N;
+    *c = accumulate ? *c + t : t;
+  }
+}
+
+// split factor of the generic kernel for (M, N, K): `split_k` <= 0 = auto (~2 resident 128^2 blocks per CU, f32 output only)
+int generic_split(int64_t M, int64_t N, int64_t K, int in_dtype, int out_dtype, int split_k, int* k_per_split) {
+  const int bk = in_dtype == DT_F32 ? 32 : 64;
+  const int64_t ktiles = cdiv(K, bk);
+  if (split_k <= 0) {
+    const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
+    split_k = (out_dtype == DT_F32 && tiles < 256) ? (int)(512 / tiles) : 1;
+    if (split_k > ktiles / 4) split_k = (int)(ktiles / 4);
+  }
+  if (split_k < 1) split_k = 1;
+  if (split_k > ktiles) split_k = (int)ktiles;
+  const int kps = (int)(cdiv(ktiles, split_k) * bk);
+  if (k_per_split) *k_per_split = kps;
+  return (int)cdiv(K, kps);
 }
 
 template <typename T, int EPI>
@@ -361,32 +391,30 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.out_dtype = out_dtype; p.res_dtype = res_dtype; p.accumulate = accumulate; p.alpha = alpha;
   p.ntm = (int)cdiv(M, BM); p.ntn = (int)cdiv(N, BN);
-  const int bk = in_dtype == DT_F32 ? 32 : 64;
-  int64_t ktiles = cdiv(K, bk);
-  if (split_k <= 0) {   // auto: ~2 resident 128^2 blocks per CU
-    const int64_t tiles = (int64_t)p.ntm * p.ntn;
-    split_k = (out_dtype == DT_F32 && tiles < 256) ? (int)(512 / tiles) : 1;
-    if (split_k > ktiles / 4) split_k = (int)(ktiles / 4);
-  }
-  if (split_k < 1) split_k = 1;
-  if (split_k > ktiles) split_k = (int)ktiles;
   if (split_k > 1 && out_dtype != DT_F32) { ctclip_set_error("gemm: split-K needs f32 output"); return CTCLIP_EUNSUPPORTED; }
-  p.k_per_split = (int)(cdiv(ktiles, split_k) * bk);
-  split_k = (int)cdiv(K, p.k_per_split);
+  split_k = generic_split(M, N, K, in_dtype, out_dtype, split_k, &p.k_per_split);
   p.atomic_out = split_k > 1;
-  if (p.atomic_out && !accumulate) {
+  const int64_t slab_bytes = (int64_t)split_k * M * N * 4;
+  if (split_k > 1 && workspace && workspace_bytes >= slab_bytes) p.slab = (float*)workspace;    // deterministic: slabs + ordered reduce
+  if (p.atomic_out && !p.slab && !accumulate) {
     if (hipMemset2DAsync(C, ldc * 4, 0, N * 4, M, stream) != hipSuccess) { ctclip_set_error("gemm: memset failed"); return -1000; }
   }
   dim3 grid(p.ntm * p.ntn, split_k);
-  if (in_dtype == DT_F32) return launch_layout<float, EPI_STD>(p, a_kc, b_kc, grid, stream);
-  return launch_layout<bf16_t, EPI_STD>(p, a_kc, b_kc, grid, stream);
+  rc = in_dtype == DT_F32 ? launch_layout<float, EPI_STD>(p, a_kc, b_kc, grid, stream) : launch_layout<bf16_t, EPI_STD>(p, a_kc, b_kc, grid, stream);
+  if (rc || !p.slab) return rc;
+  int64_t nb = cdiv(M * N, 256); if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)p.slab, split_k, (float*)C, ldc, M, N, accumulate);
+  return ctclip_check_launch("gemm split-K reduce");
 }
 
 // bytes of optional workspace for ctclip_gemm (split-K partial slabs of the large-tile bf16 path); split_k <= 0 means "auto"
 extern "C" int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k) {
-  if (in_dtype != DT_BF16) return 0;
+  const int gs = generic_split(M, N, K, in_dtype, DT_F32, split_k, nullptr);
+  const int64_t wgen = gs > 1 ? (int64_t)gs * M * N * 4 : 0;         // generic kernel: split-K slabs (without them: f32 atomics)
+  if (in_dtype != DT_BF16) return wgen;
   const int64_t w256 = ctclip_gemm256_workspace(M, N, K, split_k), wtn = ctclip_gemm_tn_workspace(M, N, K, split_k);
-  return w256 > wtn ? w256 : wtn;   // (layout-agnostic entry point: enough for whichever kernel the dispatcher picks)
+  const int64_t w = w256 > wtn ? w256 : wtn;
+  return w > wgen ? w : wgen;       // (layout-agnostic entry point: enough for whichever kernel the dispatcher picks)
 }
 
 // Row-wise arg-max of A B^T without materialising the product (vector-quantiser code assignment:

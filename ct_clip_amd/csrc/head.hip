@@ -10,9 +10,10 @@ namespace {
 constexpr int VL_MAXB = 8;    // rows of X per call (the host loops over chunks of 8 samples)
 constexpr int VL_KCH = 2048;  // k-chunk per block
 
-// Y[b][n] += sum_{k in chunk} X[b][k] * W[n][k].  block = 4 waves x 4 weight rows; X chunk staged in LDS as f32.
+// part[chunk][b][n] = sum_{k in chunk} X[b][k] * W[n][k].  block = 4 waves x 4 weight rows; X chunk staged in LDS as f32.
+// (The k-chunks are combined by vlat_reduce_kernel in chunk order: the first version added them with f32 atomics.)
 template <typename T>
-__global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, const T* __restrict__ W, float* __restrict__ Y, int Bm,
+__global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, const T* __restrict__ W, float* __restrict__ part, int Bm,
                                                        int N, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [Bm][VL_KCH]
   const int64_t k0 = (int64_t)blockIdx.y * VL_KCH;
@@ -63,9 +64,17 @@ __global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, 
     for (int b = 0; b < VL_MAXB; ++b) {
       if (b < Bm) {
         const float t = wave_sum(acc[r][b]);
-        if (lane == 0 && n0 + r < N) atomicAdd(Y + (int64_t)b * N + n0 + r, t);
+        if (lane == 0 && n0 + r < N) part[((int64_t)blockIdx.y * Bm + b) * N + n0 + r] = t;
       }
     }
+}
+
+__global__ __launch_bounds__(256) void vlat_reduce_kernel(const float* __restrict__ part, int nchunk, int n, float* __restrict__ Y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.f;
+  for (int c = 0; c < nchunk; ++c) t += part[(int64_t)c * n + i];
+  Y[i] = t;
 }
 
 // Each thread owns 8 consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
@@ -222,10 +231,15 @@ __global__ void scale_by_scalar_kernel(float* __restrict__ x, const float* __res
 
 }  // namespace
 
-// Y (Bm, N) f32 = X (Bm, K) W^T (N, K).  Y must be zero on entry (split-K partial sums are added atomically).
-extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, hipStream_t s) {
+extern "C" int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K) { return cdiv(K, VL_KCH) * (int64_t)Bm * N * 4; }
+// Y (Bm, N) f32 = X (Bm, K) W^T (N, K) (overwritten).  workspace >= ctclip_visual_latent_fwd_workspace(Bm, N, K): the k-chunk partial
+// sums, combined in chunk order (deterministic).
+extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, void* workspace,
+                                        int64_t workspace_bytes, hipStream_t s) {
   if (!X || !W || !Y || Bm < 1 || Bm > VL_MAXB || K % 8) { ctclip_set_error("visual_latent_fwd: batch must be 1..8 per call and K a multiple of 8"); return CTCLIP_EBADARG; }
-  dim3 grid((unsigned)cdiv(N, 16), (unsigned)cdiv(K, VL_KCH));
+  if (!workspace || workspace_bytes < ctclip_visual_latent_fwd_workspace(Bm, N, K)) { ctclip_set_error("visual_latent_fwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int nchunk = (int)cdiv(K, VL_KCH);
+  dim3 grid((unsigned)cdiv(N, 16), (unsigned)nchunk);
   const size_t shm = (size_t)Bm * VL_KCH * sizeof(float);
   static bool raised = false;
   if (!raised) {
@@ -233,9 +247,11 @@ extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, 
     (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     raised = true;
   }
-  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_fwd_kernel<float>, grid, dim3(256), shm, s, (const float*)X, (const float*)W, Y, Bm, N, K);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_fwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)X, (const bf16_t*)W, Y, Bm, N, K);
+  float* part = (float*)workspace;
+  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_fwd_kernel<float>, grid, dim3(256), shm, s, (const float*)X, (const float*)W, part, Bm, N, K);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_fwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)X, (const bf16_t*)W, part, Bm, N, K);
   else return CTCLIP_EUNSUPPORTED;
+  hipLaunchKernelGGL(vlat_reduce_kernel, dim3((unsigned)cdiv(Bm * N, 256)), dim3(256), 0, s, (const float*)part, nchunk, Bm * N, Y);
   return ctclip_check_launch("visual_latent_fwd");
 }
 // dX (Bm, K) in `dtype` (may be null), dW (N, K) f32 overwritten or accumulated (may be null).

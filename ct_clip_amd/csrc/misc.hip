@@ -70,7 +70,7 @@ __global__ void leaky_bwd_kernel(const float* __restrict__ dy, const float* __re
 
 // ---- out[n] += sum_m x[m][n]   (bias gradients).  block: 32 column-groups of 8 x 8 row lanes; 512 rows per block
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ld) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t M, int N, int64_t ld) {
   __shared__ float red[8][256];
   const int cgp = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.y * 32 + cgp) * 8;
@@ -94,19 +94,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
-    atomicAdd(out + col, t);
+    part[(int64_t)blockIdx.x * N + col] = t;          // per-row-block partial: summed in block order by colsum_reduce_kernel
   }
+}
+// out[col] += sum over row blocks (in order) of part[block][col]
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblk, int N, float* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * N + col];
+  out[col] += t;
 }
 
 // generic fallback (any N / pitch): one thread per column, 64 rows per block row-lane
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ld) {
+__global__ __launch_bounds__(256) void colsum_generic_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t M, int N, int64_t ld) {
+  __shared__ float red[4][64];
   const int col = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  if (col >= N) return;
   float acc = 0.f;
   const int64_t r0 = (int64_t)blockIdx.x * 1024;
-  for (int64_t r = r0 + rl; r < r0 + 1024 && r < M; r += 4) acc += Elem<T>::ld(x + r * ld + col);
-  atomicAdd(out + col, acc);
+  if (col < N)
+    for (int64_t r = r0 + rl; r < r0 + 1024 && r < M; r += 4) acc += Elem<T>::ld(x + r * ld + col);
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < N) part[(int64_t)blockIdx.x * N + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- (A, B, C, D) -> (A, C, B, D)   (ctvit.py:297-305 rearranges between the spatial and temporal phases)
@@ -253,22 +264,7 @@ __global__ void bert_embed_fwd_kernel(const int64_t* __restrict__ ids, const flo
     store4(x + r * Hd + c, o);
   }
 }
-template <typename T>
-__global__ void bert_embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx, float* __restrict__ dword,
-                                      float* __restrict__ dpos, float* __restrict__ dtype0, int64_t rows, int Tlen, int Hd) {
-  const int G = Hd / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * G; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / G; const int c = (int)(i % G) * 4;
-    float g[4];
-    load4(dx + r * Hd + c, g);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (dword) atomicAdd(dword + ids[r] * Hd + c + e, g[e]);
-      if (dpos) atomicAdd(dpos + (r % Tlen) * Hd + c + e, g[e]);
-      if (dtype0) atomicAdd(dtype0 + c + e, g[e]);
-    }
-  }
-}
+// (the embedding-table gradients are deterministic segmented sums: segsum.hip)
 
 // ---- vector quantiser (vector_quantize_pytorch 1.1.2 cosine codebook; called at ctvit.py:403)
 template <typename T>
@@ -281,21 +277,7 @@ __global__ void vq_gather_kernel(const float* __restrict__ embed, const int64_t*
     store4(out + r * d + c, v);
   }
 }
-// bins[code] += 1 ; esum[code] += xn[row]   (f32 atomics: order-independent up to f32 rounding)
-template <typename T>
-__global__ void vq_ema_accum_kernel(const int64_t* __restrict__ idx, const T* __restrict__ xn, float* __restrict__ bins,
-                                    float* __restrict__ esum, int64_t M, int d) {
-  const int G = d / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * G; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / G; const int g = (int)(i % G);
-    const int64_t code = idx[r];
-    float v[4];
-    load4(xn + r * d + g * 4, v);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(esum + code * d + g * 4 + e, v[e]);
-    if (g == 0) atomicAdd(bins + code, 1.f);
-  }
-}
+// (bins / esum: deterministic segmented sums, segsum.hip)
 // one wave per code: cluster_size <- lerp ; embed <- decay*embed + (1-decay)*(bins ? l2norm(esum/bins) : l2norm(embed))
 __global__ __launch_bounds__(256) void vq_ema_update_kernel(float* __restrict__ cluster, float* __restrict__ embed,
                                                             const float* __restrict__ bins, const float* __restrict__ esum, int C, int d,
@@ -352,15 +334,25 @@ extern "C" int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx,
   return ctclip_check_launch("leaky_relu_bwd");
 }
 // out (f32, N) += column sums of x (M, N)
-extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, hipStream_t s) {
+extern "C" int64_t ctclip_colsum_workspace(int64_t M, int N) { return cdiv(M, 512) * (int64_t)N * 4; }
+// out[0:N] += column sums of x (M, N) -- bias gradients of the Linear layers.  Two stages with a fixed summation order (the first
+// version added per-block partial sums with f32 atomics); workspace >= ctclip_colsum_workspace(M, N) bytes.
+extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* workspace, int64_t workspace_bytes,
+                             hipStream_t s) {
   if (!x || !out) { ctclip_set_error("colsum: null argument"); return CTCLIP_EBADARG; }
+  if (!workspace || workspace_bytes < ctclip_colsum_workspace(M, N)) { ctclip_set_error("colsum: workspace too small"); return CTCLIP_EWORKSPACE; }
+  float* part = (float*)workspace;
+  int nblk;
   if (N % 8 || ld % 8 || ((uintptr_t)x % 16)) {
-    dim3 gridg((unsigned)cdiv(M, 1024), (unsigned)cdiv(N, 64));
-    BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_generic_kernel<T>, gridg, dim3(256), 0, s, (const T*)x, out, M, N, ld));
-    return ctclip_check_launch("colsum");
+    nblk = (int)cdiv(M, 1024);
+    dim3 gridg((unsigned)nblk, (unsigned)cdiv(N, 64));
+    BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_generic_kernel<T>, gridg, dim3(256), 0, s, (const T*)x, part, M, N, ld));
+  } else {
+    nblk = (int)cdiv(M, 512);
+    dim3 grid((unsigned)nblk, (unsigned)cdiv(N, 256));
+    BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, part, M, N, ld));
   }
-  dim3 grid((unsigned)cdiv(M, 512), (unsigned)cdiv(N, 256));
-  BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, out, M, N, ld));
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, (const float*)part, nblk, N, out);
   return ctclip_check_launch("colsum");
 }
 extern "C" int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s) {
@@ -429,21 +421,10 @@ extern "C" int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, cons
   BY_DTYPE(dtype, hipLaunchKernelGGL(bert_embed_fwd_kernel<T>, grid_for(rows * Hd / 4), dim3(256), 0, s, ids, word, pos, type0, (T*)x, rows, Tlen, Hd));
   return ctclip_check_launch("bert_embed_fwd");
 }
-extern "C" int ctclip_bert_embed_bwd(const int64_t* ids, const void* dx, float* dword, float* dpos, float* dtype0, int64_t rows, int Tlen,
-                                     int Hd, int dtype, hipStream_t s) {
-  if (!ids || !dx || Hd % 8) { ctclip_set_error("bert_embed_bwd: bad args"); return CTCLIP_EBADARG; }
-  BY_DTYPE(dtype, hipLaunchKernelGGL(bert_embed_bwd_kernel<T>, grid_for(rows * Hd / 4), dim3(256), 0, s, ids, (const T*)dx, dword, dpos, dtype0, rows, Tlen, Hd));
-  return ctclip_check_launch("bert_embed_bwd");
-}
 extern "C" int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t M, int d, int dtype, hipStream_t s) {
   if (!embed || !idx || !out || d % 8) { ctclip_set_error("vq_gather: bad args"); return CTCLIP_EBADARG; }
   BY_DTYPE(dtype, hipLaunchKernelGGL(vq_gather_kernel<T>, grid_for(M * d / 4), dim3(256), 0, s, embed, idx, (T*)out, M, d));
   return ctclip_check_launch("vq_gather");
-}
-extern "C" int ctclip_vq_ema_accum(const int64_t* idx, const void* xn, float* bins, float* esum, int64_t M, int d, int dtype, hipStream_t s) {
-  if (!idx || !xn || !bins || !esum || d % 8) { ctclip_set_error("vq_ema_accum: bad args"); return CTCLIP_EBADARG; }
-  BY_DTYPE(dtype, hipLaunchKernelGGL(vq_ema_accum_kernel<T>, grid_for(M * d / 4), dim3(256), 0, s, idx, (const T*)xn, bins, esum, M, d));
-  return ctclip_check_launch("vq_ema_accum");
 }
 extern "C" int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s) {
   if (!cluster || !embed || !bins || !esum) return CTCLIP_EBADARG;

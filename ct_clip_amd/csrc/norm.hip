@@ -132,27 +132,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] += sum_b part[b][which][c]; block = 64 columns x 4 partial-lanes over one chunk of 64 partial rows (grid.y chunks, one
-// f32 atomic per column and chunk).  The first version walked all 1024 partial rows with 16 workgroups: 58 us of pure latency,
-// 76 times per step.
-constexpr int LN_RED_CHUNK = 64;
-__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int nblocks, int cols) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  const int b0 = blockIdx.y * LN_RED_CHUNK, b1 = b0 + LN_RED_CHUNK < nblocks ? b0 + LN_RED_CHUNK : nblocks;
+// out[c] += sum_b part[b][which][c].  One workgroup of 1024 threads per 64 columns: sixteen interleaved slices of the partial rows are
+// summed in parallel and combined in a fixed order (deterministic: the previous version combined chunks with f32 atomics; the
+// first version walked all 1024 partial rows with 16 workgroups of 64 threads: 58 us of pure latency, 76 times per step).
+constexpr int LN_RED_CHUNK = 64;      // (kept for the launch-shape arithmetic of the callers)
+__global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int nblocks, int cols) {
+  __shared__ float red[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
   float t = 0.f;
   if (c < 2 * cols) {
     const int which = c / cols, col = c % cols;
 #pragma unroll 4
-    for (int b = b0 + pl; b < b1; b += 4) t += part[((int64_t)b * 2 + which) * cols + col];
+    for (int b = sl; b < nblocks; b += 16) t += part[((int64_t)b * 2 + which) * cols + col];
   }
-  red[pl][threadIdx.x & 63] = t;
+  red[sl][threadIdx.x & 63] = t;
   __syncthreads();
-  if (pl == 0 && c < 2 * cols) {
+  if (sl == 0 && c < 2 * cols) {
     const int which = c / cols, col = c % cols;
     float* dst = which == 0 ? dgamma : dbeta;
-    if (dst) atomicAdd(dst + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red[i][threadIdx.x];
+    if (dst) dst[col] += a;
   }
 }
 
@@ -329,7 +331,7 @@ extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* 
 #undef LNB_NV
   int rc = ctclip_check_launch("layernorm_bwd");
   if (rc || !want) return rc;
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64), (unsigned)cdiv(nb, LN_RED_CHUNK)), dim3(256), 0, stream, part, dgamma, dbeta, (int)nb, cols);
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, stream, part, dgamma, dbeta, (int)nb, cols);
   return ctclip_check_launch("ln_partial_reduce");
 }
 

@@ -29,8 +29,11 @@ int ctclip_head_transpose(const void* x, void* xt, int nseq, int H, int L, int L
 /* l2norm(q)*q_scale / l2norm(k)*k_scale per head (attention.py:152-154). */
 int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y, float* inv, int64_t M, int H, int D, int64_t ldx, int64_t ldy, int dtype, hipStream_t stream);
 
+/* TODO: document */
+int64_t ctclip_qk_norm_bwd_workspace(int64_t M, int H, int D);
+
 /* backward of the above; dscale (D) ACCUMULATED. */
-int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, hipStream_t stream);
+int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* softmax(scale*q k^T + bias[h] + keymask[seq]) v (attention.py:156-178; HF BertSelfAttention). */
 int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw, const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p, uint64_t dropout_seed, int dtype, hipStream_t stream);
@@ -74,8 +77,11 @@ const char* ctclip_target_arch(void);
 /* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
 int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
+/* TODO: document */
+int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C);
+
 /* backward of the above; dw (C,27) / db (C) ACCUMULATED, may be NULL. */
-int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
+int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* TODO: document */
 int ctclip_relu_dropout(const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
@@ -98,8 +104,11 @@ int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
 /* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
 int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* TODO: document */
+int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
+
 /* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767). */
-int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, hipStream_t s);
+int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* backward of the above (dX and dW). */
 int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K, int accumulate, int dtype, hipStream_t s);
@@ -128,8 +137,11 @@ int ctclip_leaky_relu_fwd(const float* x, float* y, int64_t n, float slope, hipS
 /* backward of LeakyReLU. */
 int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, float slope, hipStream_t s);
 
+/* TODO: document */
+int64_t ctclip_colsum_workspace(int64_t M, int N);
+
 /* bias gradients: out[n] += sum_m x[m][n]. */
-int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, hipStream_t s);
+int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* rearrange '(b t)(h w) d <-> (b h w) t d' between the spatial and temporal phases (ctvit.py:297-305). */
 int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s);
@@ -161,14 +173,8 @@ int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint6
 /* HF BertEmbeddings: word + position + token_type(0) lookup. */
 int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows, int Tlen, int Hd, int dtype, hipStream_t s);
 
-/* scatter-add of the embedding gradients (f32 atomics). */
-int ctclip_bert_embed_bwd(const int64_t* ids, const void* dx, float* dword, float* dpos, float* dtype0, int64_t rows, int Tlen, int Hd, int dtype, hipStream_t s);
-
 /* quantize = embed[ind] (vector_quantize_pytorch, ctvit.py:403). */
 int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t M, int d, int dtype, hipStream_t s);
-
-/* VQ EMA statistics: bins (histogram) and embed_sum (segmented sum of normalised inputs). */
-int ctclip_vq_ema_accum(const int64_t* idx, const void* xn, float* bins, float* esum, int64_t M, int d, int dtype, hipStream_t s);
 
 /* VQ EMA buffer update (decay 0.8) of cluster_size and embed. */
 int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s);
