@@ -439,8 +439,8 @@ class HipBackend:
             self.segment_sum(ids.reshape(-1), dx, dword, dword.shape[0], accumulate=True)
         if dpos is not None:
             self.segment_sum(None, dx, dpos, dpos.shape[0], accumulate=True, key_mod=T)
-        if dtype0 is not None:
-            self.segment_sum(None, dx, dtype0[:1], 1, accumulate=True, key_mod=1)
+        if dtype0 is not None:            # every row has token type 0: a plain (deterministic) column sum
+            self.colsum(dx, dtype0[0])
 
     # ------------------------------------------------------------------ VQ
     def vq_gather(self, embed, idx, dtype):

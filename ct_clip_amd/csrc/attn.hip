@@ -1335,8 +1335,8 @@ static int dbias_nsplit(int nseq, int H, int L) {
   return ns;
 }
 // bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs)
-// (+ one slab for the full (H, L, L) gradient that the relative-position mode folds into the table)
-extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)(dbias_nsplit(nseq, H, L) + 1) * H * L * L * 4; }
+// (+ two slabs of scratch for the class bins of the deterministic fold in the relative-position mode)
+extern "C" int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L) { return (int64_t)(dbias_nsplit(nseq, H, L) + 2) * H * L * L * 4; }
 extern "C" int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
 int ctclip_dbias_fold(const float* part, int nsplit, float* bins_ws, float* dtab, int H, int gh, int gw, hipStream_t stream);   // attn2.hip
 

@@ -460,22 +460,27 @@ __global__ __launch_bounds__(512) void attn2_bwd_dbias_kernel(Params p) {
 // slabs -> table gradient (ncls, H): class bins in LDS, one workgroup per (16 query rows, head); rows and splits are summed in a
 // fixed order and the per-workgroup bins are written to a second slab that the last stage adds up in index order (no atomics on
 // floating-point data reach global memory).
+constexpr int DBIN_ROWS = 4;      // query rows per workgroup (16 at first: 103 us, a serial chain of rows x slabs)
 __global__ __launch_bounds__(256) void dbias_bin_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ bins_out, int H, int gh, int gw) {
   __shared__ float bins[MAXCLS];
   const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), h = blockIdx.y;
   for (int i = threadIdx.x; i < ncls; i += 256) bins[i] = 0.f;
   __syncthreads();
   const int64_t n = (int64_t)H * L * L;
-  const int q0 = blockIdx.x * 16;
+  const int q0 = blockIdx.x * DBIN_ROWS;
   // a class (dy, dx) receives, from one query row, at most one key: different rows are handled one after the other, so that every
   // bin sees a fixed summation order and no two threads of a step touch the same bin
-  for (int qr = 0; qr < 16; ++qr) {
+  for (int qr = 0; qr < DBIN_ROWS; ++qr) {
     const int qi = q0 + qr;
     if (qi >= L) break;
     for (int kj = threadIdx.x; kj < L; kj += 256) {
       const int64_t off = ((int64_t)h * L + qi) * L + kj;
+      float v[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) v[s] = s < nsplit ? part[(int64_t)s * n + off] : 0.f;      // independent loads (nsplit <= 8)
       float t = 0.f;
-      for (int s = 0; s < nsplit; ++s) t += part[(int64_t)s * n + off];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t += v[s];
       bins[(qi / gw - kj / gw + gh - 1) * (2 * gw - 1) + (qi % gw - kj % gw + gw - 1)] += t;
     }
     __syncthreads();
@@ -637,9 +642,9 @@ int num_cus() {
 }
 }  // namespace
 
-// slabs [nsplit][H][L][L] -> table gradient (ncls, H), deterministic; bins_ws: cdiv(L, 16) * H * ncls floats of scratch
+// slabs [nsplit][H][L][L] -> table gradient (ncls, H), deterministic; bins_ws: cdiv(L, DBIN_ROWS) * H * ncls floats of scratch
 int ctclip_dbias_fold(const float* part, int nsplit, float* bins_ws, float* dtab, int H, int gh, int gw, hipStream_t stream) {
-  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), nblk = (int)cdiv(L, 16);
+  const int L = gh * gw, ncls = (2 * gh - 1) * (2 * gw - 1), nblk = (int)cdiv(L, DBIN_ROWS);
   if (ncls > MAXCLS) { ctclip_set_error("dbias_fold: too many offset classes"); return CTCLIP_EUNSUPPORTED; }
   hipLaunchKernelGGL(dbias_bin_kernel, dim3((unsigned)nblk, H), dim3(256), 0, stream, part, nsplit, bins_ws, H, gh, gw);
   hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)cdiv(ncls * H, 256)), dim3(256), 0, stream, (const float*)bins_ws, nblk, dtab, H, ncls);
@@ -692,7 +697,7 @@ extern "C" int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_g
   int64_t n = a256(H * M * D * 2) + a256(H * M * 4);                                   // dO', delta'
   if (bias_gh > 0) {
     const int ncls = (2 * bias_gh - 1) * (2 * bias_gw - 1);
-    n += a256((int64_t)dbias_splits(nseq, H, L) * H * L * L * 4) + a256((int64_t)cdiv(L, 16) * H * ncls * 4);
+    n += a256((int64_t)dbias_splits(nseq, H, L) * H * L * L * 4) + a256((int64_t)cdiv(L, DBIN_ROWS) * H * ncls * 4);
   }
   return n;
 }
