@@ -75,6 +75,7 @@ SIGNATURES = {
     "ctclip_relu_dropout": (_I, [_P, _P, _P, _L, _F, _U64, _U32, _P]),
     "ctclip_bce_logits": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "ctclip_pair_softmax_mse": (_I, [_P, _P, _P, _I, _P]),
+    "ctclip_latent_similarity": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ctclip_grad_norm_workspace": (_L, []),
     "ctclip_grad_norm_clip": (_I, [_P, _L, _P, _F, _P, _P, _L, _P]),
     "ctclip_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P, _P]),

@@ -531,6 +531,22 @@ class HipBackend:
         _lib.check(self.lib.ctclip_pair_softmax_mse(_p(sims), _p(loss), _p(dsims), n, _stream()), "ctclip_pair_softmax_mse")
         return loss, dsims
 
+    def latent_similarity(self, text, image, temperature, dsims=None):
+        """forward: sims (max(nt, ni)); backward (dsims given): (dtext, dimage, dtemp)."""
+        nt, D = text.shape
+        ni = image.shape[0]
+        assert text.dtype == image.dtype == torch.float32 and text.is_contiguous() and image.is_contiguous() and image.shape[1] == D
+        if dsims is None:
+            sims = torch.empty(max(nt, ni), dtype=torch.float32, device=text.device)
+            _lib.check(self.lib.ctclip_latent_similarity(_p(text), _p(image), _p(temperature), None, _p(sims), None, None, None, nt, ni, D,
+                                                         _stream()), "ctclip_latent_similarity")
+            return sims
+        dt, di = torch.empty_like(text), torch.empty_like(image)
+        dtemp = torch.empty(1, dtype=torch.float32, device=text.device)
+        _lib.check(self.lib.ctclip_latent_similarity(_p(text), _p(image), _p(temperature), _p(dsims), None, _p(dt), _p(di), _p(dtemp), nt, ni, D,
+                                                     _stream()), "ctclip_latent_similarity")
+        return dt, di, dtemp
+
     # ------------------------------------------------------------------ optimiser
     def grad_norm_clip(self, g, max_norm, extra_sq=None):
         out = torch.empty(2, dtype=torch.float32, device=g.device)

@@ -62,6 +62,42 @@ __global__ __launch_bounds__(64) void pair_softmax_mse_kernel(const float* __res
   if (threadIdx.x == 0) loss[0] = s / (2.f * n);
 }
 
+// sims[p] = <t / |t|, v / |v|> * exp(temperature) for pair p of (text row, image row), either side broadcast when it has one row.
+// One workgroup walks the pairs in order, each thread owning fixed columns, so the broadcast side's gradient accumulates in a fixed order.
+__global__ __launch_bounds__(256) void latent_similarity_kernel(const float* __restrict__ text, const float* __restrict__ image,
+                                                                const float* __restrict__ temperature, const float* __restrict__ dsims,
+                                                                float* __restrict__ sims, float* __restrict__ dtext, float* __restrict__ dimage,
+                                                                float* __restrict__ dtemp, int nt, int ni, int D, float eps) {
+  __shared__ float red[16];
+  const int n = nt > ni ? nt : ni;
+  const float et = __expf(temperature[0]);
+  if (dsims) {
+    for (int i = threadIdx.x; i < nt * D; i += 256) dtext[i] = 0.f;
+    for (int i = threadIdx.x; i < ni * D; i += 256) dimage[i] = 0.f;
+  }
+  float dtacc = 0.f;
+  for (int p = 0; p < n; ++p) {
+    const float* t = text + (int64_t)(nt == 1 ? 0 : p) * D;
+    const float* v = image + (int64_t)(ni == 1 ? 0 : p) * D;
+    float tt = 0.f, vv = 0.f, tv = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) { const float a = t[c], b = v[c]; tt += a * a; vv += b * b; tv += a * b; }
+    tt = block_sum(tt, red); vv = block_sum(vv, red); tv = block_sum(tv, red);
+    const float it = 1.f / fmaxf(sqrtf(tt), eps), iv = 1.f / fmaxf(sqrtf(vv), eps);
+    const float cosv = tv * it * iv;
+    if (!dsims) { if (threadIdx.x == 0) sims[p] = cosv * et; continue; }
+    const float g = dsims[p] * et;
+    dtacc += dsims[p] * cosv * et;
+    float* dt = dtext + (int64_t)(nt == 1 ? 0 : p) * D;
+    float* dv = dimage + (int64_t)(ni == 1 ? 0 : p) * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float a = t[c] * it, b = v[c] * iv;           // unit rows
+      dt[c] += g * (b - cosv * a) * it;
+      dv[c] += g * (a - cosv * b) * iv;
+    }
+  }
+  if (dsims && threadIdx.x == 0) dtemp[0] = dtacc;
+}
+
 }  // namespace
 
 // image_latents = relu(latents) then nn.Dropout(p) in train mode (ct_lipro_train.py:33-36).  dy == null: forward (out = y);
@@ -88,4 +124,16 @@ extern "C" int ctclip_pair_softmax_mse(const float* sims, float* loss, float* ds
   if (!sims || !loss || n < 1) { ctclip_set_error("pair_softmax_mse: bad args"); return CTCLIP_EBADARG; }
   hipLaunchKernelGGL(pair_softmax_mse_kernel, dim3(1), dim3(64), 0, s, sims, loss, dsims, n);
   return ctclip_check_launch("pair_softmax_mse");
+}
+
+// CTCLIP.forward without return_loss (ct_clip.py:771,796,805-807): l2norm both latents, einsum('b d, b d -> b') with broadcasting
+// (two prompts against one volume in the zero-shot and VocabFine loops), times exp(temperature).
+// text (nt, D), image (ni, D) f32 pre-normalisation latents; nt == ni or one of them 1.  dsims == null: forward, sims (max(nt, ni)).
+// dsims != null: backward, dtext (nt, D), dimage (ni, D), dtemp (1) are overwritten.
+extern "C" int ctclip_latent_similarity(const float* text, const float* image, const float* temperature, const float* dsims, float* sims,
+                                        float* dtext, float* dimage, float* dtemp, int nt, int ni, int D, hipStream_t s) {
+  if (!text || !image || !temperature || nt < 1 || ni < 1 || D < 1 || (nt != ni && nt != 1 && ni != 1)) { ctclip_set_error("latent_similarity: nt == ni or one side has a single row"); return CTCLIP_EBADARG; }
+  if (dsims ? (!dtext || !dimage || !dtemp) : !sims) { ctclip_set_error("latent_similarity: missing output"); return CTCLIP_EBADARG; }
+  hipLaunchKernelGGL(latent_similarity_kernel, dim3(1), dim3(256), 0, s, text, image, temperature, dsims, sims, dtext, dimage, dtemp, nt, ni, D, 1e-12f);
+  return ctclip_check_launch("latent_similarity");
 }

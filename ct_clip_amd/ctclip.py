@@ -141,8 +141,7 @@ class CTCLIP(nn.Module):
             return Fn.l2norm_f32(text_lat), Fn.l2norm_f32(image_lat), enc_tokens
         if not return_loss:
             # ct_clip.py:805-807: einsum('b d, b d -> b') * temp with broadcasting (e.g. 2 prompts vs 1 volume)
-            tl, il = Fn.l2norm_f32(text_lat), Fn.l2norm_f32(image_lat)
-            return (tl * il).sum(-1) * self.temperature.exp()
+            return Fn.LatentSimilarityFn.apply(text_lat, image_lat, self.temperature)
         assert Bt == Bi, "contrastive loss needs as many texts as volumes"
         replicas = 1
         if self.gather_negatives and _dist.world_size() > 1:

@@ -705,6 +705,39 @@ class BertEmbedFn(Function):
         return None, (None if ws is not None else dw), (None if ps is not None else dp), (None if ts is not None else dt), None
 
 
+class _L2NormF32Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, _ = B().l2norm_rows(x.contiguous(), torch.float32)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raise NotImplementedError("return_latents=True is an inference output here (ct_lipro_train.py runs it under no_grad); "
+                                  "gradients flow through the similarity / contrastive-loss kernels instead")
+
+
 def l2norm_f32(x):
-    y, _ = B().l2norm_rows(x.contiguous(), torch.float32)
-    return y
+    return _L2NormF32Fn.apply(x)
+
+
+class LatentSimilarityFn(Function):
+    """ct_clip.py:771,796,805-807: l2norm both latents, pairwise dot with broadcasting, * exp(temperature)."""
+
+    @staticmethod
+    def forward(ctx, text_lat, image_lat, temperature):
+        tl, il = text_lat.contiguous(), image_lat.contiguous()
+        ctx.save_for_backward(tl, il)
+        ctx.temperature = temperature
+        return B().latent_similarity(tl, il, temperature.detach().reshape(1))
+
+    @staticmethod
+    def backward(ctx, dsims):
+        tl, il = ctx.saved_tensors
+        t = ctx.temperature
+        dt, di, dtemp = B().latent_similarity(tl, il, t.detach().reshape(1), dsims.contiguous())
+        sink = sink_of(t)
+        if sink is not None:
+            sink.add_(dtemp.view_as(sink))
+            return dt, di, None
+        return dt, di, dtemp.view_as(t)

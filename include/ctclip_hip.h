@@ -92,6 +92,9 @@ int ctclip_bce_logits(const float* logits, const float* targets, const float* po
 /* TODO: document */
 int ctclip_pair_softmax_mse(const float* sims, float* loss, float* dsims, int n, hipStream_t s);
 
+/* TODO: document */
+int ctclip_latent_similarity(const float* text, const float* image, const float* temperature, const float* dsims, float* sims, float* dtext, float* dimage, float* dtemp, int nt, int ni, int D, hipStream_t s);
+
 /* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
 int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 

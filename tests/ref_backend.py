@@ -475,6 +475,17 @@ class RefBackend:
             (g,) = torch.autograd.grad(loss, s)
         return loss.detach().reshape(1), g
 
+    def latent_similarity(self, text, image, temperature, dsims=None):
+        t = text.detach().clone().requires_grad_(True)
+        v = image.detach().clone().requires_grad_(True)
+        tp = temperature.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            sims = (F.normalize(t, dim=-1) * F.normalize(v, dim=-1)).sum(-1) * tp.exp()
+            if dsims is None:
+                return sims.detach()
+            dt, dv, dtp = torch.autograd.grad(sims, (t, v, tp), dsims)
+        return dt, dv, dtp.reshape(1)
+
     def grad_norm_clip(self, g, max_norm, extra_sq=None):
         sq = (g.double() ** 2).sum()
         if extra_sq is not None:

@@ -580,6 +580,17 @@ def test_finetune_head_kernels(hip, ref, p):
     close(l, lr, rtol=1e-5, atol=1e-7); close(ds, dsr, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("nt,ni", [(2, 1), (3, 3), (1, 4)])
+def test_latent_similarity(hip, ref, nt, ni):
+    """ct_clip.py:805-807 with broadcasting: forward and the three gradients against torch."""
+    t, v = rnd(nt, 512, seed=1), rnd(ni, 512, seed=2)
+    temp = torch.tensor([0.7], device=DEV)
+    ds = rnd(max(nt, ni), seed=3)
+    close(hip.latent_similarity(t, v, temp), ref.latent_similarity(t, v, temp), rtol=1e-5, atol=1e-6)
+    for a, b in zip(hip.latent_similarity(t, v, temp, ds), ref.latent_similarity(t, v, temp, ds)):
+        close(a, b, rtol=1e-4, atol=1e-7)
+
+
 def test_adam_weight_decay_mask(hip, ref):
     n = 4096 + 36
     p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.01)
