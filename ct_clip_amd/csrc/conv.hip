@@ -3,6 +3,7 @@
 // add of Transformer.forward (attention.py:324).  HBM-bound streaming: 4 channels per lane, a walk along the innermost grid axis
 // with three rotating output accumulators, neighbouring rows from L1/L2, weights per block in LDS as [27 + 3 zero rows][64 ch].
 #include "common.h"
+#include "peg_lds.h"
 #include <type_traits>
 
 namespace {
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void peg_wgrad_reduce_kernel(const float* __re
 extern "C" int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C,
                               int dtype, hipStream_t stream) {
   if (!x || !w || !y || C % 8) { ctclip_set_error("peg_fwd: C must be a multiple of 8"); return CTCLIP_EBADARG; }
+  if (peg_lds_supported(B, D1, D2, D3, C, dtype) && peg_lds_march(x, w, bias, y, B, D1, D2, D3, C, +1, stream) == 0) return ctclip_check_launch("peg_fwd");
   const int64_t nrows = B * D1 * D2;
   dim3 grid((unsigned)(cdiv(nrows, 16) * cdiv(C, CCH)));
   if (dtype == DT_F32) hipLaunchKernelGGL((peg_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)x, w, bias, (float*)y, nrows, D1, D2, D3, C);
@@ -279,13 +281,32 @@ extern "C" int ctclip_peg_fwd(const void* x, const float* w, const float* bias, 
 }
 
 // bytes of workspace ctclip_peg_bwd needs when dw is requested (per-row-group partial weight gradients)
-extern "C" int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C) { return cdiv(B * D1 * D2, 16 * WG_ROWS) * C * 28 * 4; }
+extern "C" int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C) {
+  const int64_t g1 = cdiv(B * D1 * D2, 16 * WG_ROWS), g2 = peg_lds_wgrad_groups(B, D2, C);
+  return (g1 > g2 ? g1 : g2) * C * 28 * 4;
+}
 
 // dx = dy + conv^T(dy) ; dw (C,27) and db (C) f32 are ACCUMULATED (+=) when non-null (two stages, fixed summation order).
 extern "C" int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2,
                               int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !w || !dx || C % 8) { ctclip_set_error("peg_bwd: bad args"); return CTCLIP_EBADARG; }
   if (dw && (!workspace || workspace_bytes < ctclip_peg_bwd_workspace(B, D1, D2, C))) { ctclip_set_error("peg_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  if (peg_lds_supported(B, D1, D2, D3, C, dtype)) {
+    // marching kernels: grad-in, then the weight gradient (per-workgroup partials + the same ordered second stage)
+    int groups = 0;
+    const bool dx_done = peg_lds_march(dy, w, nullptr, dx, B, D1, D2, D3, C, -1, stream) == 0;
+    const bool dw_done = dx_done && dw && peg_lds_wgrad(dy, x, (float*)workspace, B, D1, D2, D3, C, &groups, stream) == 0;
+    if (dw_done) hipLaunchKernelGGL(peg_wgrad_reduce_kernel, dim3((unsigned)cdiv(C * 28, 256)), dim3(256), 0, stream, (const float*)workspace, groups, C, dw, db);
+    if (dx_done && (dw_done || !dw)) return ctclip_check_launch("peg_bwd");
+    if (dx_done) {          // grad-in done, weight gradient on the first-generation kernel
+      const int64_t nrows = B * D1 * D2;
+      dim3 gridw((unsigned)(cdiv(nrows, 16 * WG_ROWS) * cdiv(C, CCH) * 3));
+      hipLaunchKernelGGL(peg_wgrad_kernel<bf16_t>, gridw, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, nrows, D1, D2, D3, C);
+      hipLaunchKernelGGL(peg_wgrad_reduce_kernel, dim3((unsigned)cdiv(C * 28, 256)), dim3(256), 0, stream, (const float*)workspace,
+                         (int)cdiv(nrows, 16 * WG_ROWS), C, dw, db);
+      return ctclip_check_launch("peg_bwd");
+    }
+  }
   const int64_t nrows = B * D1 * D2;
   dim3 grid((unsigned)(cdiv(nrows, 16) * cdiv(C, CCH)));
   dim3 gridw((unsigned)(cdiv(nrows, 16 * WG_ROWS) * cdiv(C, CCH) * 3));

@@ -1,0 +1,369 @@
+// PEG (attention.py:56-84: causal-padded depthwise 3x3x3 Conv3d over the (B, D1, D2, D3, C) token grid + the residual of
+// attention.py:324) for bf16 grids, marching along the causal axis with the input planes resident in LDS.
+//
+// The first-generation kernels (conv.hip) let every thread fetch its nine neighbour rows from L1/L2: nine 8-byte loads per step,
+// one memory round trip per step at two waves per SIMD -- latency-bound at 1.9 TB/s (118 us for 113 MB in + 113 MB out).
+// Here a workgroup owns (batch, TB rows of D2, 32 channels) and walks a = 0 .. D1-1:
+//   * a ring of four LDS slots holds the planes a-2, a-1, a (with one halo row either side of the tile and one zero column either
+//     side of D3) while plane a+1 streams in by LDS-DMA (global_load_lds, 16 B per lane): every input byte crosses HBM once,
+//     no VGPR staging, and a whole march step of compute hides the fetch;
+//   * a dedicated loader wave issues the DMA and is the only wave that waits on vmcnt, so the compute waves never wait for the
+//     acknowledgement of their output stores; one barrier per plane;
+//   * a compute thread owns (row, channel pair, a quarter of D3) and scatters each input column into three rotating output
+//     accumulators (9 ds_read_b32 + 18 unpacks + 54 FMAs per column), the 27 x 2 weights in registers, the residual folded into
+//     the centre tap; rows of a wave are an odd number of 64-byte positions apart -> the two 32-lane halves of a ds_read_b32 hit
+//     disjoint banks;
+//   * grad-in (DIR = -1) is the same march from a = D1-1 downwards with the D2 / D3 taps mirrored;
+//   * the weight gradient keeps the 27 x 2 tap sums of a thread in registers over the whole march (dy planes double-buffered in LDS
+//     next to the x ring), then folds rows -> waves -> workgroup in a fixed order and writes per-workgroup partials that
+//     conv.hip's second stage sums in order: no atomics.
+// Bytes per launch: forward / grad-in read x (or dy) once and write y once (2 x B*D1*D2*D3*C*2 B; + 2/TB halo rows from L2);
+// the weight gradient reads x and dy once.
+#include "common.h"
+#include "peg_lds.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int PCC = 32;   // channels per workgroup = 64 bytes of bf16 per grid position
+constexpr int PSEG = 4;   // quarters of the innermost axis
+
+template <int TB, int D3>
+struct Geo {
+  static constexpr int L = D3 / PSEG;             // outputs per thread and plane
+  static constexpr int RSP = (D3 + 2) | 1;        // positions per LDS row of the x ring (odd)
+  static constexpr int ROWB = RSP * 64;
+  static constexpr int SLOT = (TB + 2) * ROWB;
+  static constexpr int RSD = D3 | 1;              // positions per LDS row of a dy plane (no halo)
+  static constexpr int DROWB = RSD * 64;
+  static constexpr int DSLOT = TB * DROWB;
+  static constexpr int NCW = TB / 4 * PSEG;       // compute waves
+  static constexpr int PIECES = (D3 + 15) / 16;   // 1-KiB DMA pieces per row
+};
+
+struct Tile { int64_t b; int beta0, c0; };
+
+// 1-D grid -> (channel chunk, row tile, batch).  Workgroups are dealt to the 8 XCDs round-robin; with 16 chunks the two chunks that
+// share the 128-byte lines of x (2j, 2j+1) get ids 8 apart = the same XCD, so a line is pulled into one L2 only.
+__device__ __forceinline__ Tile tile_of(int nchunk, int ntile, int TBv) {
+  const int id = blockIdx.x;
+  int chunk, rest;
+  if (nchunk == 16) { chunk = (id & 7) * 2 + ((id >> 3) & 1); rest = id >> 4; }
+  else { chunk = id % nchunk; rest = id / nchunk; }
+  Tile t;
+  t.c0 = chunk * PCC;
+  t.beta0 = (rest % ntile) * TBv;
+  t.b = rest / ntile;
+  return t;
+}
+
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// one plane (rows beta0-1 .. beta0+TB of plane p, D3 positions, 32 channels) -> LDS rows of `rowb` bytes starting at dst
+// (+ col0 positions); rows outside [0, D2) are skipped (they stay zero).  Issued by ONE wave.
+template <int D3>
+__device__ __forceinline__ void dma_plane(const bf16_t* __restrict__ src_plane, char* dst, int rowb, int col0, int row_first, int nrows,
+                                          int D2, int C, int lane) {
+  constexpr int PIECES = (D3 + 15) / 16;
+  for (int i = 0; i < nrows; ++i) {
+    const int beta = row_first + i;
+    if (beta < 0 || beta >= D2) continue;
+#pragma unroll
+    for (int h = 0; h < PIECES; ++h) {
+      const int g = 16 * h + (lane >> 2);
+      if (g < D3) {
+        const bf16_t* src = src_plane + ((int64_t)beta * D3 + g) * C + (lane & 3) * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * rowb + (col0 + 16 * h) * 64), 16, 0, 0);
+      }
+    }
+  }
+}
+
+// piece q of a plane: row q / PIECES, sixteen positions from 16 * (q % PIECES)
+template <int D3>
+__device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ src_plane, char* dst, int rowb, int col0, int row_first, int q, int D2, int C, int lane) {
+  constexpr int PIECES = (D3 + 15) / 16;
+  const int i = q / PIECES, h = q % PIECES, beta = row_first + i;
+  if (beta < 0 || beta >= D2) return;
+  const int g = 16 * h + (lane >> 2);
+  if (g < D3) {
+    const bf16_t* src = src_plane + ((int64_t)beta * D3 + g) * C + (lane & 3) * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(dst + i * rowb + (col0 + 16 * h) * 64), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) { lo = __uint_as_float(v << 16); hi = __uint_as_float(v & 0xffff0000u); }
+
+// ---------------------------------------------------------------------------------------------------- forward / grad-in
+template <int TB, int D3, int DIR>
+__global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                                const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                                                int D1, int D2, int C, int ntile) {
+  using G = Geo<TB, D3>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = (G::NCW + 1) * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Tile t = tile_of(C / PCC, ntile, TB);
+  for (int i = threadIdx.x; i < 4 * G::SLOT / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const int64_t plane_elems = (int64_t)D2 * D3 * C;
+  const bf16_t* xb = x + t.b * D1 * plane_elems + t.c0;
+  auto plane_of = [&](int m) { return DIR > 0 ? m : D1 - 1 - m; };
+
+  if (wave == G::NCW) {                                  // ---- the loader wave
+    dma_plane<D3>(xb + plane_of(0) * plane_elems, lds, G::ROWB, 1, t.beta0 - 1, TB + 2, D2, C, lane);
+    for (int m = 0; m < D1; ++m) {
+      wait_vm0();
+      wg_barrier();
+      if (m + 1 < D1) dma_plane<D3>(xb + plane_of(m + 1) * plane_elems, lds + ((m + 1) & 3) * G::SLOT, G::ROWB, 1, t.beta0 - 1, TB + 2, D2, C, lane);
+    }
+    return;
+  }
+
+  // ---- compute waves
+  const int rg = wave % (TB / 4), seg = wave / (TB / 4);
+  const int r = rg * 4 + (lane >> 4), pr = lane & 15, g0 = seg * G::L;
+  const int ch = t.c0 + 2 * pr;
+  float wk[27][2];
+  {
+    const float* w0 = w + (int64_t)ch * 27;
+#pragma unroll
+    for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+      for (int d2 = 0; d2 < 3; ++d2)
+#pragma unroll
+        for (int d3 = 0; d3 < 3; ++d3) {
+          const int src = DIR > 0 ? d1 * 9 + d2 * 3 + d3 : d1 * 9 + (2 - d2) * 3 + (2 - d3);
+          wk[d1 * 9 + d2 * 3 + d3][0] = w0[src];
+          wk[d1 * 9 + d2 * 3 + d3][1] = w0[27 + src];
+        }
+    wk[2 * 9 + 1 * 3 + 1][0] += 1.f; wk[2 * 9 + 1 * 3 + 1][1] += 1.f;      // the residual
+  }
+  float bv[2] = {0.f, 0.f};
+  if (DIR > 0 && bias) { bv[0] = bias[ch]; bv[1] = bias[ch + 1]; }
+  const uint32_t tb = (uint32_t)((r * G::RSP + g0) * 64 + pr * 4);
+  // stores: a buffer descriptor over the batch item, a scalar offset per plane and column, one 32-bit lane offset; rows past D2
+  // (ragged last tile) get an offset beyond the descriptor and the hardware drops their stores -- no branches in the column loop
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(y + t.b * D1 * plane_elems, 0, (int)(D1 * plane_elems * 2), 0x00020000);
+  const uint32_t lane_off = t.beta0 + r < D2 ? (uint32_t)((((t.beta0 + r) * D3 + g0) * C + ch) * 2) : 0x80000000u;
+
+  for (int m = 0; m < D1; ++m) {
+    wg_barrier();
+    const char* pl[3];
+#pragma unroll
+    for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 + 2) & 3) * G::SLOT + tb;
+    const uint32_t plane_off = (uint32_t)(plane_of(m) * plane_elems * 2);
+    float accm[2] = {0.f, 0.f}, acc0[2] = {bv[0], bv[1]}, accp[2] = {bv[0], bv[1]};
+    uint32_t raw[2][9];
+    auto fetch = [&](uint32_t (&dst)[9], int jj) {
+#pragma unroll
+      for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+        for (int d2 = 0; d2 < 3; ++d2) dst[d1 * 3 + d2] = *reinterpret_cast<const uint32_t*>(pl[d1] + d2 * G::ROWB + jj * 64);
+    };
+    fetch(raw[0], 0);
+#pragma unroll
+    for (int jj = 0; jj < G::L + 2; ++jj) {
+      if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], jj + 1);   // one column ahead, no further (the barrier below)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float x0, x1;
+        unpack2(raw[jj & 1][k], x0, x1);
+        if (jj <= G::L - 1) { accp[0] = fmaf(wk[k * 3 + 0][0], x0, accp[0]); accp[1] = fmaf(wk[k * 3 + 0][1], x1, accp[1]); }
+        if (jj >= 1 && jj <= G::L) { acc0[0] = fmaf(wk[k * 3 + 1][0], x0, acc0[0]); acc0[1] = fmaf(wk[k * 3 + 1][1], x1, acc0[1]); }
+        if (jj >= 2) { accm[0] = fmaf(wk[k * 3 + 2][0], x0, accm[0]); accm[1] = fmaf(wk[k * 3 + 2][1], x1, accm[1]); }
+      }
+      if (jj >= 2) __builtin_amdgcn_raw_buffer_store_b32(pack2bf(accm[0], accm[1]), yres, lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
+      accm[0] = acc0[0]; accm[1] = acc0[1]; acc0[0] = accp[0]; acc0[1] = accp[1]; accp[0] = bv[0]; accp[1] = bv[1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+// part[(b * ntile + tile)][C][28]: 27 taps + the bias gradient of the workgroup's rows
+template <int TB, int D3>
+__global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                                      float* __restrict__ part, int D1, int D2, int C, int ntile) {
+  using G = Geo<TB, D3>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = G::NCW * 64;
+  constexpr int XR = 4 * G::SLOT;                         // x ring, then two dy planes
+  constexpr int NPX = (TB + 2) * G::PIECES, NPD = TB * G::PIECES;   // DMA pieces per x plane / dy plane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Tile t = tile_of(C / PCC, ntile, TB);
+  for (int i = threadIdx.x; i < (XR + 2 * G::DSLOT) / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const int64_t plane_elems = (int64_t)D2 * D3 * C;
+  const bf16_t* xb = x + t.b * D1 * plane_elems + t.c0;
+  const bf16_t* gb = dy + t.b * D1 * plane_elems + t.c0;
+
+  float acc[27][2], accb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 27; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; }
+  const int rg = wave % (TB / 4), seg = wave / (TB / 4);
+  const int r = rg * 4 + (lane >> 4), pr = lane & 15, g0 = seg * G::L;
+
+  // No stores in the march, so every wave fetches its share of the next planes itself (pieces wave, wave + NCW, ...) and waits for
+  // them with vmcnt(0) before the barrier: no loader waves, the twelve compute waves keep 168 registers each.
+  auto issue = [&](int m) {
+    for (int q = wave; q < NPX + NPD; q += G::NCW) {
+      if (q < NPX) dma_piece<D3>(xb + m * plane_elems, lds + (m & 3) * G::SLOT, G::ROWB, 1, t.beta0 - 1, q, D2, C, lane);
+      else dma_piece<D3>(gb + m * plane_elems, lds + XR + (m & 1) * G::DSLOT, G::DROWB, 0, t.beta0, q - NPX, D2, C, lane);
+    }
+  };
+  issue(0);
+  {
+    const uint32_t tb = (uint32_t)((r * G::RSP + g0) * 64 + pr * 4);
+    const uint32_t db = (uint32_t)(XR + (r * G::RSD + g0) * 64 + pr * 4);
+    for (int m = 0; m < D1; ++m) {
+      wait_vm0();
+      wg_barrier();
+      if (m + 1 < D1) issue(m + 1);
+      const char* pl[3];
+#pragma unroll
+      for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 + 2) & 3) * G::SLOT + tb;
+      const char* gp = lds + db + (m & 1) * G::DSLOT;
+      float gm[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};       // dy[col - 1], dy[col] of the thread's OWN outputs (0 outside its quarter)
+      uint32_t raw[2][9], graw[2] = {0u, 0u};
+      auto fetch = [&](uint32_t (&dst)[9], uint32_t& g, int jj) {
+        if (jj <= G::L - 1) g = *reinterpret_cast<const uint32_t*>(gp + jj * 64);
+#pragma unroll
+        for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+          for (int d2 = 0; d2 < 3; ++d2) dst[d1 * 3 + d2] = *reinterpret_cast<const uint32_t*>(pl[d1] + d2 * G::ROWB + jj * 64);
+      };
+      fetch(raw[0], graw[0], 0);
+#pragma unroll
+      for (int jj = 0; jj < G::L + 2; ++jj) {
+        if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], graw[(jj + 1) & 1], jj + 1);
+        asm volatile("" ::: "memory");
+        float gq[2] = {0.f, 0.f};                         // dy[col + 1]
+        if (jj <= G::L - 1) {
+          unpack2(graw[jj & 1], gq[0], gq[1]);
+          accb[0] += gq[0]; accb[1] += gq[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float x0, x1;
+          unpack2(raw[jj & 1][k], x0, x1);
+          if (jj <= G::L - 1) { acc[k * 3 + 0][0] = fmaf(gq[0], x0, acc[k * 3 + 0][0]); acc[k * 3 + 0][1] = fmaf(gq[1], x1, acc[k * 3 + 0][1]); }
+          if (jj >= 1 && jj <= G::L) { acc[k * 3 + 1][0] = fmaf(gc[0], x0, acc[k * 3 + 1][0]); acc[k * 3 + 1][1] = fmaf(gc[1], x1, acc[k * 3 + 1][1]); }
+          if (jj >= 2) { acc[k * 3 + 2][0] = fmaf(gm[0], x0, acc[k * 3 + 2][0]); acc[k * 3 + 2][1] = fmaf(gm[1], x1, acc[k * 3 + 2][1]); }
+        }
+        gm[0] = gc[0]; gm[1] = gc[1]; gc[0] = gq[0]; gc[1] = gq[1];
+      }
+    }
+  }
+  // ---- fold: the 4 rows of a wave (lanes 16 apart), then the compute waves in order, then out
+  wg_barrier();                                           // every wave is done with the ring
+  float* red = reinterpret_cast<float*>(lds);             // [wave][pair][57]
+  {
+    float v[56];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { v[2 * k] = acc[k][0]; v[2 * k + 1] = acc[k][1]; }
+    v[54] = accb[0]; v[55] = accb[1];
+#pragma unroll
+    for (int k = 0; k < 56; ++k) {
+      v[k] += __shfl_xor(v[k], 16);
+      v[k] += __shfl_xor(v[k], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 56; ++k) red[(wave * 16 + lane) * 57 + k] = v[k];
+    }
+  }
+  __syncthreads();
+  const int tile = (t.beta0 / TB);
+  for (int i = threadIdx.x; i < PCC * 28; i += NT) {
+    const int cc = i / 28, tap = i % 28;
+    const int idx = tap < 27 ? tap * 2 + (cc & 1) : 54 + (cc & 1);
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < G::NCW; ++wv) s += red[(wv * 16 + (cc >> 1)) * 57 + idx];
+    part[((t.b * ntile + tile) * C + t.c0 + cc) * 28 + tap] = s;
+  }
+}
+
+bool lds_path_enabled() {
+  static const bool on = [] { const char* e = getenv("CTCLIP_PEG_LDS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// TB = 12 when that fills the chip, else TB = 4 (three workgroups per CU)
+int pick_tb(int64_t B, int D2, int C) { return B * ((D2 + 11) / 12) * (C / PCC) >= 200 ? 12 : 4; }
+
+template <int TB, int D3, int DIR>
+int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int64_t B, int D1, int D2, int C, hipStream_t s) {
+  using G = Geo<TB, D3>;
+  const int ntile = (D2 + TB - 1) / TB;
+  const size_t shm = 4 * G::SLOT;
+  static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G::SLOT) == hipSuccess; }();
+  if (!once) return 1;
+  hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, D1, D2, C, ntile);
+  return 0;
+}
+
+template <int TB, int D3>
+int launch_wgrad(const bf16_t* dy, const bf16_t* x, float* part, int64_t B, int D1, int D2, int C, hipStream_t s) {
+  using G = Geo<TB, D3>;
+  const int ntile = (D2 + TB - 1) / TB;
+  constexpr int SHM = 4 * G::SLOT + 2 * G::DSLOT;
+  static_assert(SHM >= G::NCW * 16 * 57 * 4, "fold scratch must fit in the ring");
+  static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_wgrad_march_kernel<TB, D3>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
+  if (!once) return 1;
+  hipLaunchKernelGGL((peg_wgrad_march_kernel<TB, D3>), dim3((unsigned)(B * ntile * (C / PCC))), dim3(G::NCW * 64), SHM, s, dy, x, part, D1, D2, C, ntile);
+  return 0;
+}
+
+}  // namespace
+
+bool peg_lds_supported(int64_t B, int D1, int D2, int D3, int C, int dtype) {
+  return lds_path_enabled() && dtype == DT_BF16 && C % PCC == 0 && (D3 == 8 || D3 == 16 || D3 == 24 || D3 == 32) && B >= 1 && D1 >= 1 && D2 >= 1 &&
+         (int64_t)D1 * D2 * D3 * C * 2 < (int64_t)1 << 31;       // one buffer descriptor per batch item
+}
+
+int64_t peg_lds_wgrad_groups(int64_t B, int D2, int C) { return B * ((D2 + 3) / 4); }   // upper bound over both tile heights
+
+#define PEG_D3_SWITCH(CALL)                 \
+  switch (D3) {                             \
+    case 8: return CALL(8);                 \
+    case 16: return CALL(16);               \
+    case 24: return CALL(24);               \
+    case 32: return CALL(32);               \
+    default: return 1;                      \
+  }
+
+int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s) {
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+  const int tb = pick_tb(B, D2, C);
+#define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, B, D1, D2, C, s)
+#define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, B, D1, D2, C, s)
+#define BWD12(D) launch_march<12, D, -1>(xp, w, nullptr, yp, B, D1, D2, C, s)
+#define BWD4(D) launch_march<4, D, -1>(xp, w, nullptr, yp, B, D1, D2, C, s)
+  if (dir > 0) { if (tb == 12) { PEG_D3_SWITCH(FWD12) } else { PEG_D3_SWITCH(FWD4) } }
+  else { if (tb == 12) { PEG_D3_SWITCH(BWD12) } else { PEG_D3_SWITCH(BWD4) } }
+#undef FWD12
+#undef FWD4
+#undef BWD12
+#undef BWD4
+}
+
+int peg_lds_wgrad(const void* dy, const void* x, float* part, int64_t B, int D1, int D2, int D3, int C, int* groups, hipStream_t s) {
+  const bf16_t* gp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
+  const int tb = pick_tb(B, D2, C);
+  *groups = (int)(B * ((D2 + tb - 1) / tb));
+#define WG12(D) launch_wgrad<12, D>(gp, xp, part, B, D1, D2, C, s)
+#define WG4(D) launch_wgrad<4, D>(gp, xp, part, B, D1, D2, C, s)
+  if (tb == 12) { PEG_D3_SWITCH(WG12) } else { PEG_D3_SWITCH(WG4) }
+#undef WG12
+#undef WG4
+}

@@ -174,7 +174,11 @@ def test_l2norm_rows(hip, ref, dtype):
 
 # ---------------------------------------------------------------- PEG
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(2, 2, 4, 4, 128), (1, 5, 3, 7, 64), (2, 24, 6, 6, 512)])
+@pytest.mark.parametrize("shape", [(2, 2, 4, 4, 128), (1, 5, 3, 7, 64), (2, 24, 6, 6, 512),
+                                   # LDS-resident marching kernels (bf16, D3 in {8, 16, 24, 32}, C % 32 == 0): 4-row tiles with a ragged
+                                   # last tile / 3 channel chunks; 12-row tiles full and ragged; D3 = 32 (weight gradient falls back)
+                                   (2, 5, 7, 8, 64), (1, 3, 13, 24, 96), (8, 6, 24, 24, 512), (2, 4, 30, 16, 512), (7, 3, 17, 8, 512),
+                                   (13, 2, 12, 32, 512), (1, 1, 1, 8, 32)])
 def test_peg_fwd_bwd(hip, ref, dtype, shape):
     C = shape[-1]
     x, dy = rnd(*shape, dtype=dtype, seed=1), rnd(*shape, dtype=dtype, seed=2)

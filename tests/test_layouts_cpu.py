@@ -166,3 +166,137 @@ def test_attn2_work_item_decode_covers_every_item_once():
         per = (nitems + 7) >> 3
         seen = [(b & 7) * per + (b >> 3) for b in range(8 * per)]
         assert sorted(w for w in seen if w < nitems) == list(range(nitems))
+
+
+# ---------------------------------------------------------------------------------------------------- PEG marching kernels
+def _peg_march_model(x, w, bias, direction, TB, PSEG=4):
+    """csrc/peg_lds.hip peg_march_kernel step for step: ring of four LDS slots (halo rows / zero columns), march index m,
+    tap d1 <-> slot (m + d1 + 2) & 3, row r + d2, input column jj scattered into three rotating accumulators."""
+    import numpy as np
+    B, D1, D2, D3, C = x.shape
+    L = D3 // PSEG
+    y = np.zeros_like(x)
+    wk = w.reshape(C, 3, 3, 3).copy()
+    if direction < 0:
+        wk = wk[:, :, ::-1, ::-1].copy()
+    wk[:, 2, 1, 1] += 1.0                                       # the residual in the centre tap
+    bv = bias if direction > 0 else np.zeros(C, x.dtype)
+    for b in range(B):
+        for beta0 in range(0, D2, TB):
+            slots = np.zeros((4, TB + 2, D3 + 2, C), x.dtype)
+            plane_of = (lambda m: m) if direction > 0 else (lambda m: D1 - 1 - m)
+
+            def dma(m):
+                for i in range(TB + 2):
+                    beta = beta0 - 1 + i
+                    if 0 <= beta < D2:
+                        slots[m & 3, i, 1:D3 + 1] = x[b, plane_of(m), beta]
+            dma(0)
+            for m in range(D1):
+                if m + 1 < D1:
+                    dma(m + 1)                                   # overwrites the slot of march plane m - 3
+                for r in range(TB):
+                    if beta0 + r >= D2:
+                        continue
+                    for seg in range(PSEG):
+                        g0 = seg * L
+                        accm, acc0, accp = np.zeros(C, x.dtype), bv.copy(), bv.copy()
+                        for jj in range(L + 2):
+                            for d1 in range(3):
+                                for d2 in range(3):
+                                    xs = slots[(m + d1 + 2) & 3, r + d2, g0 + jj]
+                                    if jj <= L - 1:
+                                        accp = accp + wk[:, d1, d2, 0] * xs
+                                    if 1 <= jj <= L:
+                                        acc0 = acc0 + wk[:, d1, d2, 1] * xs
+                                    if jj >= 2:
+                                        accm = accm + wk[:, d1, d2, 2] * xs
+                            if jj >= 2:
+                                y[b, plane_of(m), beta0 + r, g0 + jj - 2] = accm
+                            accm, acc0, accp = acc0, accp, bv.copy()
+    return y
+
+
+def _peg_wgrad_model(dy, x, TB, PSEG=4):
+    """peg_wgrad_march_kernel: own dy window (zero outside the thread's quarter), x column jj meets dy[col + 1], dy[col], dy[col - 1]."""
+    import numpy as np
+    B, D1, D2, D3, C = x.shape
+    L = D3 // PSEG
+    dw, db = np.zeros((C, 3, 3, 3), x.dtype), np.zeros(C, x.dtype)
+    for b in range(B):
+        for beta0 in range(0, D2, TB):
+            slots = np.zeros((4, TB + 2, D3 + 2, C), x.dtype)
+            gsl = np.zeros((2, TB, D3, C), x.dtype)
+
+            def dma(m):
+                for i in range(TB + 2):
+                    beta = beta0 - 1 + i
+                    if 0 <= beta < D2:
+                        slots[m & 3, i, 1:D3 + 1] = x[b, m, beta]
+                gsl[m & 1] = 0                                   # (rows past D2 are never written: they stay zero)
+                for i in range(TB):
+                    if beta0 + i < D2:
+                        gsl[m & 1, i] = dy[b, m, beta0 + i]
+            dma(0)
+            for m in range(D1):
+                if m + 1 < D1:
+                    dma(m + 1)
+                for r in range(TB):
+                    for seg in range(PSEG):
+                        g0 = seg * L
+                        gm, gc = np.zeros(C, x.dtype), np.zeros(C, x.dtype)
+                        for jj in range(L + 2):
+                            gq = gsl[m & 1, r, g0 + jj] if jj <= L - 1 else np.zeros(C, x.dtype)
+                            if jj <= L - 1:
+                                db += gq
+                            for d1 in range(3):
+                                for d2 in range(3):
+                                    xs = slots[(m + d1 + 2) & 3, r + d2, g0 + jj]
+                                    if jj <= L - 1:
+                                        dw[:, d1, d2, 0] += gq * xs
+                                    if 1 <= jj <= L:
+                                        dw[:, d1, d2, 1] += gc * xs
+                                    if jj >= 2:
+                                        dw[:, d1, d2, 2] += gm * xs
+                            gm, gc = gc, gq
+    return dw.reshape(C, 27), db
+
+
+def test_peg_marching_kernels_index_arithmetic():
+    """The march (ring slots, mirrored taps of the grad-in pass, quarter-row scatter, own-dy window of the weight gradient) against
+    F.conv3d with the reference's causal padding (attention.py:63-84) and its autograd."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    for (B, D1, D2, D3, C, TB) in [(1, 4, 5, 8, 2, 4), (2, 3, 12, 4, 1, 12), (1, 5, 13, 8, 2, 12)]:
+        x = torch.randn(B, D1, D2, D3, C, generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(C, 27, generator=g, dtype=torch.float64, requires_grad=True)
+        bias = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(B, D1, D2, D3, C, generator=g, dtype=torch.float64)
+        xc = x.permute(0, 4, 1, 2, 3)
+        yr = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C).permute(0, 2, 3, 4, 1) + x
+        dxr, dwr, dbr = torch.autograd.grad(yr, (x, w, bias), dy)
+        y = _peg_march_model(x.detach().numpy(), w.detach().numpy(), bias.detach().numpy(), +1, TB)
+        np.testing.assert_allclose(y, yr.detach().numpy(), rtol=1e-10, atol=1e-10)
+        dx = _peg_march_model(dy.numpy(), w.detach().numpy(), None, -1, TB)
+        np.testing.assert_allclose(dx, dxr.numpy(), rtol=1e-10, atol=1e-10)
+        dw, db = _peg_wgrad_model(dy.numpy(), x.detach().numpy(), TB)
+        np.testing.assert_allclose(dw, dwr.numpy(), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(db, dbr.numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_peg_marching_lds_reads_are_bank_conflict_free():
+    """ds_read_b32 is served in two groups of 32 lanes; a group = two rows of the tile x 16 channel pairs.  With an odd number of
+    64-byte positions per LDS row the two rows fall into different halves of the 128-byte bank window."""
+    for D3 in (8, 16, 24, 32):
+        for rsp, what in (((D3 + 2) | 1, "x ring"), (D3 | 1, "dy plane")):
+            for g0 in range(0, D3, D3 // 4):
+                for jj in range(D3 // 4 + 2):
+                    for half in (0, 1):
+                        banks = set()
+                        for lane in range(32 * half, 32 * half + 32):
+                            r, pr = lane >> 4, lane & 15
+                            a = (r * rsp + g0 + jj) * 64 + pr * 4
+                            banks.add((a // 4) % 32)
+                        assert len(banks) == 32, (D3, what, g0, jj)
