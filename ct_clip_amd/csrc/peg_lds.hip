@@ -5,10 +5,11 @@
 // one memory round trip per step at two waves per SIMD -- latency-bound at 1.9 TB/s (118 us for 113 MB in + 113 MB out).
 // Here a workgroup owns (batch, TB rows of D2, 32 channels) and walks a = 0 .. D1-1:
 //   * a ring of four LDS slots holds the planes a-2, a-1, a (with one halo row either side of the tile and one zero column either
-//     side of D3) while plane a+1 streams in by LDS-DMA (global_load_lds, 16 B per lane): every input byte crosses HBM once,
-//     no VGPR staging, and a whole march step of compute hides the fetch;
-//   * a dedicated loader wave issues the DMA and is the only wave that waits on vmcnt, so the compute waves never wait for the
-//     acknowledgement of their output stores; one barrier per plane;
+//     side of D3) while plane a+1 streams in by LDS-DMA (global_load_lds, 16 B per lane): every input byte crosses HBM once, no
+//     VGPR staging.  (Deeper rings are built in -- DEPTH / WDEPTH -- but two planes in flight measured 8 % slower: the march is bound
+//     by vector-instruction issue, 330 VALU + 72 LDS instructions per thread and plane, not by the fetch; see profiles/r02_peg.md);
+//   * a dedicated loader wave issues the DMA and is the only wave that waits on vmcnt (counted: vmcnt retires in issue order), so
+//     the compute waves never wait for the acknowledgement of their output stores; one barrier per plane;
 //   * a compute thread owns (row, channel pair, a quarter of D3) and scatters each input column into three rotating output
 //     accumulators (9 ds_read_b32 + 18 unpacks + 54 FMAs per column), the 27 x 2 weights in registers, the residual folded into
 //     the centre tap; rows of a wave are an odd number of 64-byte positions apart -> the two 32-lane halves of a ds_read_b32 hit
@@ -23,6 +24,11 @@
 #include "peg_lds.h"
 
 #include <cstdlib>
+
+#ifndef PEG_ABL
+#define PEG_ABL 0      // ablations (tools/build_ablation.py peg_lds.hip:PEG_ABL ...): 1 deeper prefetch, 2 drain every DMA at each step,
+                       // 4 no bf16 unpack instructions (timing only)
+#endif
 
 namespace {
 
@@ -40,7 +46,27 @@ struct Geo {
   static constexpr int DSLOT = TB * DROWB;
   static constexpr int NCW = TB / 4 * PSEG;       // compute waves
   static constexpr int PIECES = (D3 + 15) / 16;   // 1-KiB DMA pieces per row
+  static constexpr int NPX = (TB + 2) * PIECES;   // DMA pieces per x plane (halo rows included), per dy plane
+  static constexpr int NPD = TB * PIECES;
+  static constexpr int LDS_MAX = 160 * 1024;
+  // forward / grad-in: three live planes + as many planes in flight as fit (at most three), + one dump row
+  // (vmcnt is a 6-bit counter: the loader wave never has more than 63 pieces outstanding)
+  static constexpr int DEPTH_LDS = (LDS_MAX - ROWB) / SLOT - 3;
+  static constexpr int DEPTH_VM = 63 / NPX;
+  static constexpr int DEPTH_CAP = (PEG_ABL & 1) ? 3 : 1;    // measured: 69.8 us with one plane in flight, 76.2 us with two
+  static constexpr int DEPTH = DEPTH_LDS < DEPTH_VM ? (DEPTH_LDS < DEPTH_CAP ? DEPTH_LDS : DEPTH_CAP) : (DEPTH_VM < DEPTH_CAP ? DEPTH_VM : DEPTH_CAP);
+  static constexpr int NSLOT = DEPTH + 3;
+  // weight gradient: x planes WDEPTH ahead, the dy planes one ahead (measured: 92 us with one, 104 us with two)
+  static constexpr int WDEPTH = (PEG_ABL & 1) ? 2 : 1;
+  static constexpr int WSLOT = 3 + WDEPTH;
 };
+
+// s_waitcnt vmcnt(N) only (lgkmcnt / expcnt untouched); vmcnt retires in issue order
+template <int N> __device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  constexpr int M = (PEG_ABL & 2) ? 0 : N;
+  __builtin_amdgcn_s_waitcnt((M & 15) | ((M >> 4) << 14) | 0x0F70);
+}
 
 struct Tile { int64_t b; int beta0, c0; };
 
@@ -58,49 +84,75 @@ __device__ __forceinline__ Tile tile_of(int nchunk, int ntile, int TBv) {
   return t;
 }
 
-__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
-// one plane (rows beta0-1 .. beta0+TB of plane p, D3 positions, 32 channels) -> LDS rows of `rowb` bytes starting at dst
-// (+ col0 positions); rows outside [0, D2) are skipped (they stay zero).  Issued by ONE wave.
+// The lane part of a DMA piece's source address: sixteen positions x four 16-byte quarters of the 64 channel bytes.
 template <int D3>
-__device__ __forceinline__ void dma_plane(const bf16_t* __restrict__ src_plane, char* dst, int rowb, int col0, int row_first, int nrows,
-                                          int D2, int C, int lane) {
-  constexpr int PIECES = (D3 + 15) / 16;
-  for (int i = 0; i < nrows; ++i) {
-    const int beta = row_first + i;
-    if (beta < 0 || beta >= D2) continue;
+struct LaneSrc {
+  static constexpr int PIECES = (D3 + 15) / 16;
+  uint32_t off[PIECES];    // bytes from the start of the grid row
+  bool on[PIECES];         // position < D3
+  __device__ __forceinline__ void init(int C, int lane) {
 #pragma unroll
     for (int h = 0; h < PIECES; ++h) {
       const int g = 16 * h + (lane >> 2);
-      if (g < D3) {
-        const bf16_t* src = src_plane + ((int64_t)beta * D3 + g) * C + (lane & 3) * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + i * rowb + (col0 + 16 * h) * 64), 16, 0, 0);
-      }
+      on[h] = g < D3;
+      off[h] = (uint32_t)((g < D3 ? g : 0) * C + (lane & 3) * 8) * 2u;
+    }
+  }
+  // (selects, not indexing: a run-time index would put the arrays into scratch memory -- and every scratch load is followed by a
+  // vmcnt(0) that drains the DMA queue)
+  __device__ __forceinline__ uint32_t off_of(int h) const {
+    uint32_t v = off[0];
+#pragma unroll
+    for (int k = 1; k < PIECES; ++k) v = h == k ? off[k] : v;
+    return v;
+  }
+  __device__ __forceinline__ bool on_of(int h) const {
+    bool v = on[0];
+#pragma unroll
+    for (int k = 1; k < PIECES; ++k) v = h == k ? on[k] : v;
+    return v;
+  }
+};
+
+// All pieces wave0, wave0 + stride, ... of one plane: piece q = row q / PIECES of the tile (grid row row_first + q / PIECES), sixteen
+// positions from 16 * (q % PIECES), to dst + row * rowb + col0 positions.  Rows outside [0, D2) fetch a clamped row into `dump`
+// (their LDS rows stay zero): every plane costs the same number of DMA instructions, so the vmcnt arithmetic is exact.  Everything
+// but the lane offset is wave-uniform (scalar registers); the loop is unrolled.
+typedef __attribute__((address_space(3))) char* lds_ptr;     // (LDS addresses stay 32-bit: no generic-pointer round trip)
+
+template <int D3, int NPIECE, int STRIDE>
+__device__ __forceinline__ void dma_plane(const bf16_t* __restrict__ src_plane, lds_ptr l3, uint32_t dst, uint32_t dump, int rowb, int col0, int row_first,
+                                          int q0, int D2, int C, const LaneSrc<D3>& ls) {
+  constexpr int PIECES = (D3 + 15) / 16;
+  const int64_t row_bytes = (int64_t)D3 * C * 2;
+#pragma unroll
+  for (int k = 0; k < (NPIECE + STRIDE - 1) / STRIDE; ++k) {
+    const int q = q0 + k * STRIDE;
+    if (q < NPIECE) {
+      const int i = q / PIECES, h = q % PIECES, beta = row_first + i;
+      const bool inside = beta >= 0 && beta < D2;
+      const int bc = beta < 0 ? 0 : (beta >= D2 ? D2 - 1 : beta);
+      const char* row = reinterpret_cast<const char*>(src_plane) + bc * row_bytes;
+      const uint32_t to = inside ? dst + (uint32_t)(i * rowb + (col0 + 16 * h) * 64) : dump + (uint32_t)(16 * h * 64);
+      if (ls.on_of(h))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + ls.off_of(h)), (__attribute__((address_space(3))) void*)(l3 + to), 16, 0, 0);
     }
   }
 }
 
-// piece q of a plane: row q / PIECES, sixteen positions from 16 * (q % PIECES)
-template <int D3>
-__device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ src_plane, char* dst, int rowb, int col0, int row_first, int q, int D2, int C, int lane) {
-  constexpr int PIECES = (D3 + 15) / 16;
-  const int i = q / PIECES, h = q % PIECES, beta = row_first + i;
-  if (beta < 0 || beta >= D2) return;
-  const int g = 16 * h + (lane >> 2);
-  if (g < D3) {
-    const bf16_t* src = src_plane + ((int64_t)beta * D3 + g) * C + (lane & 3) * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(dst + i * rowb + (col0 + 16 * h) * 64), 16, 0, 0);
-  }
+__device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
+#if PEG_ABL & 4      // timing only: no unpack instructions (wrong values)
+  lo = __uint_as_float(v); hi = __uint_as_float(v);
+#else
+  lo = __uint_as_float(v << 16); hi = __uint_as_float(v & 0xffff0000u);
+#endif
 }
-
-__device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) { lo = __uint_as_float(v << 16); hi = __uint_as_float(v & 0xffff0000u); }
 
 // ---------------------------------------------------------------------------------------------------- forward / grad-in
 template <int TB, int D3, int DIR>
@@ -112,18 +164,29 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
   constexpr int NT = (G::NCW + 1) * 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const Tile t = tile_of(C / PCC, ntile, TB);
-  for (int i = threadIdx.x; i < 4 * G::SLOT / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = threadIdx.x; i < G::NSLOT * G::SLOT / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   const int64_t plane_elems = (int64_t)D2 * D3 * C;
   const bf16_t* xb = x + t.b * D1 * plane_elems + t.c0;
   auto plane_of = [&](int m) { return DIR > 0 ? m : D1 - 1 - m; };
 
-  if (wave == G::NCW) {                                  // ---- the loader wave
-    dma_plane<D3>(xb + plane_of(0) * plane_elems, lds, G::ROWB, 1, t.beta0 - 1, TB + 2, D2, C, lane);
+  if (wave == G::NCW) {                                  // ---- the loader wave: plane m + DEPTH is issued in step m
+    const lds_ptr l3 = (lds_ptr)lds;
+    constexpr uint32_t dump = G::NSLOT * G::SLOT;
+    LaneSrc<D3> ls;
+    ls.init(C, lane);
+    auto issue = [&](int m) {
+      dma_plane<D3, G::NPX, 1>(xb + plane_of(m) * plane_elems, l3, (uint32_t)((m % G::NSLOT) * G::SLOT), dump, G::ROWB, 1, t.beta0 - 1, 0, D2, C, ls);
+    };
+    for (int m = 0; m < G::DEPTH && m < D1; ++m) issue(m);
     for (int m = 0; m < D1; ++m) {
-      wait_vm0();
+      // plane m must have landed; the planes issued after it (at most DEPTH - 1 of them) may stay in flight
+      const int ahead = D1 - 1 - m < G::DEPTH - 1 ? D1 - 1 - m : G::DEPTH - 1;
+      if (ahead >= 2) wait_vm<(G::DEPTH >= 3 ? 2 : 0) * G::NPX>();
+      else if (ahead == 1) wait_vm<(G::DEPTH >= 2 ? 1 : 0) * G::NPX>();
+      else wait_vm<0>();
       wg_barrier();
-      if (m + 1 < D1) dma_plane<D3>(xb + plane_of(m + 1) * plane_elems, lds + ((m + 1) & 3) * G::SLOT, G::ROWB, 1, t.beta0 - 1, TB + 2, D2, C, lane);
+      if (m + G::DEPTH < D1) issue(m + G::DEPTH);
     }
     return;
   }
@@ -159,7 +222,7 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
     wg_barrier();
     const char* pl[3];
 #pragma unroll
-    for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 + 2) & 3) * G::SLOT + tb;
+    for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 - 2 + G::NSLOT) % G::NSLOT) * G::SLOT + tb;
     const uint32_t plane_off = (uint32_t)(plane_of(m) * plane_elems * 2);
     float accm[2] = {0.f, 0.f}, acc0[2] = {bv[0], bv[1]}, accp[2] = {bv[0], bv[1]};
     uint32_t raw[2][9];
@@ -196,8 +259,8 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kerne
   using G = Geo<TB, D3>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NT = G::NCW * 64;
-  constexpr int XR = 4 * G::SLOT;                         // x ring, then two dy planes
-  constexpr int NPX = (TB + 2) * G::PIECES, NPD = TB * G::PIECES;   // DMA pieces per x plane / dy plane
+  constexpr int XR = G::WSLOT * G::SLOT;                  // x ring, then two dy planes, then the dump row
+  constexpr int NPX = G::NPX, NPD = G::NPD;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const Tile t = tile_of(C / PCC, ntile, TB);
   for (int i = threadIdx.x; i < (XR + 2 * G::DSLOT) / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -212,25 +275,35 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kerne
   const int rg = wave % (TB / 4), seg = wave / (TB / 4);
   const int r = rg * 4 + (lane >> 4), pr = lane & 15, g0 = seg * G::L;
 
-  // No stores in the march, so every wave fetches its share of the next planes itself (pieces wave, wave + NCW, ...) and waits for
-  // them with vmcnt(0) before the barrier: no loader waves, the twelve compute waves keep 168 registers each.
-  auto issue = [&](int m) {
-    for (int q = wave; q < NPX + NPD; q += G::NCW) {
-      if (q < NPX) dma_piece<D3>(xb + m * plane_elems, lds + (m & 3) * G::SLOT, G::ROWB, 1, t.beta0 - 1, q, D2, C, lane);
-      else dma_piece<D3>(gb + m * plane_elems, lds + XR + (m & 1) * G::DSLOT, G::DROWB, 0, t.beta0, q - NPX, D2, C, lane);
-    }
+  // No stores in the march, so every wave fetches its share of the coming planes itself (pieces wave, wave + NCW, ...): no loader
+  // waves, the twelve compute waves keep 168 registers each.  Step m issues dy plane m + 1, then x plane m + WDEPTH; with WDEPTH = 2 a
+  // wave waits before the barrier of step m until only its pieces of x plane m + 1 (the youngest) are still in flight.
+  const lds_ptr l3 = (lds_ptr)lds;
+  constexpr uint32_t dump = XR + 2 * G::DSLOT;
+  LaneSrc<D3> ls;
+  ls.init(C, lane);
+  auto issue_x = [&](int m) {
+    dma_plane<D3, NPX, G::NCW>(xb + m * plane_elems, l3, (uint32_t)((m % G::WSLOT) * G::SLOT), dump, G::ROWB, 1, t.beta0 - 1, wave, D2, C, ls);
   };
-  issue(0);
+  auto issue_g = [&](int m) {
+    dma_plane<D3, NPD, G::NCW>(gb + m * plane_elems, l3, (uint32_t)(XR + (m & 1) * G::DSLOT), dump, G::DROWB, 0, t.beta0, wave, D2, C, ls);
+  };
+  constexpr int XLO = NPX / G::NCW, XEXTRA = NPX % G::NCW;   // x pieces per wave: XLO, + 1 for the first XEXTRA waves
+  issue_x(0); issue_g(0);
+  if (G::WDEPTH == 2 && D1 > 1) issue_x(1);
   {
     const uint32_t tb = (uint32_t)((r * G::RSP + g0) * 64 + pr * 4);
     const uint32_t db = (uint32_t)(XR + (r * G::RSD + g0) * 64 + pr * 4);
     for (int m = 0; m < D1; ++m) {
-      wait_vm0();
+      if (G::WDEPTH == 1 || m + 1 >= D1) wait_vm<0>();
+      else if (wave < XEXTRA) wait_vm<XLO + 1>();
+      else wait_vm<XLO>();
       wg_barrier();
-      if (m + 1 < D1) issue(m + 1);
+      if (m + 1 < D1) issue_g(m + 1);
+      if (m + G::WDEPTH < D1) issue_x(m + G::WDEPTH);
       const char* pl[3];
 #pragma unroll
-      for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 + 2) & 3) * G::SLOT + tb;
+      for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 - 2 + G::WSLOT) % G::WSLOT) * G::SLOT + tb;
       const char* gp = lds + db + (m & 1) * G::DSLOT;
       float gm[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};       // dy[col - 1], dy[col] of the thread's OWN outputs (0 outside its quarter)
       uint32_t raw[2][9], graw[2] = {0u, 0u};
@@ -305,9 +378,11 @@ template <int TB, int D3, int DIR>
 int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int64_t B, int D1, int D2, int C, hipStream_t s) {
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
-  const size_t shm = 4 * G::SLOT;
-  static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G::SLOT) == hipSuccess; }();
-  if (!once) return 1;
+  constexpr int SHM = G::NSLOT * G::SLOT + G::ROWB;
+  static_assert(G::DEPTH >= 1, "three live planes and at least one in flight");
+  const size_t shm = SHM;
+  static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
+  if (!once) { (void)hipGetLastError(); return 1; }
   hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, D1, D2, C, ntile);
   return 0;
 }
@@ -316,10 +391,11 @@ template <int TB, int D3>
 int launch_wgrad(const bf16_t* dy, const bf16_t* x, float* part, int64_t B, int D1, int D2, int C, hipStream_t s) {
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
-  constexpr int SHM = 4 * G::SLOT + 2 * G::DSLOT;
+  constexpr int SHM = G::WSLOT * G::SLOT + 2 * G::DSLOT + G::ROWB;
   static_assert(SHM >= G::NCW * 16 * 57 * 4, "fold scratch must fit in the ring");
+  if (SHM > G::LDS_MAX) return 1;                        // e.g. 12-row tiles of D3 = 32: the first-generation kernel takes over
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_wgrad_march_kernel<TB, D3>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
-  if (!once) return 1;
+  if (!once) { (void)hipGetLastError(); return 1; }
   hipLaunchKernelGGL((peg_wgrad_march_kernel<TB, D3>), dim3((unsigned)(B * ntile * (C / PCC))), dim3(G::NCW * 64), SHM, s, dy, x, part, D1, D2, C, ntile);
   return 0;
 }

@@ -169,9 +169,10 @@ def test_attn2_work_item_decode_covers_every_item_once():
 
 
 # ---------------------------------------------------------------------------------------------------- PEG marching kernels
-def _peg_march_model(x, w, bias, direction, TB, PSEG=4):
-    """csrc/peg_lds.hip peg_march_kernel step for step: ring of four LDS slots (halo rows / zero columns), march index m,
-    tap d1 <-> slot (m + d1 + 2) & 3, row r + d2, input column jj scattered into three rotating accumulators."""
+def _peg_march_model(x, w, bias, direction, TB, PSEG=4, NS=6):
+    """csrc/peg_lds.hip peg_march_kernel step for step: ring of NS LDS slots (halo rows / zero columns), plane m + NS - 3 fetched in
+    step m, tap d1 <-> slot (m + d1 - 2) % NS, row r + d2, input column jj scattered into three rotating accumulators."""
+    DEPTH = NS - 3
     import numpy as np
     B, D1, D2, D3, C = x.shape
     L = D3 // PSEG
@@ -183,18 +184,19 @@ def _peg_march_model(x, w, bias, direction, TB, PSEG=4):
     bv = bias if direction > 0 else np.zeros(C, x.dtype)
     for b in range(B):
         for beta0 in range(0, D2, TB):
-            slots = np.zeros((4, TB + 2, D3 + 2, C), x.dtype)
+            slots = np.zeros((NS, TB + 2, D3 + 2, C), x.dtype)
             plane_of = (lambda m: m) if direction > 0 else (lambda m: D1 - 1 - m)
 
             def dma(m):
                 for i in range(TB + 2):
                     beta = beta0 - 1 + i
                     if 0 <= beta < D2:
-                        slots[m & 3, i, 1:D3 + 1] = x[b, plane_of(m), beta]
-            dma(0)
+                        slots[m % NS, i, 1:D3 + 1] = x[b, plane_of(m), beta]
+            for m in range(min(DEPTH, D1)):
+                dma(m)
             for m in range(D1):
-                if m + 1 < D1:
-                    dma(m + 1)                                   # overwrites the slot of march plane m - 3
+                if m + DEPTH < D1:
+                    dma(m + DEPTH)                               # overwrites the slot of march plane m - 3
                 for r in range(TB):
                     if beta0 + r >= D2:
                         continue
@@ -204,7 +206,7 @@ def _peg_march_model(x, w, bias, direction, TB, PSEG=4):
                         for jj in range(L + 2):
                             for d1 in range(3):
                                 for d2 in range(3):
-                                    xs = slots[(m + d1 + 2) & 3, r + d2, g0 + jj]
+                                    xs = slots[(m + d1 - 2) % NS, r + d2, g0 + jj]
                                     if jj <= L - 1:
                                         accp = accp + wk[:, d1, d2, 0] * xs
                                     if 1 <= jj <= L:
@@ -217,7 +219,7 @@ def _peg_march_model(x, w, bias, direction, TB, PSEG=4):
     return y
 
 
-def _peg_wgrad_model(dy, x, TB, PSEG=4):
+def _peg_wgrad_model(dy, x, TB, PSEG=4, NS=5):
     """peg_wgrad_march_kernel: own dy window (zero outside the thread's quarter), x column jj meets dy[col + 1], dy[col], dy[col - 1]."""
     import numpy as np
     B, D1, D2, D3, C = x.shape
@@ -225,22 +227,27 @@ def _peg_wgrad_model(dy, x, TB, PSEG=4):
     dw, db = np.zeros((C, 3, 3, 3), x.dtype), np.zeros(C, x.dtype)
     for b in range(B):
         for beta0 in range(0, D2, TB):
-            slots = np.zeros((4, TB + 2, D3 + 2, C), x.dtype)
+            slots = np.zeros((NS, TB + 2, D3 + 2, C), x.dtype)
             gsl = np.zeros((2, TB, D3, C), x.dtype)
 
-            def dma(m):
+            def dma_x(m):
                 for i in range(TB + 2):
                     beta = beta0 - 1 + i
                     if 0 <= beta < D2:
-                        slots[m & 3, i, 1:D3 + 1] = x[b, m, beta]
-                gsl[m & 1] = 0                                   # (rows past D2 are never written: they stay zero)
-                for i in range(TB):
+                        slots[m % NS, i, 1:D3 + 1] = x[b, m, beta]
+
+            def dma_g(m):
+                for i in range(TB):                              # (rows past D2 are never written: they stay zero)
                     if beta0 + i < D2:
                         gsl[m & 1, i] = dy[b, m, beta0 + i]
-            dma(0)
+            dma_x(0), dma_g(0)
+            if D1 > 1:
+                dma_x(1)
             for m in range(D1):
                 if m + 1 < D1:
-                    dma(m + 1)
+                    dma_g(m + 1)
+                if m + 2 < D1:
+                    dma_x(m + 2)
                 for r in range(TB):
                     for seg in range(PSEG):
                         g0 = seg * L
@@ -251,7 +258,7 @@ def _peg_wgrad_model(dy, x, TB, PSEG=4):
                                 db += gq
                             for d1 in range(3):
                                 for d2 in range(3):
-                                    xs = slots[(m + d1 + 2) & 3, r + d2, g0 + jj]
+                                    xs = slots[(m + d1 - 2) % NS, r + d2, g0 + jj]
                                     if jj <= L - 1:
                                         dw[:, d1, d2, 0] += gq * xs
                                     if 1 <= jj <= L:
