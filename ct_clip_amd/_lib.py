@@ -40,6 +40,10 @@ SIGNATURES = {
     "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
     "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
+    "ctclip_attn_short_supported": (_I, [_I, _I, _I]),
+    "ctclip_attn_short_fwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    "ctclip_attn_short_bwd_workspace": (_L, [_I, _I]),
+    "ctclip_attn_short_bwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _P, _L, _P]),
     "ctclip_attn2_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "ctclip_attn2_prep": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _P]),
     "ctclip_attn2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _I, _I, _I, _P]),

@@ -273,6 +273,31 @@ class HipBackend:
                                       _stream())
         _lib.check(rc, "ctclip_attn_bwd")
 
+    # ------------------------------------------------------------------ short-sequence attention (csrc/attn_short.hip)
+    def attn_short_supported(self, dtype, L, D):
+        return dtype == torch.bfloat16 and bool(self.lib.ctclip_attn_short_supported(int(L), int(D), dcode(dtype)))
+
+    def attn_short_fwd(self, q, kv, q_scale, k_scale, nseq, L, H, scale):
+        """q (M, H*32), kv (M, 2*H*32) = [k | v] row-major bf16 -> o (M, H*32)."""
+        M = q.shape[0]
+        o = torch.empty((M, H * 32), dtype=q.dtype, device=q.device)
+        rc = self.lib.ctclip_attn_short_fwd(_p(q), _rowmajor(q, "q"), _p(kv), _rowmajor(kv, "kv"), _p(q_scale), _p(k_scale), _p(o), H * 32,
+                                            nseq, H, L, float(scale), _stream())
+        _lib.check(rc, "ctclip_attn_short_fwd")
+        return o
+
+    def attn_short_bwd(self, q, kv, q_scale, k_scale, do, nseq, L, H, scale, dq_scale=None, dk_scale=None):
+        """-> dq (M, H*32), dkv (M, 2*H*32); dq_scale / dk_scale (32) f32 are accumulated into when given."""
+        M = q.shape[0]
+        dq = torch.empty((M, H * 32), dtype=q.dtype, device=q.device)
+        dkv = torch.empty((M, 2 * H * 32), dtype=q.dtype, device=q.device)
+        ws = self.workspace(q.device, self.lib.ctclip_attn_short_bwd_workspace(nseq, H))
+        rc = self.lib.ctclip_attn_short_bwd(_p(q), _rowmajor(q, "q"), _p(kv), _rowmajor(kv, "kv"), _p(q_scale), _p(k_scale), _p(do),
+                                            _rowmajor(do, "do"), _p(dq), H * 32, _p(dkv), 2 * H * 32, _p(dq_scale), _p(dk_scale), nseq, H, L,
+                                            float(scale), _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_attn_short_bwd")
+        return dq, dkv
+
     # ------------------------------------------------------------------ attention, second generation (csrc/attn2.hip)
     def attn2_supported(self, dtype, H, L, D, bias_grid, has_bias):
         gh, gw = bias_grid if bias_grid is not None else (0, 0)

@@ -465,8 +465,34 @@ class CosineAttn2Fn(Function):
                 None, None, None, None, None, None)
 
 
+class CosineAttnShortFn(Function):
+    """The same operator for sequences of at most 32 tokens (csrc/attn_short.hip: CTViT's temporal transformer): one wave per
+    (sequence, head), q / kv read and o / dq / dkv written in place -- nothing saved but the inputs, no layout passes."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_scale, k_scale, nseq, L, H, scale):
+        o = B().attn_short_fwd(q, kv, q_scale.detach(), k_scale.detach(), nseq, L, H, scale)
+        ctx.save_for_backward(q, kv)
+        ctx.scales = (q_scale, k_scale)
+        ctx.dims = (nseq, L, H, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv = ctx.saved_tensors
+        nseq, L, H, scale = ctx.dims
+        q_scale, k_scale = ctx.scales
+        qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
+        dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
+        dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
+        dq, dkv = B().attn_short_bwd(q, kv, q_scale.detach(), k_scale.detach(), do.contiguous(), nseq, L, H, scale, dqs, dks)
+        return dq, dkv, None if qs_sink is not None else dqs, None if ks_sink is not None else dks, None, None, None, None
+
+
 def cosine_attention(q, kv, q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid=None):
     """attention.py:145-178 on whichever kernel generation serves the shape (bias: the (ncls, H) table when bias_grid is given)."""
+    if bias is None and B().attn_short_supported(q.dtype, L, D):
+        return CosineAttnShortFn.apply(q, kv, q_scale, k_scale, nseq, L, H, scale)
     table = bias is not None and bias_grid is not None
     if (bias is None or table) and B().attn2_supported(q.dtype, H, L, D, bias_grid if table else None, table):
         return CosineAttn2Fn.apply(q, kv, q_scale, k_scale, bias if table else None, nseq, L, H, D, scale, bias_grid if table else None)

@@ -65,6 +65,18 @@ int64_t ctclip_attn2_unprep_workspace(void);
 /* TODO: document */
 int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* TODO: document */
+int ctclip_attn_short_supported(int L, int D, int dtype);
+
+/* TODO: document */
+int ctclip_attn_short_fwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, void* out, int64_t ldo, int nseq, int H, int L, float scale, hipStream_t stream);
+
+/* TODO: document */
+int64_t ctclip_attn_short_bwd_workspace(int nseq, int H);
+
+/* TODO: document */
+int ctclip_attn_short_bwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, const void* dout, int64_t lddo, void* dq, int64_t lddq, void* dkv, int64_t lddkv, float* dq_scale, float* dk_scale, int nseq, int H, int L, float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* thread-local message of the last failing call. */
 const char* ctclip_last_error(void);
 

@@ -182,6 +182,34 @@ class RefBackend:
     # ---- attention, second generation (head-planar operands; spec of csrc/attn2.hip)
     LOG2E = 1.4426950408889634
 
+    # short-sequence cosine attention (csrc/attn_short.hip): torch f32 on the same inputs
+    def attn_short_supported(self, dtype, L, D):
+        return dtype == torch.bfloat16 and D == 32 and 1 <= L <= 32
+
+    @staticmethod
+    def _short_graph(q, kv, q_scale, k_scale, nseq, L, H, scale):
+        HD = H * 32
+        qf, kf, vf = (t.float().view(nseq, L, H, 32).transpose(1, 2) for t in (q, kv[:, :HD], kv[:, HD:]))
+        qn = F.normalize(qf, dim=-1) * q_scale
+        kn = F.normalize(kf, dim=-1) * k_scale
+        p = torch.softmax(qn @ kn.transpose(-1, -2) * scale, dim=-1)
+        return (p @ vf).transpose(1, 2).reshape(nseq * L, HD)
+
+    def attn_short_fwd(self, q, kv, q_scale, k_scale, nseq, L, H, scale):
+        return self._short_graph(q, kv, q_scale.float(), k_scale.float(), nseq, L, H, scale).to(q.dtype)
+
+    def attn_short_bwd(self, q, kv, q_scale, k_scale, do, nseq, L, H, scale, dq_scale=None, dk_scale=None):
+        qd, kvd = q.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+        qs, ks = q_scale.detach().float().clone().requires_grad_(True), k_scale.detach().float().clone().requires_grad_(True)
+        with torch.enable_grad():
+            o = self._short_graph(qd, kvd, qs, ks, nseq, L, H, scale)
+            dq, dkv, dqs, dks = torch.autograd.grad(o, (qd, kvd, qs, ks), do.float())
+        if dq_scale is not None:
+            dq_scale += dqs
+        if dk_scale is not None:
+            dk_scale += dks
+        return dq.to(q.dtype), dkv.to(q.dtype)
+
     def attn2_supported(self, dtype, H, L, D, bias_grid, has_bias):
         if dtype != torch.bfloat16 or D != 32 or L % 32 or L < 64 or L > 1024:
             return False

@@ -172,6 +172,34 @@ def test_l2norm_rows(hip, ref, dtype):
     close(y32, ref.l2norm_rows(rnd(16, 64, seed=7), torch.float32)[0], rtol=1e-5, atol=1e-6)
 
 
+# ---------------------------------------------------------------- short-sequence cosine attention (csrc/attn_short.hip)
+@pytest.mark.parametrize("nseq,H,L,strided", [(5, 8, 24, False), (3, 2, 32, False), (7, 3, 1, False), (4, 8, 2, True), (300, 8, 24, True),
+                                              (2, 1, 9, False), (1100, 8, 24, False)])
+def test_attn_short_fwd_bwd(hip, ref, nseq, H, L, strided):
+    """One wave per (sequence, head): forward, dq / dk / dv and the learned-scale gradients against torch f32 on the same bf16
+    inputs; `strided`: q / kv / do are column slices of wider buffers (leading dimension > H * 32)."""
+    M, HD, bf = nseq * L, H * 32, torch.bfloat16
+    pad = 64 if strided else 0
+    q = rnd(M, HD + pad, dtype=bf, seed=1)[:, :HD]
+    kv = rnd(M, 2 * HD + pad, dtype=bf, seed=2)[:, :2 * HD]
+    do = rnd(M, HD + pad, dtype=bf, seed=3)[:, :HD]
+    qs, ks = 1.0 + 0.3 * rnd(32, seed=4), 1.0 + 0.3 * rnd(32, seed=5)
+    assert hip.attn_short_supported(bf, L, 32)
+    o, orf = hip.attn_short_fwd(q, kv, qs, ks, nseq, L, H, 8.0), ref.attn_short_fwd(q, kv, qs, ks, nseq, L, H, 8.0)
+    close(o, orf, rtol=3e-2, atol=3e-2)
+    dqs, dks = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    dqsr, dksr = dqs.clone(), dks.clone()
+    dq, dkv = hip.attn_short_bwd(q, kv, qs, ks, do, nseq, L, H, 8.0, dqs, dks)
+    dqr, dkvr = ref.attn_short_bwd(q, kv, qs, ks, do, nseq, L, H, 8.0, dqsr, dksr)
+    for a, b, what in ((dq, dqr, "dq"), (dkv[:, :HD], dkvr[:, :HD], "dk"), (dkv[:, HD:], dkvr[:, HD:], "dv"), (dqs, dqsr, "dq_scale"), (dks, dksr, "dk_scale")):
+        err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+        assert err < 2e-2, (what, err)
+    # deterministic: the second run reproduces the first bit for bit (fixed summation order of the scale gradients)
+    dqs2, dks2 = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    dq2, dkv2 = hip.attn_short_bwd(q, kv, qs, ks, do, nseq, L, H, 8.0, dqs2, dks2)
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2) and torch.equal(dqs, dqs2) and torch.equal(dks, dks2)
+
+
 # ---------------------------------------------------------------- PEG
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(2, 2, 4, 4, 128), (1, 5, 3, 7, 64), (2, 24, 6, 6, 512),

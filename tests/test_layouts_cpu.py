@@ -307,3 +307,95 @@ def test_peg_marching_lds_reads_are_bank_conflict_free():
                             a = (r * rsp + g0 + jj) * 64 + pr * 4
                             banks.add((a // 4) % 32)
                         assert len(banks) == 32, (D3, what, g0, jj)
+
+
+# ---------------------------------------------------------------------------------------------------- short-sequence attention
+class _ShortAttnModel:
+    """csrc/attn_short.hip lane by lane: layout R, the 32x32x16 MFMA operand / accumulator maps, ds_read_b64_tr_b16."""
+
+    @staticmethod
+    def dims(half):                                  # the 16 head dims (or tokens) of a lane, register order 4 j + r
+        return [8 * j + 4 * half + r for j in range(4) for r in range(4)]
+
+    @classmethod
+    def rows(cls, X):                                # (32, 32) row-major -> per-lane registers [64][16]
+        import numpy as np
+        return np.array([[X[lane & 31, d] for d in cls.dims(lane >> 5)] for lane in range(64)])
+
+    @classmethod
+    def mma(cls, A, B):
+        """v_mfma_f32_32x32x16 x 2: lane (m | n = lane & 31, half) supplies contraction slots (t, half, i) = its registers 8 t + i;
+        result lane (n, half) register 4 j + r = D[8 j + 4 half + r][n]."""
+        import numpy as np
+        Dm = np.zeros((32, 32))
+        for m in range(32):
+            for n in range(32):
+                Dm[m, n] = sum(A[m + 32 * half, k] * B[n + 32 * half, k] for half in range(2) for k in range(16))
+        return np.array([[Dm[d, lane & 31] for d in cls.dims(lane >> 5)] for lane in range(64)])
+
+    @classmethod
+    def tile_cols(cls, X):
+        """tile_write of rows(X) then tile_cols: lane (m = lane & 31, half) gets X[token][m] for its 16 tokens, through the measured
+        ds_read_b64_tr_b16 rule on the byte image of the tile."""
+        import numpy as np
+        tile = np.zeros((32, 32))                    # [token][dim] (2-byte elements)
+        R = cls.rows(X)
+        for lane in range(64):
+            row, half = lane & 31, lane >> 5
+            for j in range(4):
+                for r in range(4):
+                    tile[row, 8 * j + 4 * half + r] = R[lane, 4 * j + r]        # ds_write_b64 at row * 64 + 16 j + 8 half
+        out = np.zeros((64, 16))
+        for lane in range(64):
+            g16, i = lane >> 4, lane & 15
+            for blk, off in enumerate((0, 512, 1024, 1536)):
+                for j in range(4):                   # element j of the result comes from the address of lane 4 j + (i >> 2) of the group
+                    src = 16 * g16 + 4 * j + (i >> 2)
+                    t16, grp, half = src & 15, (src >> 4) & 1, src >> 5
+                    addr = (4 * half + (t16 >> 2)) * 64 + (16 * grp + 4 * (t16 & 3)) * 2 + off
+                    token, dim = addr // 64, (addr % 64) // 2 + (i & 3)
+                    out[lane, 4 * blk + j] = tile[token, dim]
+        return out
+
+
+def test_short_attention_lane_maps():
+    """Forward and backward of attn_short.hip in the kernel's own register layouts against plain matrix algebra."""
+    import numpy as np
+    M = _ShortAttnModel
+    rng = np.random.default_rng(0)
+    Q, K, V, dO = (rng.standard_normal((32, 32)) for _ in range(4))
+    # transposed fragments: lane (m, half) holds X[token][m] for tokens dims(half)
+    T = M.tile_cols(V)
+    for lane in range(64):
+        assert np.allclose(T[lane], [V[tok, lane & 31] for tok in M.dims(lane >> 5)])
+    # S^T = K Q^T with queries as columns; O^T = V^T P
+    St = M.mma(M.rows(K), M.rows(Q))
+    S = Q @ K.T
+    for lane in range(64):
+        assert np.allclose(St[lane], [S[lane & 31, key] for key in M.dims(lane >> 5)])
+    P = np.exp(S - S.max(1, keepdims=True)); P /= P.sum(1, keepdims=True)
+    Pt = np.array([[P[lane & 31, key] for key in M.dims(lane >> 5)] for lane in range(64)])      # what the lanes hold after the softmax
+    Ot = M.mma(M.tile_cols(V), Pt)
+    O = P @ V
+    for lane in range(64):
+        assert np.allclose(Ot[lane], [O[lane & 31, d] for d in M.dims(lane >> 5)])               # layout R of the query row: store_row
+    # backward, queries as columns: dP^T = V dO^T, dQ = dS K
+    dPt = M.mma(M.rows(V), M.rows(dO))
+    dP = dO @ V.T
+    for lane in range(64):
+        assert np.allclose(dPt[lane], [dP[lane & 31, key] for key in M.dims(lane >> 5)])
+    dS = P * (dP - (P * dP).sum(1, keepdims=True))
+    dSt = np.array([[dS[lane & 31, key] for key in M.dims(lane >> 5)] for lane in range(64)])
+    dQt = M.mma(M.tile_cols(K), dSt)
+    for lane in range(64):
+        assert np.allclose(dQt[lane], [(dS @ K)[lane & 31, d] for d in M.dims(lane >> 5)])
+    # keys as columns: S = Q K^T (rows = queries), dK = dS^T Q, dV = P^T dO
+    S2 = M.mma(M.rows(Q), M.rows(K))
+    for lane in range(64):
+        assert np.allclose(S2[lane], [S[q, lane & 31] for q in M.dims(lane >> 5)])
+    dS2 = np.array([[dS[q, lane & 31] for q in M.dims(lane >> 5)] for lane in range(64)])
+    P2 = np.array([[P[q, lane & 31] for q in M.dims(lane >> 5)] for lane in range(64)])
+    dKt, dVt = M.mma(M.tile_cols(Q), dS2), M.mma(M.tile_cols(dO), P2)
+    for lane in range(64):
+        assert np.allclose(dKt[lane], [(dS.T @ Q)[lane & 31, d] for d in M.dims(lane >> 5)])
+        assert np.allclose(dVt[lane], [(P.T @ dO)[lane & 31, d] for d in M.dims(lane >> 5)])

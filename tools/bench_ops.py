@@ -107,6 +107,14 @@ if what in ("tattn", "all"):
     out["attn_fwd temporal (4608 x 24)"] = dict(avg_us=round(timeit(lambda: be.attn_fwd(q, k, vt, None, None, nseq, H, L, D, 8.0)), 1))
     out["attn_bwd temporal (4608 x 24)"] = dict(avg_us=round(timeit(
         lambda: be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, None, dq, dk, dv, None, nseq, H, L, D, 8.0)), 1))
+    # the same on the one-wave-per-problem kernels (csrc/attn_short.hip): q / kv in, o / dq / dkv out, nothing else
+    qq, kkv = rnd(M, HD), rnd(M, 2 * HD)
+    qs, ks = torch.ones(32, device=dev), torch.ones(32, device=dev)
+    dqs, dks = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
+    us = timeit(lambda: be.attn_short_fwd(qq, kkv, qs, ks, nseq, L, H, 8.0))
+    out["attn_short_fwd temporal (4608 x 24)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(4 * M * HD * 2 / us / 1e3, 1))
+    us = timeit(lambda: be.attn_short_bwd(qq, kkv, qs, ks, do, nseq, L, H, 8.0, dqs, dks))
+    out["attn_short_bwd temporal (4608 x 24)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(7 * M * HD * 2 / us / 1e3, 1))
 if what in ("stream", "all"):
     M, d, Hp = 110592, 512, 1408
     x, dy = rnd(M, d), rnd(M, d)
