@@ -333,28 +333,64 @@ class _ShortAttnModel:
                 Dm[m, n] = sum(A[m + 32 * half, k] * B[n + 32 * half, k] for half in range(2) for k in range(16))
         return np.array([[Dm[d, lane & 31] for d in cls.dims(lane >> 5)] for lane in range(64)])
 
+    @staticmethod
+    def tile_off(row, byte):                         # 16-byte chunk c of row r lives at chunk position c ^ ((r >> 2) & 3)
+        return row * 64 + ((((byte >> 4) ^ (row >> 2)) & 3) << 4) + (byte & 15)
+
     @classmethod
-    def tile_cols(cls, X):
-        """tile_write of rows(X) then tile_cols: lane (m = lane & 31, half) gets X[token][m] for its 16 tokens, through the measured
-        ds_read_b64_tr_b16 rule on the byte image of the tile."""
+    def tile_image(cls, X, how):
+        """the 2-KB tile as {byte address: element}: written by tile_write from layout R, or by the two LDS-DMA instructions of tile_fetch"""
+        img = {}
+        if how == "write":
+            R = cls.rows(X)
+            for lane in range(64):
+                row, half = lane & 31, lane >> 5
+                for j in range(4):
+                    for r in range(4):                                           # ds_write_b64 at tile_off(row, 16 j + 8 half)
+                        img[cls.tile_off(row, 16 * j + 8 * half) + 2 * r] = R[lane, 4 * j + r]
+        else:
+            for e in range(2):
+                for lane in range(64):                                           # lane's 16 bytes land at e * 1024 + 16 lane
+                    row = 16 * e + (lane >> 2)
+                    c = (lane ^ (row >> 2)) & 3                                  # the global chunk the lane fetches
+                    for k in range(8):
+                        img[e * 1024 + 16 * lane + 2 * k] = X[row, 8 * c + k]
+        return img
+
+    @classmethod
+    def tile_cols(cls, X, how="write"):
+        """tile_cols: lane (m = lane & 31, half) gets X[token][m] for its 16 tokens, through the measured ds_read_b64_tr_b16 rule."""
         import numpy as np
-        tile = np.zeros((32, 32))                    # [token][dim] (2-byte elements)
-        R = cls.rows(X)
-        for lane in range(64):
-            row, half = lane & 31, lane >> 5
-            for j in range(4):
-                for r in range(4):
-                    tile[row, 8 * j + 4 * half + r] = R[lane, 4 * j + r]        # ds_write_b64 at row * 64 + 16 j + 8 half
+        img = cls.tile_image(X, how)
         out = np.zeros((64, 16))
         for lane in range(64):
             g16, i = lane >> 4, lane & 15
-            for blk, off in enumerate((0, 512, 1024, 1536)):
+            for blk in range(4):                     # reads: (a0, +0), (a1, +0), (a0, +1024), (a1, +1024)
                 for j in range(4):                   # element j of the result comes from the address of lane 4 j + (i >> 2) of the group
                     src = 16 * g16 + 4 * j + (i >> 2)
                     t16, grp, half = src & 15, (src >> 4) & 1, src >> 5
-                    addr = (4 * half + (t16 >> 2)) * 64 + (16 * grp + 4 * (t16 & 3)) * 2 + off
-                    token, dim = addr // 64, (addr % 64) // 2 + (i & 3)
-                    out[lane, 4 * blk + j] = tile[token, dim]
+                    tok, byte = 4 * half + (t16 >> 2) + (8 if blk & 1 else 0), 32 * grp + 8 * (t16 & 3)
+                    addr = cls.tile_off(tok, byte) + (1024 if blk >= 2 else 0)
+                    out[lane, 4 * blk + j] = img[addr + 2 * (i & 3)]
+        return out
+
+    @classmethod
+    def tile_rows(cls, X, how):
+        """tile_read: layout R of the lane's row from the tile image"""
+        import numpy as np
+        img = cls.tile_image(X, how)
+        return np.array([[img[cls.tile_off(lane & 31, 16 * j + 8 * (lane >> 5)) + 2 * r] for j in range(4) for r in range(4)] for lane in range(64)])
+
+    @classmethod
+    def tile_store_rows(cls, X):
+        """tile_write of layout R then tile_store: (row, chunk, eight elements) of every 16-byte store"""
+        img = cls.tile_image(X, "write")
+        out = {}
+        for e in range(2):
+            for lane in range(64):
+                row = 16 * e + (lane >> 2)
+                c = (lane ^ (row >> 2)) & 3
+                out[(row, c)] = [img[e * 1024 + 16 * lane + 2 * k] for k in range(8)]
         return out
 
 
@@ -364,10 +400,19 @@ def test_short_attention_lane_maps():
     M = _ShortAttnModel
     rng = np.random.default_rng(0)
     Q, K, V, dO = (rng.standard_normal((32, 32)) for _ in range(4))
-    # transposed fragments: lane (m, half) holds X[token][m] for tokens dims(half)
-    T = M.tile_cols(V)
-    for lane in range(64):
-        assert np.allclose(T[lane], [V[tok, lane & 31] for tok in M.dims(lane >> 5)])
+    # transposed fragments: lane (m, half) holds X[token][m] for tokens dims(half) -- from a tile written from registers or by the DMA
+    for how in ("write", "dma"):
+        T = M.tile_cols(V, how)
+        for lane in range(64):
+            assert np.allclose(T[lane], [V[tok, lane & 31] for tok in M.dims(lane >> 5)])
+        assert np.allclose(M.tile_rows(V, how), M.rows(V))                                       # tile_read gives layout R
+    for (row, c), vals in M.tile_store_rows(V).items():                                          # staged stores: 16 B = dims 8 c .. 8 c + 7
+        assert np.allclose(vals, V[row, 8 * c:8 * c + 8])
+    # swizzled row reads: at most two lanes of a 32-lane ds_read_b64 group share a bank pair
+    for half in range(2):
+        for j in range(4):
+            banks = [M.tile_off(row, 16 * j + 8 * half) // 8 % 32 for row in range(32)]
+            assert max(banks.count(b) for b in set(banks)) <= 2
     # S^T = K Q^T with queries as columns; O^T = V^T P
     St = M.mma(M.rows(K), M.rows(Q))
     S = Q @ K.T
