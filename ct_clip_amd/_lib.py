@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTCLIP_LIB") or os.path.join(_HERE, "libctclip_hip.so")   # CTCLIP_LIB: profiling builds only
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
-_U64, _U32 = ctypes.c_uint64, ctypes.c_uint32
+_U64, _U32, _D = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double
 
 # name -> (restype, argtypes).  Every entry point ends with a hipStream_t (void*) unless noted.
 SIGNATURES = {
@@ -40,6 +40,7 @@ SIGNATURES = {
     "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
     "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
+    "ctclip_preprocess_volume": (_I, [_P, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, _P, _I, _I, _I, _D, _D, _D, _F, _P]),
     "ctclip_attn_short_supported": (_I, [_I, _I, _I]),
     "ctclip_attn_short_fwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "ctclip_attn_short_bwd_workspace": (_L, [_I, _I]),

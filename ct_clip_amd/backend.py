@@ -273,6 +273,21 @@ class HipBackend:
                                       _stream())
         _lib.check(rc, "ctclip_attn_bwd")
 
+    # ------------------------------------------------------------------ input pipeline (csrc/preprocess.hip)
+    def preprocess_volume(self, vox, slope, intercept, xy_spacing, z_spacing, target_xy=0.75, target_z=1.5, out_shape=(480, 480, 240),
+                          hu_range=(-1000.0, 1000.0), hu_div=1000.0, pad_value=-1.0):
+        """vox: (H, W, D) int16 / f32 / f64 voxel array on the device -> (1, out_d, out_h, out_w) f32 model input."""
+        code = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[vox.dtype]
+        assert vox.dim() == 3 and vox.is_contiguous()
+        H, W, D = vox.shape
+        oh, ow, od = out_shape
+        out = torch.empty((1, od, oh, ow), dtype=torch.float32, device=vox.device)
+        rc = self.lib.ctclip_preprocess_volume(_p(vox), code, H, W, D, float(slope), float(intercept), float(xy_spacing), float(z_spacing),
+                                               float(target_xy), float(target_z), _p(out), oh, ow, od, float(hu_range[0]), float(hu_range[1]),
+                                               float(hu_div), float(pad_value), _stream())
+        _lib.check(rc, "ctclip_preprocess_volume")
+        return out
+
     # ------------------------------------------------------------------ short-sequence attention (csrc/attn_short.hip)
     def attn_short_supported(self, dtype, L, D):
         return dtype == torch.bfloat16 and bool(self.lib.ctclip_attn_short_supported(int(L), int(D), dcode(dtype)))

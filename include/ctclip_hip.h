@@ -222,6 +222,9 @@ int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, floa
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s);
 
 /* TODO: document */
+int ctclip_preprocess_volume(const void* src, int src_dtype, int H, int W, int D, double slope, double intercept, double xy_spacing, double z_spacing, double target_xy, double target_z, float* out, int out_h, int out_w, int out_d, double hu_lo, double hu_hi, double hu_div, float pad_value, hipStream_t stream);
+
+/* TODO: document */
 int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);
 
 /* TODO: document */

@@ -331,9 +331,65 @@ def run_finetune_case(name="finetune_tiny", base="tiny"):
           f"({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+PREPROCESS_CASES = {
+    # name: (seed, (H, W, D), source dtype, slope, intercept, XYSpacing, ZSpacing)
+    "pad": (11, (200, 180, 90), "int16", 1.0, -1024.0, 1.1, 2.5),          # resampled (293, 264, 150): padded on every axis
+    "crop": (12, (420, 400, 210), "int16", 1.0, -1024.0, 0.95, 1.9),       # resampled (532, 506, 266): cropped on every axis
+    "float": (13, (100, 120, 60), "float32", 0.5, 10.0, 0.75, 1.5),        # identity resample, non-unit slope, float voxels
+}
+PREPROCESS_STRIDE = (7, 11, 13)
+
+
+def run_preprocess_case():
+    """tests/golden/preprocess.pt: outputs of the REAL CTReportDataset.nii_img_to_tensor (scripts/data.py:92-162) on synthetic volumes.
+    nibabel (absent here) is replaced by a loader that returns the in-memory array as float64, exactly what get_fdata() yields."""
+    import importlib.util
+    import types
+    import numpy as np
+    import pandas as pd
+    from oracle import preprocess_oracle as PO
+    store = {}
+    fake = types.ModuleType("nibabel")
+
+    class _Img:
+        def __init__(self, arr):
+            self.arr = arr
+
+        def get_fdata(self):
+            return np.asarray(self.arr, dtype=np.float64)
+    fake.load = lambda path: _Img(store[str(path)])
+    sys.modules["nibabel"] = fake
+    spec = importlib.util.spec_from_file_location("ref_scripts_data", os.path.join(ref_shim.REF_ROOT, "scripts", "data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for name, (seed, shape, dt, slope, intercept, xy, z) in PREPROCESS_CASES.items():
+        vox = PO.synthetic_volume(seed, shape)
+        if dt == "float32":
+            vox = vox.astype(np.float32) * 0.37
+        fname = f"{name}.nii.gz"
+        store[f"/data/{fname}"] = vox
+        df = pd.DataFrame([dict(VolumeName=fname, RescaleSlope=slope, RescaleIntercept=intercept, XYSpacing=f"[{xy}, {xy}]", ZSpacing=z)])
+        y = mod.CTReportDataset.nii_img_to_tensor(None, f"/data/{fname}", df)          # the reference method itself
+        mine = PO.volume_to_tensor(vox, slope, intercept, xy, z)
+        assert y.shape == (1, 240, 480, 480) and y.dtype == torch.float32
+        assert torch.equal(y, mine), f"{name}: the restatement differs from the reference"
+        sd, sh, sw = PREPROCESS_STRIDE
+        out[name] = dict(seed=seed, shape=shape, dtype=dt, slope=slope, intercept=intercept, xy=xy, z=z,
+                         sample=y[0, ::sd, ::sh, ::sw].clone(), sum=y.double().sum(), abs_sum=y.double().abs().sum(),
+                         n_pad=(y == -1).sum(), slab=y[0, 117:123, 236:244, 232:248].clone())
+        print(f"preprocess/{name}: sum {float(out[name]['sum']):.4f} pads {int(out[name]['n_pad'])}")
+    path = os.path.join(OUT, "preprocess.pt")
+    torch.save(out, path)
+    print(f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(CASES)
     for name in which:
+        if name == "preprocess":
+            run_preprocess_case()
+            continue
         if name == "full1":
             run_full_case()
         elif name == "finetune_tiny":

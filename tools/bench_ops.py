@@ -1,6 +1,6 @@
 """Stand-alone timing of the non-GEMM hot kernels at the bench shapes (bf16, B=8): PEG, spatial / temporal attention, the streaming
 kernels (LayerNorm, GEGLU, qk-norm, head transpose).
-usage: python tools/bench_ops.py [peg|attn|tattn|stream|all] [iters]"""
+usage: python tools/bench_ops.py [peg|attn|tattn|stream|prep|all] [iters]"""
 import json
 import os
 import sys
@@ -139,4 +139,10 @@ if what in ("stream", "all"):
     out["qk_norm_fwd (110592 x 256)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(2 * q.numel() * 2 / us / 1e3, 1))
     us = timeit(lambda: be.head_transpose(q, 192, 8, 576, 32))
     out["head_transpose (192 x 8 x 576 x 32)"] = dict(avg_us=round(us, 1), algorithmic_GBps=round(2 * q.numel() * 2 / us / 1e3, 1))
+if what in ("prep", "all"):
+    # the input pipeline on a typical chest CT: 512 x 512 x 300 int16 at 0.8 x 0.8 x 1.0 mm -> (1, 240, 480, 480) f32
+    from ct_clip_amd import preprocess as PP
+    vox = torch.randint(-1200, 2000, (512, 512, 300), dtype=torch.int16, device=dev)
+    us = timeit(lambda: PP.volume_to_tensor(vox, 1.0, -1024.0, 0.8, 1.0, device=dev))
+    out["preprocess_volume 512x512x300 int16 -> 240x480x480 f32"] = dict(avg_us=round(us, 1), out_GBps=round(240 * 480 * 480 * 4 / us / 1e3, 1))
 print(json.dumps(out, indent=1))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU session K: short-sequence attention kernels (parity, timing), PEG defaults, full test suite, step time + kernel statistics
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2k; mkdir -p $O
+O=gpurun_out/r2o; mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "attn_short or peg" > $O/t_short.log 2>&1; echo "short/peg tests rc=$? $(tail -n 1 $O/t_short.log)" >> $O/summary.log
 timeout 300 python tools/bench_ops.py tattn 10 > $O/ops_tattn.json 2> $O/ops.err
@@ -14,7 +14,7 @@ cd $GRAFT_REPO_ROOT
 python - <<'PY' > $O/prof_stats.md 2>&1
 import csv, glob, re, collections
 rows = collections.defaultdict(list)
-for path in glob.glob("gpurun_out/r2k/prof/**/*kernel_trace.csv", recursive=True):
+for path in glob.glob("gpurun_out/r2o/prof/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         n = re.sub(r"^void ", "", n).split("(")[0]
