@@ -55,10 +55,8 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
     for li, layer in enumerate(bert.encoder.layer):
         x = Fn.grad_ready(x, layer)
         sa, so = layer.attention.self, layer.attention.output
-        q = Fn.linear(x, sa.query.weight, sa.query.bias)
-        k = Fn.linear(x, sa.key.weight, sa.key.bias)
-        v = Fn.linear(x, sa.value.weight, sa.value.bias)
-        c = Fn.SdpaFn.apply(q, k, v, keymask, Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None)
+        c = Fn.QkvSdpaFn.apply(x, sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias, keymask,
+                               Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None)
         if p_hid > 0:    # dense -> dropout -> + input -> LayerNorm
             h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias), x, 1 + 2 * li)
         else:

@@ -527,6 +527,55 @@ class SdpaFn(Function):
         return dq, dk, dv, None, None, None, None, None, None, None
 
 
+class QkvSdpaFn(Function):
+    """HF BertSelfAttention as one node: q, k, v = x Wq^T + bq, x Wk^T + bk, x Wv^T + bv as ONE GEMM against the stacked weight
+    shadow (3 * hidden outputs: three times the column tiles for the M = B * T = a-few-hundred-rows text tower, one launch instead
+    of three), softmax(q k^T / sqrt(d) + mask) v on column views of that buffer; backward writes dq | dk | dv side by side and
+    runs one grad-input GEMM and three weight-gradient GEMMs on column views."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, keymask, nseq, L, H, D, scale, dropout):
+        be = B()
+        N, K = wq.shape
+
+        def make_w():
+            out = torch.empty((3 * N, K), dtype=x.dtype, device=x.device)
+            for i, w in enumerate((wq, wk, wv)):
+                be.convert_pad(w.detach(), N, K, x.dtype, out=out[i * N:(i + 1) * N])
+            return out
+        # (the stamp of the cache entry is wq's; the fused optimiser bumps the weight epoch, load_state_dict touches all three)
+        wsh = shadow(wq, ("qkv", id(wk), id(wv)), x.dtype, make_w)
+        bias = shadow(bq, ("qkv_bias", id(bk), id(bv)), torch.float32, lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]).float())
+        qkv = be.gemm(x, wsh, bias=bias)
+        q, k, v = qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
+        vt = be.head_transpose(v, nseq, H, L, D)
+        o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale, dropout=dropout)
+        ctx.save_for_backward(x, wsh, qkv, o, lse, keymask if keymask is not None else x.new_empty(0))
+        ctx.params = (wq, wk, wv, bq, bk, bv)
+        ctx.dims = (nseq, L, H, D, scale, keymask is not None, dropout, N, K)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        be = B()
+        x, wsh, qkv, o, lse, keymask = ctx.saved_tensors
+        nseq, L, H, D, scale, has_mask, dropout, N, K = ctx.dims
+        wq, wk, wv, bq, bk, bv = ctx.params
+        do = do.contiguous()
+        q, k, v = qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
+        qt, kt, dot = (be.head_transpose(t, nseq, H, L, D) for t in (q, k, do))
+        dqkv = torch.empty_like(qkv)
+        be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, keymask if has_mask else None, dqkv[:, :N], dqkv[:, N:2 * N], dqkv[:, 2 * N:], None,
+                    nseq, H, L, D, scale, dropout=dropout)
+        dx = be.gemm(dqkv, wsh, a_kc=True, b_kc=False) if ctx.needs_input_grad[0] else None
+        grads = []
+        for i, w in enumerate((wq, wk, wv)):
+            grads.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)
+        for i, b in enumerate((bq, bk, bv)):
+            grads.append(vec_grad(b, lambda dst, i=i: be.colsum(dqkv[:, i * N:(i + 1) * N], dst, N=N)) if b.requires_grad else None)
+        return (dx, *grads, None, None, None, None, None, None, None)
+
+
 class DropoutAddFn(Function):
     """y = dropout(x) (+ residual) -- nn.Dropout(hidden_dropout_prob) of HF BertEmbeddings / BertSelfOutput / BertOutput and the
     residual add that follows it.  The mask is regenerated from (seed, stream_id) in backward."""
