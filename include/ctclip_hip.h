@@ -29,10 +29,10 @@ int ctclip_head_transpose(const void* x, void* xt, int nseq, int H, int L, int L
 /* l2norm(q)*q_scale / l2norm(k)*k_scale per head (attention.py:152-154). */
 int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y, float* inv, int64_t M, int H, int D, int64_t ldx, int64_t ldy, int dtype, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_qk_norm_bwd needs for the per-workgroup partial sums of the learned-scale gradient (deterministic two-stage sum). */
 int64_t ctclip_qk_norm_bwd_workspace(int64_t M, int H, int D);
 
-/* backward of the above; dscale (D) ACCUMULATED. */
+/* backward of the above; dscale (D) ACCUMULATED (+=) through per-workgroup partials in `workspace` (>= ctclip_qk_norm_bwd_workspace bytes), summed in a fixed order. */
 int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* softmax(scale*q k^T + bias[h] + keymask[seq]) v (attention.py:156-178; HF BertSelfAttention). */
@@ -44,37 +44,37 @@ int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L);
 /* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). */
 int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* TODO: document */
+/* 1 when the second-generation cosine-attention kernels (csrc/attn2*.hip) serve the shape: bf16, d_head 32, L a multiple of 32 in [64, 1024]; with a position-bias table (has_bias) the grid gh x gw must equal L, gw % 8 == 0, (2gh-1)(2gw-1) <= 4096 classes.  attention.py:145-178. */
 int ctclip_attn2_supported(int H, int L, int D_, int bias_gh, int bias_gw, int has_bias);
 
-/* TODO: document */
+/* attention.py:152-160 for the second-generation kernels: q (M, H*32), k, v row-major bf16 -> head-planar [H][M][32] operands q~ = l2norm(q) * q_scale * (scale * log2 e), k^ = l2norm(k) * k_scale, v (copy) + the inverse row norms qinv, kinv (M, H) f32 that the backward needs. */
 int ctclip_attn2_prep(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* q_scale, const float* k_scale, float scale, void* qh, void* kh, void* vh, float* qinv, float* kinv, int64_t M, int H, hipStream_t stream);
 
-/* TODO: document */
+/* softmax(q~ k^T + bias) v on head-planar operands (attention.py:162-178).  tab: the (nclass, H) f32 continuous-position-bias table of attention.py:257-276 (nclass = (2 bias_gh - 1)(2 bias_gw - 1)) or null; out (M, ldo) row-major bf16; lse2 [H][M] f32 log2-domain log-sum-exp for the backward. */
 int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, void* out, int64_t ldo, float* lse2, int nseq, int H, int L, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace for ctclip_attn2_bwd: dO' / delta' planes passed from the query pass to the key pass, and (with a bias table) the per-workgroup dBias slabs and bins of the deterministic fold. */
 int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
 
-/* TODO: document */
+/* backward of ctclip_attn2_fwd: head-planar dq~, dk^, dv [H][M][32] bf16 (the l2norm / scale backward is ctclip_attn2_unprep) and, when dtab is non-null, the gradient of the position-bias table (nclass, H) f32, ACCUMULATED (+=) in a fixed summation order. */
 int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, void* dqh, void* dkh, void* dvh, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_attn2_unprep needs for the partial sums of the q_scale / k_scale gradients. */
 int64_t ctclip_attn2_unprep_workspace(void);
 
-/* TODO: document */
+/* backward of ctclip_attn2_prep: head-planar dq~, dk^, dv -> row-major dq (M, lddq), dk, dv bf16 through the l2norm backward; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=), summed in a fixed order. */
 int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* TODO: document */
+/* 1 when ctclip_attn_short_* serves the shape (bf16, d_head 32, 1 <= L <= 32 tokens per sequence, no bias, no mask): CTViT's temporal transformer (attention.py:145-178 on (b h w, t, d) sequences, ctvit.py:297-305). */
 int ctclip_attn_short_supported(int L, int D, int dtype);
 
-/* TODO: document */
+/* out[(s L + i), h*32 + :] = softmax_j(scale * <l2norm(q_i) q_scale, l2norm(k_j) k_scale>) v_j for nseq sequences of L tokens, H heads (attention.py:145-178): q (nseq*L, ldq >= H*32), kv (nseq*L, ldkv >= 2*H*32) = [k | v], out (nseq*L, ldo) row-major bf16; q_scale, k_scale (32) f32.  One wave per (sequence, head); nothing is saved for the backward. */
 int ctclip_attn_short_fwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, void* out, int64_t ldo, int nseq, int H, int L, float scale, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_attn_short_bwd needs (one 64-float row of learned-scale gradient partials per workgroup). */
 int64_t ctclip_attn_short_bwd_workspace(int nseq, int H);
 
-/* TODO: document */
+/* backward of ctclip_attn_short_fwd from q, kv and dout alone (the 32 x 32 softmax is recomputed): dq (nseq*L, lddq), dkv (nseq*L, lddkv) = [dk | dv] bf16 are overwritten; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=) when non-null, in a fixed summation order. */
 int ctclip_attn_short_bwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, const void* dout, int64_t lddo, void* dq, int64_t lddq, void* dkv, int64_t lddkv, float* dq_scale, float* dk_scale, int nseq, int H, int L, float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* thread-local message of the last failing call. */
@@ -89,22 +89,22 @@ const char* ctclip_target_arch(void);
 /* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
 int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_peg_bwd needs when dw is requested (per-workgroup partial weight gradients of the deterministic two-stage sum). */
 int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C);
 
-/* backward of the above; dw (C,27) / db (C) ACCUMULATED, may be NULL. */
+/* backward of the above; dw (C,27) / db (C) ACCUMULATED (+=), may be NULL; with dw, `workspace` holds >= ctclip_peg_bwd_workspace bytes of per-workgroup partials (two-stage sum in a fixed order, no atomics). */
 int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* TODO: document */
+/* ClassFine / CT-LiPro head (scripts/ct_lipro_train.py:33-36): out = relu(x) * dropout_mask / (1 - p) when dy is null, else the gradient dy * mask / (1 - p) * [x > 0]; f32, n % 4 == 0; the mask is Philox(seed, element, stream_id) as in ctclip_dropout. */
 int ctclip_relu_dropout(const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
 
-/* TODO: document */
+/* torch.nn.BCEWithLogitsLoss(pos_weight) with mean reduction (ct_lipro_train.py:84,104): logits, targets (B, C) f32, pos_weight (C) f32 or null -> loss (1) and, when non-null, dlogits (B, C) = d loss / d logits. */
 int ctclip_bce_logits(const float* logits, const float* targets, const float* pos_weight, float* loss, float* dlogits, int B, int C, hipStream_t s);
 
-/* TODO: document */
+/* VocabFine objective of one prompt group (scripts/ct_vocabfine_train.py:112-121): sims (n, 2) f32 = (true prompt, false prompt) similarities -> softmax over each pair, MSE against (1, 0): loss (1), dsims (n, 2) or null. */
 int ctclip_pair_softmax_mse(const float* sims, float* loss, float* dsims, int n, hipStream_t s);
 
-/* TODO: document */
+/* CTCLIP.forward without return_loss (ct_clip.py:771,796,805-807): sims[p] = <l2norm(text_p), l2norm(image_p)> * exp(temperature) with broadcasting (nt == ni, or one side has one row: two prompts against one volume).  dsims null: forward, sims (max(nt, ni)) f32.  dsims non-null: backward, dtext (nt, D), dimage (ni, D), dtemp (1) are overwritten. */
 int ctclip_latent_similarity(const float* text, const float* image, const float* temperature, const float* dsims, float* sims, float* dtext, float* dimage, float* dtemp, int nt, int ni, int D, hipStream_t s);
 
 /* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
@@ -119,10 +119,10 @@ int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
 /* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
 int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 
-/* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767). */
+/* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767); `workspace` >= ctclip_visual_latent_fwd_workspace bytes (split-K partials, fixed summation order). */
 int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* backward of the above (dX and dW). */
@@ -152,10 +152,10 @@ int ctclip_leaky_relu_fwd(const float* x, float* y, int64_t n, float slope, hipS
 /* backward of LeakyReLU. */
 int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, float slope, hipStream_t s);
 
-/* TODO: document */
+/* bytes of workspace ctclip_colsum needs (per-row-block partial sums of the deterministic two-stage reduction). */
 int64_t ctclip_colsum_workspace(int64_t M, int N);
 
-/* bias gradients: out[n] += sum_m x[m][n]. */
+/* bias gradients: out[n] += sum_m x[m][n]; `workspace` >= ctclip_colsum_workspace bytes (row-block partials, fixed summation order). */
 int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* rearrange '(b t)(h w) d <-> (b h w) t d' between the spatial and temporal phases (ctvit.py:297-305). */
@@ -179,10 +179,10 @@ int ctclip_cpb_expand(const float* tab, float* bias, int H, int gh, int gw, hipS
 /* backward of the gather (deterministic segmented sum). */
 int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
 
-/* TODO: document */
+/* nn.Dropout of HF BertEmbeddings / BertSelfOutput / BertOutput fused with the residual add that follows it (modeling_bert.py BertSelfOutput.forward): y = x * mask / (1 - p) (+ residual); the mask is Philox4x32-10(seed, element / 4, stream_id), so the backward re-applies the same call to dy. */
 int ctclip_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, int dtype, hipStream_t s);
 
-/* TODO: document */
+/* test helper: writes the 0 / 1 keep mask (nseq, H, L, L) u8 that ctclip_attn_fwd / bwd apply to the attention probabilities for (dropout_p, dropout_seed). */
 int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint64_t seed, hipStream_t s);
 
 /* HF BertEmbeddings: word + position + token_type(0) lookup. */
@@ -209,7 +209,7 @@ int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, 
 /* F.normalize(x, dim=-1) (attention.py:22-23; ct_clip.py:49-50; VQ l2norm). */
 int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int out_dtype, hipStream_t stream);
 
-/* TODO: document */
+/* F.normalize rows as the three-term bf16 expansion the vector-quantiser code search multiplies on the matrix cores (vector_quantize_pytorch 1.1.2 CosineSimCodebook.forward computes the distances in f32): y (rows, 3 cols) bf16 = [hi | hi | lo] (order 0, tokens) or [hi | lo | hi] (order 1, codes) with hi = bf16(x^), lo = bf16(x^ - hi); inv (rows) f32 inverse norms or null. */
 int ctclip_l2norm_split3(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int order, hipStream_t stream);
 
 /* bytes of workspace ctclip_grad_norm_clip needs. */
@@ -218,16 +218,16 @@ int64_t ctclip_grad_norm_workspace(void);
 /* accelerator.clip_grad_norm_(params, 0.5) (CTCLIPTrainer.py:259-260): out = [norm, clip coefficient]. */
 int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, float max_norm, float* out, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
-/* torch.optim.Adam(lr, betas=(0.9,0.99), eps=1e-8).step() over a flat buffer (optimizer.py:24; CTCLIPTrainer.py:262). */
+/* torch.optim.Adam / AdamW(lr, betas, eps, weight_decay).step() over a flat buffer (optimizer.py:24-32; CTCLIPTrainer.py:262).  weight_decay > 0 is the decoupled AdamW decay; decay_mask4 (one byte per 4 parameters, 1 = decayed) or null (all decayed) implements the reference's no-decay group for parameters with ndim < 2 (transformer_maskgit/optimizer.py:3-8).  clip: the 2-float result of ctclip_grad_norm_clip or null. */
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s);
 
-/* TODO: document */
+/* scripts/data.py:92-162 (CTReportDataset.nii_img_to_tensor) without the file decode: src = the (H, W, D) voxel array as nibabel returns it (src_dtype 0 int16, 1 f32, 2 f64, device memory) -> HU = slope * v + intercept, trilinear resample to target_xy / target_z mm (F.interpolate align_corners=False, new size int(n * spacing / target)), clip to [hu_lo, hu_hi], / hu_div, centre crop / pad with pad_value -> out (out_d, out_h, out_w) f32 = (240, 480, 480). */
 int ctclip_preprocess_volume(const void* src, int src_dtype, int H, int W, int D, double slope, double intercept, double xy_spacing, double z_spacing, double target_xy, double target_z, float* out, int out_h, int out_w, int out_d, double hu_lo, double hu_hi, double hu_div, float pad_value, hipStream_t stream);
 
-/* TODO: document */
+/* bytes of workspace ctclip_segment_sum needs (row histogram, scan and the row order of each segment). */
 int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);
 
-/* TODO: document */
+/* out[key[r]] (+)= rowscale[r] * x[r, :d] summed in ascending row order per segment (deterministic scatter-add: the EMA statistics of the vector quantiser and the embedding-table gradients of HF BertEmbeddings).  keys (M) int64 or null (then key(r) = r % key_mod); x (M, ldx) f32 / bf16; rowscale (M) f32 or null; out (nseg, d) f32; counts_f (nseg) f32 row counts or null; accumulate 0 overwrites. */
 int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* x, int64_t ldx, const float* rowscale, float* out, float* counts_f, int64_t M, int d, int nseg, int accumulate, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
