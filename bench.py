@@ -227,8 +227,10 @@ def measure_traffic(kernel_label, timeout=150.0):
             vals = {}
             for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(path)):
-                    if r.get("Counter_Name") == counter and r["Kernel_Name"].split("(")[0].find("gemm") >= 0 and "reduce" not in r["Kernel_Name"]:
-                        vals.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+                    # "void (anonymous namespace)::gemm_tn_kernel(...)": drop the namespace before cutting at the argument list
+                    kname = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+                    if r.get("Counter_Name") == counter and "gemm" in kname and "reduce" not in kname:
+                        vals.setdefault(kname, []).append(float(r["Counter_Value"]))
             if not vals:
                 return None, f"no {counter} rows for a gemm kernel in the rocprofv3 output"
             name = max(vals, key=lambda k: sum(vals[k]))          # the GEMM kernel proper (not its split-K reduce)
