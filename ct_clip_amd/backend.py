@@ -373,6 +373,27 @@ class HipBackend:
         return m
 
     # ------------------------------------------------------------------ elementwise / streaming
+    def geglu_weight_interleave(self, w, hp, dtype):
+        """FeedForward[1].weight (2 * inner, K) f32 -> the (2 * hp, K) operand of gemm_geglu (x / gate rows interleaved in fours)."""
+        two_inner, K = w.shape
+        out = torch.empty((2 * hp, K), dtype=dtype, device=w.device)
+        _lib.check(self.lib.ctclip_geglu_weight_interleave(_p(w), _p(out), two_inner // 2, hp, K, K, _stream()), "ctclip_geglu_weight_interleave")
+        return out
+
+    def gemm_geglu(self, x, w_il, hp):
+        """u (M, 2 hp) = [x | gate], g (M, hp) = x * gelu(gate) in one launch; None when the shape is not served (caller: gemm + geglu_fwd)."""
+        M, K = x.shape
+        if x.dtype != torch.bfloat16:
+            return None
+        u = torch.empty((M, 2 * hp), dtype=x.dtype, device=x.device)
+        g = torch.empty((M, hp), dtype=x.dtype, device=x.device)
+        rc = self.lib.ctclip_gemm_geglu(_p(x), _p(w_il), _p(u), _p(g), M, hp, K, _rowmajor(x, "x"), _rowmajor(w_il, "w"), 2 * hp, hp,
+                                        dcode(x.dtype), _stream())
+        if rc == -2:      # CTCLIP_EUNSUPPORTED
+            return None
+        _lib.check(rc, "ctclip_gemm_geglu")
+        return u, g
+
     def geglu_fwd(self, u):
         M, H2 = u.shape
         g = torch.empty((M, H2 // 2), dtype=u.dtype, device=u.device)

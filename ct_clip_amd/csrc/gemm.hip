@@ -452,3 +452,41 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
                      out_val, M, p.nparts);
   return ctclip_check_launch("argmax_reduce");
 }
+
+// ---------------------------------------------------------------------------------------------------- fused GEGLU in-projection
+int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                             int64_t ldu, int64_t ldg, hipStream_t stream);
+
+namespace {
+__global__ __launch_bounds__(256) void geglu_weight_interleave_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int inner, int hp, int K, int64_t ldo) {
+  const int64_t n4 = (int64_t)2 * hp * (K / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+    const int j = 4 * (n >> 3) + (n & 3), part = (n >> 2) & 1;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < inner) load4(w + (int64_t)(part * inner + j) * K + k, v);
+    store4(out + (int64_t)n * ldo + k, v);
+  }
+}
+}  // namespace
+
+// FeedForward[1].weight (2 * inner, K) f32 = [x rows | gate rows] (attention.py:48) -> the bf16 operand of ctclip_gemm_geglu:
+// (2 * hp, ldo >= K) with row 8 q + r = x row 4 q + r and row 8 q + 4 + r = gate row 4 q + r (r < 4); rows of features >= inner are zero.
+extern "C" int ctclip_geglu_weight_interleave(const float* w, void* out, int inner, int hp, int K, int64_t ldo, hipStream_t stream) {
+  if (!w || !out || inner < 1 || hp < inner || hp % 4 || K % 4 || ldo < K || ldo % 4) { ctclip_set_error("geglu_weight_interleave: hp % 4 == 0, K % 4 == 0"); return CTCLIP_EBADARG; }
+  int64_t nb = cdiv((int64_t)2 * hp * (K / 4), 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(geglu_weight_interleave_kernel, dim3((unsigned)nb), dim3(256), 0, stream, w, (bf16_t*)out, inner, hp, K, ldo);
+  return ctclip_check_launch("geglu_weight_interleave");
+}
+
+// FeedForward in-projection + GEGLU in one launch (attention.py:39-48): u (M, ldu >= 2 hp) = [x | gate] = A B^T (the layout
+// ctclip_geglu_bwd reads), g (M, ldg >= hp) = x * gelu_erf(gate); A (M, lda) bf16, B = ctclip_geglu_weight_interleave's output.
+// Returns CTCLIP_EUNSUPPORTED when the shape does not fill whole 256 x 256 tiles of the large-tile kernel: the caller then runs
+// ctclip_gemm + ctclip_geglu_fwd.
+extern "C" int ctclip_gemm_geglu(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                                 int64_t ldu, int64_t ldg, int dtype, hipStream_t stream) {
+  if (!A || !B || !U || !G || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu: bad args"); return CTCLIP_EBADARG; }
+  if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
+  const int rc = ctclip_gemm_nt_geglu_try(A, B, U, G, M, hp, K, lda, ldb, ldu, ldg, stream);
+  return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
+}

@@ -60,6 +60,10 @@ struct NtParams {
   int ntm, ntn;
   // arg-max epilogue (vector-quantiser code search): no C; per (row, tile column half) partial (max, lowest index of the max)
   float* part_val; int32_t* part_idx; int nparts;
+  // GEGLU epilogue (feed-forward in-projection, attention.py:39-48): B's rows are interleaved in groups of four (output column
+  // 8 q + r = x feature 4 q + r, 8 q + 4 + r = its gate), so a lane's eight consecutive columns are four (x, gate) pairs; the epilogue
+  // stores u = [x | gate] in the split layout the backward reads AND g = x * gelu(gate).  geglu_hp = padded hidden width (0 = off).
+  bf16_t* geglu_g; int64_t ldg; int geglu_hp;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -321,7 +325,30 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
-      if (fast) {
+      if (p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only
+        const int64_t j0 = col >> 1;              // first of the lane's four features
+        bf16_t* u = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = rbase + a * 16 + r;
+            float x[4], gt[4], g[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { x[b] = acc[a][b][r] * p.alpha; gt[b] = acc[a][4 + b][r] * p.alpha; g[b] = x[b] * gelu_erf_fast(gt[b]); }
+            const u32x2 ux = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}, ug = {pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])};
+            const u32x2 gg = {pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
+            if (NONTEMPORAL) {
+              __builtin_nontemporal_store(ux, reinterpret_cast<u32x2*>(u + row * p.ldc + j0));
+              __builtin_nontemporal_store(ug, reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0));
+              __builtin_nontemporal_store(gg, reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0));
+            } else {
+              *reinterpret_cast<u32x2*>(u + row * p.ldc + j0) = ux;
+              *reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0) = ug;
+              *reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0) = gg;
+            }
+          }
+      } else if (fast) {
         float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.bias) load8(p.bias + col, bv);
 #pragma unroll
@@ -458,4 +485,23 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
   // hidden activation: they no longer evict the operand panels the other CUs of the XCD are about to re-read)
   const bool nontemporal = ((NT_ABL & 64) != 0) || (M * N * (out_dtype == DT_F32 ? 4 : 2) > ((int64_t)NT_STREAM_MB << 20));
   return nt_launch(p, nontemporal, stream);
+}
+
+// Feed-forward in-projection with the GEGLU fused into the epilogue (attention.py:39-48).  B = the in-projection weight with its
+// rows interleaved in groups of four (ctclip_geglu_weight_interleave), N = 2 * hp.  Writes u (M, ldu >= 2 hp) = [x | gate] and
+// g (M, ldg >= hp) = x * gelu(gate), both bf16.  Returns 1 when the shape is not eligible (the caller runs GEMM + ctclip_geglu_fwd).
+int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                             int64_t ldu, int64_t ldg, hipStream_t stream) {
+  const int64_t N = 2 * (int64_t)hp;
+  if (K % TK || K / TK < 2 || M % TM || N % TN || hp % 4 || ldu % 4 || ldg % 4) return 1;
+  if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
+  if ((reinterpret_cast<uintptr_t>(U) % 8) || (reinterpret_cast<uintptr_t>(G) % 8)) return 1;
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
+  const int64_t ntm = M / TM, ntn = N / TN;
+  if (ntm * ntn < 160) return 1;
+  NtParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = U; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldu;
+  p.out_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
+  p.geglu_g = (bf16_t*)G; p.ldg = ldg; p.geglu_hp = hp;
+  return nt_launch(p, M * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
 }

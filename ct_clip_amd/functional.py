@@ -212,6 +212,56 @@ def linear_geglu_in(x, weight):
     return LinearFn.apply(x, weight, None, None, wsh, [(0, inner, 0), (inner, inner, Hp)], K, None)
 
 
+class FfInGegluFn(Function):
+    """FeedForward[1] + GEGLU in one GEMM launch (bf16, whole 256-row tiles): the in-projection weight's rows are interleaved in
+    groups of four so that the epilogue lane that owns an x column owns its gate; u = [x | gate] is still stored in the split
+    layout, so the backward is the unfused one (geglu_bwd, grad-input and weight-gradient GEMMs against the ordinary shadow)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wsh, w_il, Hp, inner, K):
+        u, g = B().gemm_geglu(x, w_il, Hp)
+        ctx.save_for_backward(x, wsh, u)
+        ctx.weight, ctx.dims = weight, (Hp, inner, K)
+        ctx.wkey = (weight, tuple(wsh.shape))
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, wsh, u = ctx.saved_tensors
+        Hp, inner, K = ctx.dims
+        be = B()
+        du = be.geglu_bwd(dg.contiguous(), u)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if du.shape[0] >= 4096:
+                w, shp = ctx.wkey
+                wt = shadow(w, ("T",) + shp, du.dtype, lambda: be.transpose2d(wsh))
+                dx = be.gemm(du, wt)
+            else:
+                dx = be.gemm(du, wsh, a_kc=True, b_kc=False)
+        dw = weight_grad(du, x, ctx.weight, [(0, inner, 0), (inner, inner, Hp)], K) if ctx.weight.requires_grad else None
+        return dx, dw, None, None, None, None, None
+
+
+def feed_forward_in(x, weight):
+    """LayerNormed tokens -> GEGLU hidden (M, Hp): fused launch when the large-tile kernel serves the shape, else GEMM + GEGLU kernel."""
+    two_inner, K = weight.shape
+    inner = two_inner // 2
+    Hp = geglu_hidden_pad(inner)
+    M = x.shape[0]
+    if x.dtype == torch.bfloat16 and M % 256 == 0 and (2 * Hp) % 256 == 0 and (M // 256) * (2 * Hp // 256) >= 160 and K % 64 == 0 and K >= 128:
+        def make():
+            w = weight.detach()
+            out = torch.empty((2 * Hp, K), dtype=x.dtype, device=w.device)
+            B().convert_pad(w[:inner], Hp, K, x.dtype, out=out[:Hp])
+            B().convert_pad(w[inner:], Hp, K, x.dtype, out=out[Hp:])
+            return out
+        wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make)
+        w_il = shadow(weight, ("geglu_il", Hp), x.dtype, lambda: B().geglu_weight_interleave(weight.detach(), Hp, x.dtype))
+        return FfInGegluFn.apply(x, weight, wsh, w_il, Hp, inner, K)
+    return GegluFn.apply(linear_geglu_in(x, weight))
+
+
 def linear_geglu_out(g, weight, residual):
     """FeedForward[4]: Linear(inner, d, no bias) (attention.py:51) consuming the padded hidden (M, Hp), + residual."""
     N, inner = weight.shape

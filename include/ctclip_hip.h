@@ -119,6 +119,12 @@ int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
 /* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
 int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* FeedForward[1].weight (2 * inner, K) f32 = [x rows | gate rows] (attention.py:48) -> the bf16 operand of ctclip_gemm_geglu: (2 * hp, ldo >= K) with row 8 q + r = x row 4 q + r and row 8 q + 4 + r = gate row 4 q + r (r < 4); rows of padded features (>= inner) are zero. */
+int ctclip_geglu_weight_interleave(const float* w, void* out, int inner, int hp, int K, int64_t ldo, hipStream_t stream);
+
+/* Feed-forward in-projection + GEGLU in one launch (attention.py:39-48): u (M, ldu >= 2 hp) = [x | gate] = A B^T in the layout ctclip_geglu_bwd reads, g (M, ldg >= hp) = x * gelu_erf(gate); A (M, lda) bf16, B = the output of ctclip_geglu_weight_interleave.  Returns -2 (unsupported) when M or 2 hp is not a multiple of 256 or the shape does not fill the chip: the caller then runs ctclip_gemm + ctclip_geglu_fwd. */
+int ctclip_gemm_geglu(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu, int64_t ldg, int dtype, hipStream_t stream);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

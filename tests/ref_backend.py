@@ -338,6 +338,24 @@ class RefBackend:
                 dbias += ds.sum(0)
 
     # ---- elementwise
+    def geglu_weight_interleave(self, w, hp, dtype):
+        two_inner, K = w.shape
+        inner = two_inner // 2
+        out = torch.zeros((2 * hp, K), dtype=torch.float32, device=w.device)
+        j = torch.arange(inner, device=w.device)
+        out[8 * (j // 4) + j % 4] = w[:inner].float()
+        out[8 * (j // 4) + 4 + j % 4] = w[inner:].float()
+        return out.to(dtype)
+
+    def gemm_geglu(self, x, w_il, hp):
+        if x.dtype != torch.bfloat16 or x.shape[0] % 256 or (2 * hp) % 256:
+            return None
+        y = _f(x) @ _f(w_il).t()                                  # interleaved columns
+        y = y.view(x.shape[0], hp // 4, 2, 4)
+        xs, gate = y[:, :, 0, :].reshape(x.shape[0], hp), y[:, :, 1, :].reshape(x.shape[0], hp)
+        g = xs * F.gelu(gate)
+        return torch.cat([xs, gate], dim=1).to(x.dtype), g.to(x.dtype)
+
     def geglu_fwd(self, u):
         a, g = _f(u).chunk(2, dim=-1)
         return (a * F.gelu(g)).to(u.dtype)

@@ -172,6 +172,30 @@ def test_l2norm_rows(hip, ref, dtype):
     close(y32, ref.l2norm_rows(rnd(16, 64, seed=7), torch.float32)[0], rtol=1e-5, atol=1e-6)
 
 
+# ---------------------------------------------------------------- GEGLU fused into the in-projection GEMM
+@pytest.mark.parametrize("M,inner,K", [(256 * 40, 1365, 512), (256 * 90, 341, 128), (256 * 14, 1365, 512)])
+def test_gemm_geglu_fused(hip, ref, M, inner, K):
+    """attention.py:39-48: u = [x | gate] and g = x * gelu(gate) from one launch against the interleaved weight; the last shape does not
+    fill the chip and must be declined (None)."""
+    bf = torch.bfloat16
+    Hp = (inner + 127) // 128 * 128
+    x, w = rnd(M, K, dtype=bf, seed=1), rnd(2 * inner, K, seed=2, scale=K ** -0.5)
+    w_il, w_ilr = hip.geglu_weight_interleave(w, Hp, bf), ref.geglu_weight_interleave(w, Hp, bf)
+    assert torch.equal(w_il, w_ilr)
+    got = hip.gemm_geglu(x, w_il, Hp)
+    if (M // 256) * (2 * Hp // 256) < 160:
+        assert got is None
+        return
+    u, g = got
+    ur, gr = ref.gemm_geglu(x, w_il, Hp)
+    close(u, ur, rtol=2e-2, atol=2e-2)
+    close(g, gr, rtol=3e-2, atol=2e-2)
+    # the split layout: u[:, :inner] = x W_x^T, u[:, Hp:Hp + inner] = x W_gate^T, padding columns zero
+    close(u[:, :inner], (x.float() @ w[:inner].to(bf).float().t()), rtol=2e-2, atol=2e-2)
+    close(u[:, Hp:Hp + inner], (x.float() @ w[inner:].to(bf).float().t()), rtol=2e-2, atol=2e-2)
+    assert float(u[:, inner:Hp].abs().max()) == 0.0 and float(g[:, inner:].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------- short-sequence cosine attention (csrc/attn_short.hip)
 @pytest.mark.parametrize("nseq,H,L,strided", [(5, 8, 24, False), (3, 2, 32, False), (7, 3, 1, False), (4, 8, 2, True), (300, 8, 24, True),
                                               (2, 1, 9, False), (1100, 8, 24, False)])
