@@ -795,7 +795,7 @@ class ClipLossFn(Function):
 
     @staticmethod
     def backward(ctx, dloss):
-        dtl, dil, dtemp = ctx.saved_tensors
+        dtl, dil, dtemp = (t.clone() for t in ctx.saved_tensors)      # (not in place: backward may run again with retain_graph)
         be = B()
         s = dloss.reshape(1).to(torch.float32).contiguous()
         be.scale_by_scalar(dtl, s)

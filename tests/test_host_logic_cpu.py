@@ -118,3 +118,28 @@ def test_second_generation_attention_composition(ref_backend):
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
     assert Fn.B().attn2_supported(torch.bfloat16, H, L, D, (gh, gw), True) and not Fn.B().attn2_supported(torch.float32, H, L, D, (gh, gw), True)
+
+
+def test_fused_geglu_in_projection_composition(ref_backend):
+    """functional.feed_forward_in: the fused path (interleaved weight rows, u = [x | gate] + g from one GEMM, FfInGegluFn) and the
+    unfused one (linear_geglu_in + GegluFn) are the same operator: hidden activations and the gradients of x and of the weight."""
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(0)
+    M, K, inner = 256 * 54, 128, 341                      # Hp = 384: 54 x 3 = 162 tiles -> the fused path is taken in bf16
+    w = (torch.randn(2 * inner, K) * K ** -0.5).requires_grad_(True)
+    x = torch.randn(M, K).to(torch.bfloat16).requires_grad_(True)
+    dg = torch.randn(M, 384).to(torch.bfloat16)
+    g1 = Fn.feed_forward_in(x, w)
+    assert type(g1.grad_fn).__name__.startswith("FfInGegluFn")
+    g1.backward(dg)
+    dx1, dw1 = x.grad.clone(), w.grad.clone()
+    x.grad = None; w.grad = None
+    g2 = Fn.GegluFn.apply(Fn.linear_geglu_in(x, w))
+    g2.backward(dg)
+    torch.testing.assert_close(g1.float(), g2.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dx1.float(), x.grad.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dw1, w.grad, rtol=1e-3, atol=1e-2)
+    assert float(g1[:, inner:].abs().max()) == 0.0
+    # f32 (parity mode) and small token counts stay on the unfused path
+    assert not type(Fn.feed_forward_in(x.float(), w).grad_fn).__name__.startswith("FfInGegluFn")
+    assert not type(Fn.feed_forward_in(x[:512], w).grad_fn).__name__.startswith("FfInGegluFn")
