@@ -40,6 +40,7 @@ SIGNATURES = {
     "ctclip_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _F, _U64, _I, _P]),
     "ctclip_attn_bwd_workspace": (_L, [_I, _I, _I]),
     "ctclip_attn_bwd": (_I, [_P] * 10 + [_I, _I] + [_P] * 6 + [_I] * 5 + [_L] * 8 + [_F, _F, _U64, _I, _P, _L, _P]),
+    "ctclip_accumulate_f32": (_I, [_P, _P, _L, _P]),
     "ctclip_geglu_weight_interleave": (_I, [_P, _P, _I, _I, _I, _L, _P]),
     "ctclip_gemm_geglu": (_I, [_P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_preprocess_volume": (_I, [_P, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, _P, _I, _I, _I, _D, _D, _D, _F, _P]),

@@ -376,6 +376,12 @@ class HipBackend:
         return m
 
     # ------------------------------------------------------------------ elementwise / streaming
+    def accumulate(self, dst, src):
+        """dst += src (f32, contiguous, same size)"""
+        assert dst.dtype == src.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+        _lib.check(self.lib.ctclip_accumulate_f32(_p(dst), _p(src), dst.numel(), _stream()), "ctclip_accumulate_f32")
+        return dst
+
     def geglu_weight_interleave(self, w, hp, dtype):
         """FeedForward[1].weight (2 * inner, K) f32 -> the (2 * hp, K) operand of gemm_geglu (x / gate rows interleaved in fours)."""
         two_inner, K = w.shape

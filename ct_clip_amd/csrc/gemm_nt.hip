@@ -322,6 +322,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       const int64_t col = n0 + wn * 128 + li * 8;
       const int64_t rbase = m0 + wm * 64 + lg * 4;
       const bool fast = vec_ok && !p.residual && !p.accumulate && (m0 + TM <= p.M) && (n0 + TN <= p.N);   // wave-uniform
+      // the two residual-stream GEMMs of every layer (to_out, feed-forward out-projection: bf16 in, bf16 residual, bf16 out): the residual
+      // rows of the lane are requested eight at a time (the fragment registers are dead here), then added and stored -- the
+      // general path below loads each row right before its use (one dependent round trip per row: +37 us on a 48-us launch)
+      const bool fast_res = vec_ok && p.residual && p.res_dtype == DT_BF16 && p.out_dtype == DT_BF16 && !p.accumulate && !p.bias &&
+                            (m0 + TM <= p.M) && (n0 + TN <= p.N);
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
@@ -348,6 +353,30 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
               *reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0) = gg;
             }
           }
+      } else if (fast_res) {
+        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + rbase * p.ldr + col;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {          // eight rows in flight per lane (sixteen spilled: the accumulators own half the file)
+          u32x4 rr[2][4];
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr[a2][r] = *reinterpret_cast<const u32x4*>(rp + (int64_t)((2 * ah + a2) * 16 + r) * p.ldr);
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int a = 2 * ah + a2;
+              const int64_t row = rbase + a * 16 + r;
+              u32x4 d;
+#pragma unroll
+              for (int b = 0; b < 4; ++b) {
+                const uint32_t w = rr[a2][r][b];
+                d[b] = pack2bf(fmaf(acc[a][2 * b][r], p.alpha, __uint_as_float(w << 16)), fmaf(acc[a][2 * b + 1][r], p.alpha, __uint_as_float(w & 0xffff0000u)));
+              }
+              store16<NONTEMPORAL>(reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col, d);
+            }
+        }
       } else if (fast) {
         float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.bias) load8(p.bias + col, bv);

@@ -224,6 +224,14 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void accumulate_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<f32x4*>(dst)[i];
+    const f32x4 b = reinterpret_cast<const f32x4*>(src)[i];
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    reinterpret_cast<f32x4*>(dst)[i] = a;
+  }
+}
 __global__ void scale_by_scalar_kernel(float* __restrict__ x, const float* __restrict__ s, int64_t n) {
   const float f = s[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= f;
@@ -276,6 +284,14 @@ extern "C" int ctclip_clip_loss(const float* text_latents, const float* image_la
   }
   hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(256), shm, s, text_latents, image_latents, temperature, out, logits, d_text, d_image, d_temperature, G, Dl);
   return ctclip_check_launch("clip_loss");
+}
+// dst[i] += src[i] (f32, n % 4 == 0, 16-byte aligned): row blocks of a stacked weight gradient into the flat gradient buffer
+extern "C" int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s) {
+  if (!dst || !src || n < 0 || n % 4 || (reinterpret_cast<uintptr_t>(dst) % 16) || (reinterpret_cast<uintptr_t>(src) % 16)) { ctclip_set_error("accumulate_f32: n % 4 == 0, 16-byte aligned"); return CTCLIP_EBADARG; }
+  if (n == 0) return CTCLIP_OK;
+  int64_t b = cdiv(n / 4, 256); if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(accumulate_f32_kernel, dim3((unsigned)b), dim3(256), 0, s, dst, src, n / 4);
+  return ctclip_check_launch("accumulate_f32");
 }
 extern "C" int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s) {
   int64_t b = cdiv(n, 256); if (b > 4096) b = 4096;

@@ -82,6 +82,16 @@ def weight_grad(dy, x, weight, segments, K):
     else:
         dst = sink
     dst2 = dst.view(weight.shape[0], -1)
+    if (len(segments) > 1 and dy.dtype == torch.bfloat16 and dy.shape[0] >= 4096 and K == dst2.shape[1] and K % 4 == 0
+            and all(n * K % 4 == 0 for _, n, _ in segments)):
+        # stacked outputs (GEGLU in-projection [x | pad | gate | pad]): ONE pass over dy and x into a scratch, then the row blocks are
+        # added to their places -- two launches per segment read x (113 MB) once per segment
+        c_lo, c_hi = min(c0 for _, _, c0 in segments), max(c0 + n for _, n, c0 in segments)
+        tmp = torch.empty((c_hi - c_lo, K), dtype=torch.float32, device=dy.device)
+        B().gemm(dy[:, c_lo:c_hi], x[:, :K], a_kc=False, b_kc=False, out=tmp, accumulate=False, split_k=0, M=c_hi - c_lo, N=K, K=dy.shape[0])
+        for (r0, n, c0) in segments:
+            B().accumulate(dst2[r0:r0 + n], tmp[c0 - c_lo:c0 - c_lo + n])
+        return None if sink is not None else dst
     for (r0, n, c0) in segments:
         B().gemm(dy[:, c0:c0 + n], x[:, :K], a_kc=False, b_kc=False, out=dst2[r0:r0 + n, :K], accumulate=True,
                  split_k=0, M=n, N=K, K=dy.shape[0])

@@ -137,6 +137,9 @@ int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void
 /* l2norm + logits*exp(temperature) + symmetric InfoNCE, forward and backward (ct_clip.py:771,796,845-901). */
 int ctclip_clip_loss(const float* text_latents, const float* image_latents, const float* temperature, float* out, float* logits, float* d_text, float* d_image, float* d_temperature, int G, int Dl, hipStream_t s);
 
+/* dst[i] += src[i] over n f32 values (n % 4 == 0, 16-byte aligned): the row blocks of a stacked weight gradient (one GEMM over [x | gate]) added into the flat gradient buffer. */
+int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s);
+
 /* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). */
 int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s);
 

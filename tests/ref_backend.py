@@ -338,6 +338,10 @@ class RefBackend:
                 dbias += ds.sum(0)
 
     # ---- elementwise
+    def accumulate(self, dst, src):
+        dst += src
+        return dst
+
     def geglu_weight_interleave(self, w, hp, dtype):
         two_inner, K = w.shape
         inner = two_inner // 2

@@ -43,6 +43,9 @@ for name, K, N in layers:
         "wgrad TN dW += dy^T x": (lambda: be.gemm(dy, x, a_kc=False, b_kc=False, out=dw, accumulate=True, split_k=0, M=N, N=K, K=M),
                                   2 * M * N * K, (M * N + M * K) * 2 + N * K * 4),
     }
+    if name in ("to_out", "ff_out"):      # the two forward GEMMs that add the residual stream in their epilogue (attention.py:324-331)
+        res = rnd(M, N)
+        cases["fwd  NT y = x W^T + residual"] = (lambda: be.gemm(x, w, residual=res), 2 * M * N * K, (M * K + N * K + 2 * M * N) * 2)
     for cname, (fn, fl, by) in cases.items():
         us = timeit(fn)
         t_mfma, t_hbm = fl / 2.5e15 * 1e6, by / 6.3e12 * 1e6
