@@ -321,12 +321,15 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
                           (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
       const int64_t col = n0 + wn * 128 + li * 8;
       const int64_t rbase = m0 + wm * 64 + lg * 4;
-      const bool fast = vec_ok && !p.residual && !p.accumulate && (m0 + TM <= p.M) && (n0 + TN <= p.N);   // wave-uniform
+      // (wave-uniform conditions.  A wave owns 128 of the tile's 256 columns: in the last, half-filled column tile of N = 1408 the
+      // waves of the filled half keep the fast path and the others have nothing to store)
+      const bool cols_in = n0 + wn * 128 + 128 <= p.N, cols_out = n0 + wn * 128 >= p.N;
+      const bool fast = vec_ok && !p.residual && !p.accumulate && (m0 + TM <= p.M) && cols_in;
       // the two residual-stream GEMMs of every layer (to_out, feed-forward out-projection: bf16 in, bf16 residual, bf16 out): the residual
       // rows of the lane are requested eight at a time (the fragment registers are dead here), then added and stored -- the
       // general path below loads each row right before its use (one dependent round trip per row: +37 us on a 48-us launch)
       const bool fast_res = vec_ok && p.residual && p.res_dtype == DT_BF16 && p.out_dtype == DT_BF16 && !p.accumulate && !p.bias &&
-                            (m0 + TM <= p.M) && (n0 + TN <= p.N);
+                            (m0 + TM <= p.M) && cols_in;
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
               store16<NONTEMPORAL>(reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col, d);
             }
           }
-      } else {
+      } else if (!cols_out) {
         const bool colfull = vec_ok && (col + 8 <= p.N);
 #pragma unroll
         for (int a = 0; a < 4; ++a)

@@ -78,10 +78,11 @@ __global__ __launch_bounds__(256) void vlat_reduce_kernel(const float* __restric
 }
 
 // Each thread owns 8 consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
-template <typename T>
+// The walk over n is unrolled by four with every load of the group issued first (the first version fetched W and the old dW of one
+// row per iteration, the latter behind a branch: one dependent round trip per row at 2 waves per CU -- 800 us for 1.5 GB).
+template <typename T, bool ACC, bool WANT_DW>
 __global__ __launch_bounds__(128) void vlat_bwd_kernel(const float* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ W,
-                                                       T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K,
-                                                       int accumulate) {
+                                                       T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) float dys[];  // [Bm][N]
   for (int i = threadIdx.x; i < Bm * N; i += 128) dys[i] = dY[i];
   __syncthreads();
@@ -94,28 +95,31 @@ __global__ __launch_bounds__(128) void vlat_bwd_kernel(const float* __restrict__
     for (int e = 0; e < 8; ++e) { xv[b][e] = 0.f; dx[b][e] = 0.f; }
     if (b < Bm) load8(X + (int64_t)b * K + k, xv[b]);
   }
-  for (int n = 0; n < N; ++n) {
-    float w[8], g[8];
-    load8(W + (int64_t)n * K + k, w);
+  constexpr int UNR = 4;
+  for (int n0 = 0; n0 < N; n0 += UNR) {
+    float w[UNR][8], old[UNR][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = 0.f;
-#pragma unroll
-    for (int b = 0; b < VL_MAXB; ++b) {
-      if (b < Bm) {
-        const float d = dys[b * N + n];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dx[b][e] += d * w[e]; g[e] += d * xv[b][e]; }
-      }
+    for (int u = 0; u < UNR; ++u) {
+      const int n = n0 + u < N ? n0 + u : N - 1;           // clamped, always issued
+      load8(W + (int64_t)n * K + k, w[u]);
+      if (ACC && WANT_DW) load8(dW + (int64_t)n * K + k, old[u]);
     }
-    if (dW) {
-      float* dst = dW + (int64_t)n * K + k;
-      if (accumulate) {
-        float old[8];
-        load8(dst, old);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += old[e];
+    for (int u = 0; u < UNR; ++u) {
+      const int n = n0 + u;
+      if (n >= N) break;
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (ACC && WANT_DW) ? old[u][e] : 0.f;
+#pragma unroll
+      for (int b = 0; b < VL_MAXB; ++b) {
+        if (b < Bm) {
+          const float d = dys[b * N + n];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { dx[b][e] += d * w[u][e]; g[e] += d * xv[b][e]; }
+        }
       }
-      store8(dst, g);
+      if (WANT_DW) store8(dW + (int64_t)n * K + k, g);
     }
   }
   if (dX) {
@@ -268,8 +272,12 @@ extern "C" int ctclip_visual_latent_bwd(const float* dY, const void* X, const vo
   if (!dY || !X || !W || Bm < 1 || Bm > VL_MAXB || K % 8 || (int64_t)Bm * N * 4 > 64 * 1024) { ctclip_set_error("visual_latent_bwd: bad args"); return CTCLIP_EBADARG; }
   dim3 grid((unsigned)cdiv(K / 8, 128));
   const size_t shm = (size_t)Bm * N * sizeof(float);
-  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_bwd_kernel<float>, grid, dim3(128), shm, s, dY, (const float*)X, (const float*)W, (float*)dX, dW, Bm, N, K, accumulate);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_bwd_kernel<bf16_t>, grid, dim3(128), shm, s, dY, (const bf16_t*)X, (const bf16_t*)W, (bf16_t*)dX, dW, Bm, N, K, accumulate);
+#define VLB(T, ACC, WDW) hipLaunchKernelGGL((vlat_bwd_kernel<T, ACC, WDW>), grid, dim3(128), shm, s, dY, (const T*)X, (const T*)W, (T*)dX, dW, Bm, N, K)
+#define VLB_T(T) do { if (!dW) VLB(T, false, false); else if (accumulate) VLB(T, true, true); else VLB(T, false, true); } while (0)
+  if (dtype == DT_F32) VLB_T(float);
+  else if (dtype == DT_BF16) VLB_T(bf16_t);
+#undef VLB_T
+#undef VLB
   else return CTCLIP_EUNSUPPORTED;
   return ctclip_check_launch("visual_latent_bwd");
 }
