@@ -673,7 +673,14 @@ __global__ __launch_bounds__(DB_NTH, 2) void dbias_slab_kernel(Params p, Geo g) 
   float* stats = reinterpret_cast<float*>(dyn + SREL_BYTES);                       // [2][4][lse2 | delta'][32]
   char* tiles = dyn + SREL_BYTES + 2 * DB_G * 64 * 4;                              // [2][16][TILE]
   const int nkb = p.L / 32, ngrp = (nkb + DB_G - 1) / DB_G;
-  const int qg = blockIdx.x / ngrp, kg = blockIdx.x % ngrp, h = blockIdx.y, split = blockIdx.z;
+  // XCD-aware work map.  The ngrp^2 tile groups of one (head, sequence subset) "family" read the same Q~ / dO' / K^ / V planes (each
+  // tile by ngrp of them), so a family belongs on ONE XCD, in adjacent dispatch slots: workgroup ids are dealt round-robin to the 8
+  // XCDs, hence xcd = id % 8 picks the family column and id / 8 walks (family row, group).  (With the plain 3-D grid the groups of a
+  // family landed on eight different L2s and every plane was fetched five times: 1.26 GB per launch, 258 us.)
+  const int ngg = ngrp * ngrp, nfam = p.H * p.nsplit;
+  const int slot = blockIdx.x >> 3, fam = (slot / ngg) * 8 + (blockIdx.x & 7), grp = slot % ngg;
+  if (fam >= nfam) return;                                                         // (whole workgroup: before any barrier)
+  const int qg = grp / ngrp, kg = grp % ngrp, h = fam % p.H, split = fam / p.H;
   stage_srel<true>(rel, p, g, h);                                                  // (NTH == DB_NTH)
   if (split >= p.nseq) return;
   if (rel.safe) dbias_item<true>(p, rel, g, tiles, stats, h, qg, kg, split);
@@ -738,6 +745,7 @@ int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream) {
     raised = true;
   }
   const int nkb = p.L / 32, ngrp = (nkb + DB_G - 1) / DB_G;
-  hipLaunchKernelGGL(dbias_slab_kernel, dim3((unsigned)(ngrp * ngrp), p.H, p.nsplit), dim3(DB_NTH), shm, stream, p, g);
+  const int nfam8 = (p.H * p.nsplit + 7) / 8;                                       // family rows of 8 (one family per XCD)
+  hipLaunchKernelGGL(dbias_slab_kernel, dim3((unsigned)(nfam8 * ngrp * ngrp * 8)), dim3(DB_NTH), shm, stream, p, g);
   return ctclip_check_launch("attn2_bwd_dbias (slab)");
 }
