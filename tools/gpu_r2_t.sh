@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU session T: GEGLU fused into the in-projection GEMM
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2x; mkdir -p $O
+O=gpurun_out/r2z; mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "geglu or gemm or latent or vlat or visual" > $O/t_geglu.log 2>&1; echo "geglu tests rc=$? $(tail -n 1 $O/t_geglu.log)" >> $O/summary.log
 timeout 1500 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; echo "all gpu tests rc=$? $(tail -n 1 $O/t_all.log)" >> $O/summary.log
@@ -12,7 +12,7 @@ cd $GRAFT_REPO_ROOT
 python - <<'PY' > $O/prof_stats.md 2>&1
 import csv, glob, re, collections
 rows = collections.defaultdict(list)
-for path in glob.glob("gpurun_out/r2x/prof/**/*kernel_trace.csv", recursive=True):
+for path in glob.glob("gpurun_out/r2z/prof/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         n = re.sub(r"^void ", "", n).split("(")[0]
