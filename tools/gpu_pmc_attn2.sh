@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tools/bench_ops.py attn2 (slab kernels incl. dBias)
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2pmc; mkdir -p $O
+O=gpurun_out/pmc_attn2; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc1 -- python $GRAFT_REPO_ROOT/tools/bench_ops.py attn2 3 > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc1.err
@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 rm -rf $O/pmc*/*/*.db
 python - <<'PY'
 import csv, glob, collections, re
-for d in ("gpurun_out/r2pmc/pmc1","gpurun_out/r2pmc/pmc2"):
+for d in ("gpurun_out/pmc_attn2/pmc1","gpurun_out/pmc_attn2/pmc2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
