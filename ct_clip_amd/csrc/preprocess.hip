@@ -48,19 +48,28 @@ __device__ __forceinline__ void source_index(double scale, int dst, int n, int& 
   l0 = 1.0 - l1;
 }
 
-// one thread per output voxel, ow fastest
+// Workgroup = one output row (d, h fixed; blockIdx.y, blockIdx.z), thread = w: the d / h source indices and weights are uniform per
+// workgroup (scalar registers), no 64-bit divisions; the two d-neighbours of a corner are adjacent in the source (d is its
+// contiguous axis) and come in one access when the voxels are int16.  (First version: one flat index per thread, three 64-bit
+// divisions and eight scalar gathers per voxel: 5.5 ms per volume.)
 __global__ __launch_bounds__(256) void preprocess_kernel(PreParams p) {
-  const int64_t n = (int64_t)p.od * p.oh * p.ow;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
-    const int w = (int)(idx % p.ow), h = (int)((idx / p.ow) % p.oh), d = (int)(idx / ((int64_t)p.ow * p.oh));
-    const int ch = h - p.ph, cw = w - p.pw, cd = d - p.pd;           // position in the cropped volume
+  const int d = blockIdx.z, h = blockIdx.y;
+  const int ch = h - p.ph, cd = d - p.pd;
+  const bool row_in = ch >= 0 && ch < p.ch && cd >= 0 && cd < p.cd;
+  int h_0 = 0, h_1 = 0, d_0 = 0, d_1 = 0;
+  double hl0 = 0.0, hl1 = 0.0, dl0 = 0.0, dl1 = 0.0;
+  if (row_in) {
+    // the reference interpolates the (D, H, W)-transposed array: output index order (d, h, w)
+    source_index(p.sd, cd + p.d0, p.D, d_0, d_1, dl0, dl1);
+    source_index(p.sh, ch + p.h0, p.H, h_0, h_1, hl0, hl1);
+  }
+  float* orow = p.out + ((int64_t)d * p.oh + h) * p.ow;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < p.ow; w += gridDim.x * 256) {
+    const int cw = w - p.pw;
     float r = p.pad;
-    if (ch >= 0 && ch < p.ch && cw >= 0 && cw < p.cw && cd >= 0 && cd < p.cd) {
-      int h_0, h_1, w_0, w_1, d_0, d_1;
-      double hl0, hl1, wl0, wl1, dl0, dl1;
-      // the reference interpolates the (D, H, W)-transposed array: output index order (d, h, w)
-      source_index(p.sd, cd + p.d0, p.D, d_0, d_1, dl0, dl1);
-      source_index(p.sh, ch + p.h0, p.H, h_0, h_1, hl0, hl1);
+    if (row_in && cw >= 0 && cw < p.cw) {
+      int w_0, w_1;
+      double wl0, wl1;
       source_index(p.sw, cw + p.w0, p.W, w_0, w_1, wl0, wl1);
       // UpSampleKernel.cpp cpu_upsample_linear / upsample_trilinear3d: t0 h0 w0, t0 h0 w1, t0 h1 w0, ... (d outermost, w innermost)
       const double v = dl0 * (hl0 * (wl0 * fetch(p, h_0, w_0, d_0) + wl1 * fetch(p, h_0, w_1, d_0)) +
@@ -70,7 +79,64 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreParams p) {
       const double c = v < p.lo ? p.lo : (v > p.hi ? p.hi : v);
       r = (float)(c * p.inv_scale);
     }
-    p.out[idx] = r;
+    orow[w] = r;
+  }
+}
+
+// int16 volumes (the stored form): a workgroup owns 16 output columns of one output row-plane (h fixed, all d) and first stages the
+// source slab it needs -- rows h_0, h_1, source columns wlo .. whi, ALL of d (d is the source's contiguous axis: 600-byte runs,
+// coalesced) -- in LDS; the eight taps of a voxel are then LDS reads, and 16 lanes write 64 contiguous bytes of an output row.
+// The row kernel above reads 2 bytes out of every 600-byte source run per output row: 2.2 ms per volume, this one ~5x less.
+__global__ __launch_bounds__(256) void preprocess_tile_kernel(PreParams p, int nws_max) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int16_t* slab = reinterpret_cast<int16_t*>(smem);                  // [2][nws_max][D]
+  const int h = blockIdx.y, wt0 = blockIdx.x * 16;
+  const int ch = h - p.ph;
+  const bool row_in = ch >= 0 && ch < p.ch;
+  const int cw_first = wt0 - p.pw > 0 ? wt0 - p.pw : 0;
+  const int cw_last = wt0 + 15 - p.pw < p.cw - 1 ? wt0 + 15 - p.pw : p.cw - 1;
+  const bool any = row_in && cw_first <= cw_last;
+  int h_0 = 0, h_1 = 0, wlo = 0, nws = 0;
+  double hl0 = 0.0, hl1 = 0.0;
+  if (any) {
+    int a0, a1, b0, b1; double t0, t1;
+    source_index(p.sh, ch + p.h0, p.H, h_0, h_1, hl0, hl1);
+    source_index(p.sw, cw_first + p.w0, p.W, a0, a1, t0, t1);
+    source_index(p.sw, cw_last + p.w0, p.W, b0, b1, t0, t1);
+    wlo = a0; nws = b1 - a0 + 1;
+    // stage: 2 * nws runs of D voxels, as 32-bit words (D even, checked by the launcher)
+    const int D2 = p.D >> 1, nwords = 2 * nws * D2;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(slab);
+    for (int i = threadIdx.x; i < nwords; i += 256) {
+      const int run = i / D2, col = i - run * D2;
+      const int hh = run / nws, ws = run - hh * nws;
+      dst[(hh * nws_max + ws) * D2 + col] = src[((int64_t)(hh ? h_1 : h_0) * p.W + wlo + ws) * D2 + col];
+    }
+  }
+  __syncthreads();
+  const int wl = threadIdx.x & 15, w = wt0 + wl, cw = w - p.pw;
+  const bool col_in = any && w < p.ow && cw >= 0 && cw < p.cw;
+  int w_0 = 0, w_1 = 0; double wl0 = 0.0, wl1 = 0.0;
+  if (col_in) source_index(p.sw, cw + p.w0, p.W, w_0, w_1, wl0, wl1);
+  const int16_t* r00 = slab + (0 * nws_max + (w_0 - wlo)) * p.D;     // (h_0, w_0), (h_0, w_1), (h_1, w_0), (h_1, w_1)
+  const int16_t* r01 = slab + (0 * nws_max + (w_1 - wlo)) * p.D;
+  const int16_t* r10 = slab + (1 * nws_max + (w_0 - wlo)) * p.D;
+  const int16_t* r11 = slab + (1 * nws_max + (w_1 - wlo)) * p.D;
+  if (w >= p.ow) return;
+  for (int d = threadIdx.x >> 4; d < p.od; d += 16) {
+    const int cd = d - p.pd;
+    float r = p.pad;
+    if (col_in && cd >= 0 && cd < p.cd) {
+      int d_0, d_1; double dl0, dl1;
+      source_index(p.sd, cd + p.d0, p.D, d_0, d_1, dl0, dl1);
+      auto hu = [&](const int16_t* row, int dd) { return p.slope * (double)row[dd] + p.intercept; };
+      const double v = dl0 * (hl0 * (wl0 * hu(r00, d_0) + wl1 * hu(r01, d_0)) + hl1 * (wl0 * hu(r10, d_0) + wl1 * hu(r11, d_0))) +
+                       dl1 * (hl0 * (wl0 * hu(r00, d_1) + wl1 * hu(r01, d_1)) + hl1 * (wl0 * hu(r10, d_1) + wl1 * hu(r11, d_1)));
+      const double c = v < p.lo ? p.lo : (v > p.hi ? p.hi : v);
+      r = (float)(c * p.inv_scale);
+    }
+    p.out[((int64_t)d * p.oh + h) * p.ow + w] = r;
   }
 }
 
@@ -101,8 +167,20 @@ extern "C" int ctclip_preprocess_volume(const void* src, int src_dtype, int H, i
     before = (t - len) / 2;
   };
   crop(p.rh, out_h, p.h0, p.ch, p.ph); crop(p.rw, out_w, p.w0, p.cw, p.pw); crop(p.rd, out_d, p.d0, p.cd, p.pd);
-  const int64_t n = (int64_t)out_d * out_h * out_w;
-  int64_t nb = cdiv(n, 256); if (nb > 65536) nb = 65536;
-  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  if (out_h > 65535 || out_d > 65535) { ctclip_set_error("preprocess_volume: output extents above 65535"); return CTCLIP_EBADARG; }
+  // tiled kernel: int16 voxels, even D, 4-byte aligned source, and a slab that fits in LDS
+  const int nws_max = (int)(15.0 * p.sw) + 4;
+  const size_t slab_bytes = (size_t)2 * nws_max * D * 2;
+  if (src_dtype == 0 && D % 2 == 0 && (reinterpret_cast<uintptr_t>(src) % 4) == 0 && slab_bytes <= 150 * 1024) {
+    static size_t raised = 0;
+    if (slab_bytes > 64 * 1024 && slab_bytes > raised) {
+      if (hipFuncSetAttribute((const void*)preprocess_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); goto rows; }
+      raised = 150 * 1024;
+    }
+    hipLaunchKernelGGL(preprocess_tile_kernel, dim3((unsigned)cdiv(out_w, 16), (unsigned)out_h), dim3(256), slab_bytes, stream, p, nws_max);
+    return ctclip_check_launch("preprocess_volume");
+  }
+rows:
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)cdiv(out_w, 256), (unsigned)out_h, (unsigned)out_d), dim3(256), 0, stream, p);
   return ctclip_check_launch("preprocess_volume");
 }
