@@ -32,3 +32,42 @@ def test_kernel_matches_oracle_small(shape, xy, z, target, dtype):
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=0, atol=2e-7)
     assert float((got == want).float().mean()) > 0.995
+
+
+def test_nii_img_to_tensor_drop_in(monkeypatch):
+    """ct_clip_amd.preprocess.nii_img_to_tensor(path, df) = the reference method's signature (data.py:92): file name -> metadata row ->
+    tensor, with nibabel's loader replaced by an in-memory image (integer voxels with an identity header scaling, and a float image)."""
+    import sys
+    import types
+    import pandas as pd
+    from oracle import preprocess_oracle as PO
+    from ct_clip_amd import preprocess as PP
+    vox = PO.synthetic_volume(21, (48, 40, 30))
+
+    class _Obj:
+        def __init__(self, arr, slope, inter):
+            self._a, self.slope, self.inter = arr, slope, inter
+
+        def get_unscaled(self):
+            return self._a
+
+    class _Img:
+        def __init__(self, arr, slope=1.0, inter=0.0):
+            self.dataobj = _Obj(arr, slope, inter)
+            self._f = arr.astype(np.float64) * slope + inter
+
+        def get_fdata(self):
+            return self._f
+    store = {"/d/a.nii.gz": _Img(vox), "/d/b.nii.gz": _Img(vox, 0.5, 3.0)}
+    fake = types.ModuleType("nibabel")
+    fake.load = lambda path: store[str(path)]
+    monkeypatch.setitem(sys.modules, "nibabel", fake)
+    df = pd.DataFrame([dict(VolumeName="a.nii.gz", RescaleSlope=1.0, RescaleIntercept=-1024.0, XYSpacing="[0.9, 0.9]", ZSpacing=2.0),
+                       dict(VolumeName="b.nii.gz", RescaleSlope=2.0, RescaleIntercept=-100.0, XYSpacing="[0.75, 0.75]", ZSpacing=1.5)])
+    assert PP.parse_xy_spacing("[0.9, 0.9]") == 0.9
+    for name, arr, slope, inter, xy, z in (("a", vox.astype(np.float64), 1.0, -1024.0, 0.9, 2.0),
+                                          ("b", vox.astype(np.float64) * 0.5 + 3.0, 2.0, -100.0, 0.75, 1.5)):
+        got = PP.nii_img_to_tensor(f"/d/{name}.nii.gz", df, device=DEV).cpu()
+        want = PO.volume_to_tensor(arr, slope, inter, xy, z)
+        assert got.shape == (1, 240, 480, 480)
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-7)
