@@ -54,12 +54,20 @@ class HipBackend:
         groups = []
         for key, pairs in ev.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
-            layout, dt, M, N, K, side = key
+            layout, dt, M, N, K, side = key[:6]
+            variant = key[6] if len(key) > 6 else ""       # fused GEGLU launches: forward (u and / or g written), backward recomputation
             flops = 2.0 * M * N * K
             esz = 2 if dt == "bf16" else 4
-            groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}", launches=len(ms), side_stream=side,
-                               avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops,
-                               bytes_per_launch=float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))))
+            nbytes = float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))
+            if variant == "+geglu":
+                nbytes += M * (N // 2) * esz                       # u and g
+            elif variant == "+geglu(g only)":
+                nbytes = float((M * K + N * K + M * (N // 2)) * esz)
+            elif variant == "geglu-bwd recompute":
+                nbytes += M * (N // 2) * esz                       # dg read, du written
+            groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}" + (f" [{variant}]" if variant else ""), launches=len(ms),
+                               side_stream=side, avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops,
+                               bytes_per_launch=nbytes))
         # launches on the text tower's side stream wait for the image tower's kernels between their two events: their event time is
         # not kernel time, so the dominant kernel is picked among the launches of the main stream
         groups.sort(key=lambda g: (g["side_stream"], -g["total_ms"]))
@@ -389,12 +397,13 @@ class HipBackend:
         _lib.check(self.lib.ctclip_geglu_weight_interleave(_p(w), _p(out), two_inner // 2, hp, K, K, _stream()), "ctclip_geglu_weight_interleave")
         return out
 
-    def gemm_geglu(self, x, w_il, hp):
-        """u (M, 2 hp) = [x | gate], g (M, hp) = x * gelu(gate) in one launch; None when the shape is not served (caller: gemm + geglu_fwd)."""
+    def gemm_geglu(self, x, w_il, hp, save_u=True):
+        """g (M, hp) = x * gelu(gate) and, with save_u, u (M, 2 hp) = [x | gate] in one launch -> (u or None, g); None when the shape
+        is not served (caller: gemm + geglu_fwd)."""
         M, K = x.shape
         if x.dtype != torch.bfloat16:
             return None
-        u = torch.empty((M, 2 * hp), dtype=x.dtype, device=x.device)
+        u = torch.empty((M, 2 * hp), dtype=x.dtype, device=x.device) if save_u else None
         g = torch.empty((M, hp), dtype=x.dtype, device=x.device)
         timing = self._gemm_events
         if timing is not None:
@@ -406,9 +415,33 @@ class HipBackend:
             return None
         if timing is not None:
             e1.record()
-            timing.setdefault(("NT", "bf16", M, 2 * hp, K, torch.cuda.current_stream() != torch.cuda.default_stream()), []).append((e0, e1))
+            timing.setdefault(("NT", "bf16", M, 2 * hp, K, torch.cuda.current_stream() != torch.cuda.default_stream(),
+                               "+geglu" if save_u else "+geglu(g only)"), []).append((e0, e1))
         _lib.check(rc, "ctclip_gemm_geglu")
         return u, g
+
+    def gemm_geglu_bwd(self, x, w_il, dg, hp):
+        """du (M, 2 hp) = [dg * gelu(gate) | dg * x * gelu'(gate)] with (x, gate) = x @ w_il^T recomputed inside the launch (nothing of the
+        forward is read); None when the shape is not served."""
+        M, K = x.shape
+        if x.dtype != torch.bfloat16 or dg.dtype != torch.bfloat16:
+            return None
+        assert dg.shape == (M, hp) and dg.stride(1) == 1
+        du = torch.empty((M, 2 * hp), dtype=x.dtype, device=x.device)
+        timing = self._gemm_events
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = self.lib.ctclip_gemm_geglu_bwd(_p(x), _p(w_il), _p(dg), _p(du), M, hp, K, _rowmajor(x, "x"), _rowmajor(w_il, "w"), dg.stride(0),
+                                            2 * hp, dcode(x.dtype), _stream())
+        if rc == -2:
+            return None
+        if timing is not None:
+            e1.record()
+            timing.setdefault(("NT", "bf16", M, 2 * hp, K, torch.cuda.current_stream() != torch.cuda.default_stream(),
+                               "geglu-bwd recompute"), []).append((e0, e1))
+        _lib.check(rc, "ctclip_gemm_geglu_bwd")
+        return du
 
     def geglu_fwd(self, u):
         M, H2 = u.shape

@@ -125,6 +125,18 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float erf_abs = fmaf(-poly * t, e, 1.f);
   return 0.5f * x * (1.f + copysignf(erf_abs, s));
 }
+// the same evaluation returning both gelu(x) and d gelu / dx = Phi(x) + x phi(x) (the exponential is shared: phi(x) = e / sqrt(2 pi))
+__device__ __forceinline__ void gelu_erf_fast_both(float x, float& y, float& dy) {
+  const float s = x * 0.70710678118654752440f, a = fabsf(s);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f); poly = fmaf(poly, t, -0.284496736f); poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-a * a * 1.4426950408889634f);
+  const float erf_abs = fmaf(-poly * t, e, 1.f);
+  const float cdf = 0.5f * (1.f + copysignf(erf_abs, s));
+  y = x * cdf;
+  dy = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);

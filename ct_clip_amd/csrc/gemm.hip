@@ -454,8 +454,8 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
 }
 
 // ---------------------------------------------------------------------------------------------------- fused GEGLU in-projection
-int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
-                             int64_t ldu, int64_t ldg, hipStream_t stream);
+int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
+                             int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream);
 
 namespace {
 __global__ __launch_bounds__(256) void geglu_weight_interleave_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int inner, int hp, int K, int64_t ldo) {
@@ -479,14 +479,27 @@ extern "C" int ctclip_geglu_weight_interleave(const float* w, void* out, int inn
   return ctclip_check_launch("geglu_weight_interleave");
 }
 
-// FeedForward in-projection + GEGLU in one launch (attention.py:39-48): u (M, ldu >= 2 hp) = [x | gate] = A B^T (the layout
-// ctclip_geglu_bwd reads), g (M, ldg >= hp) = x * gelu_erf(gate); A (M, lda) bf16, B = ctclip_geglu_weight_interleave's output.
+// FeedForward in-projection + GEGLU in one launch (attention.py:39-48): g (M, ldg >= hp) = x * gelu_erf(gate) and, when U is not
+// NULL, u (M, ldu >= 2 hp) = [x | gate] = A B^T (the layout ctclip_geglu_bwd reads); A (M, lda) bf16, B = ctclip_geglu_weight_interleave's
+// output.  Training passes U = NULL and differentiates with ctclip_gemm_geglu_bwd (nothing but the layer input is kept).
 // Returns CTCLIP_EUNSUPPORTED when the shape does not fill whole 256 x 256 tiles of the large-tile kernel: the caller then runs
 // ctclip_gemm + ctclip_geglu_fwd.
 extern "C" int ctclip_gemm_geglu(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
                                  int64_t ldu, int64_t ldg, int dtype, hipStream_t stream) {
-  if (!A || !B || !U || !G || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu: bad args"); return CTCLIP_EBADARG; }
+  if (!A || !B || !G || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu: bad args"); return CTCLIP_EBADARG; }
   if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
-  const int rc = ctclip_gemm_nt_geglu_try(A, B, U, G, M, hp, K, lda, ldb, ldu, ldg, stream);
+  const int rc = ctclip_gemm_nt_geglu_try(A, B, U, G, nullptr, M, hp, K, lda, ldb, U ? ldu : 2 * (int64_t)hp, ldg, 4, stream);
+  return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
+}
+
+// Backward of ctclip_gemm_geglu through the GEGLU by RECOMPUTATION: the same GEMM A B^T rebuilds (x, gate) in f32 and the epilogue
+// writes dU (M, lddu >= 2 hp) = [dG * gelu(gate) | dG * x * gelu'(gate)] (the gradient of u in the split layout the grad-input and
+// weight-gradient GEMMs read) from dG (M, lddg >= hp).  Replaces the stored u (2 hp values per token and layer) and the streaming
+// ctclip_geglu_bwd pass.  Same eligibility as ctclip_gemm_geglu.
+extern "C" int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* dG, void* dU, int64_t M, int hp, int64_t K, int64_t lda,
+                                     int64_t ldb, int64_t lddg, int64_t lddu, int dtype, hipStream_t stream) {
+  if (!A || !B || !dG || !dU || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu_bwd: bad args"); return CTCLIP_EBADARG; }
+  if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
+  const int rc = ctclip_gemm_nt_geglu_try(A, B, dU, nullptr, dG, M, hp, K, lda, ldb, lddu, 4, lddg, stream);
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }

@@ -42,6 +42,9 @@
 #ifndef NT_STREAM_MB
 #define NT_STREAM_MB 128     // outputs larger than this use non-temporal stores
 #endif
+#ifndef NT_COUNTED_EPI
+#define NT_COUNTED_EPI 1     // 1 = the first step of a tile waits for its panels only, not for the previous tile's epilogue stores
+#endif
 
 namespace {
 
@@ -64,6 +67,9 @@ struct NtParams {
   // 8 q + r = x feature 4 q + r, 8 q + 4 + r = its gate), so a lane's eight consecutive columns are four (x, gate) pairs; the epilogue
   // stores u = [x | gate] in the split layout the backward reads AND g = x * gelu(gate).  geglu_hp = padded hidden width (0 = off).
   bf16_t* geglu_g; int64_t ldg; int geglu_hp;
+  // GEGLU backward by recomputation (ctclip_gemm_geglu_bwd): the same GEMM recomputes (x, gate) in f32, the epilogue loads dg and
+  // stores du = [dg * gelu(gate) | dg * x * gelu'(gate)] to C -- the forward then has no u to store and the backward no u to read.
+  const bf16_t* geglu_dg; int64_t lddg;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -202,6 +208,10 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   NT_RA(0, 0) NT_RA(1, 0)
   NT_RB(0, 0) NT_RB(1, 0) NT_RB(2, 0) NT_RB(3, 0) NT_RB(4, 0) NT_RB(5, 0) NT_RB(6, 0) NT_RB(7, 0)
   int cs = 0;             // ring slot of A(g) for the consumer's current step g
+  int pn = 0;             // VMEM instructions this wave issued in the previous tile's epilogue (exact or an under-count; 0 = unknown)
+  auto wait_prev = [&](int n) {      // wave-uniform
+    if (n == 16) wait_vm<GL + 16>(); else if (n == 32) wait_vm<GL + 32>(); else if (n == 48) wait_vm<GL + 48>(); else wait_vm<GL>();
+  };
 
   for (int it = 0;; ++it) {
     f32x4 acc[4][8];
@@ -224,67 +234,77 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     //   H3: A2' A3' | MFMA(0,1) needs A0' A1' B'[b]       barrier      H4: A0'' A1'' | MFMA(2,3) ; then B[b]''
     // In H1 / H3 the reads younger than B[b] are B[b+1..7] and the two A fragments just issued: lgkmcnt(2 + 7 - b).
 #define NT_H13(b) wait_lds3<2 + 7 - (b)>(fa[0], fa[1], fb[b]); NT_MFMA2(0, b)
-    for (int t = 0; t < nk; ++t) {
-      const int slot_b2 = cs;                                 // B(g+2) replaces A(g) after barrier_g
-      const int slot_a2 = wrap(cs + 4);                       // A(g+2): issued during this step's first half-unit (freed by barrier_g-1)
-      const int slot_na = wrap(cs + 2), slot_nb = wrap(cs + 3);
-      cs = wrap(cs + 2);
-      const char* a_k = a_base + (int64_t)a_t * (TK * 2);     // cursor position of A(g+2)
-      // ---- H1: (t, ks=0), rows a = 0,1; LDS-DMA of A(g+2)
-      NT_RA(2, 0) NT_RA(3, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      NT_H13(0) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(1) glds(a_k, a_off[0], slot_a2, 0); __builtin_amdgcn_sched_barrier(0);
-      NT_H13(2) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(3) glds(a_k, a_off[1], slot_a2, 1); __builtin_amdgcn_sched_barrier(0);
-      NT_H13(4) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(5) glds(a_k, a_off[2], slot_a2, 2); __builtin_amdgcn_sched_barrier(0);
-      NT_H13(6) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(7) glds(a_k, a_off[3], slot_a2, 3); __builtin_amdgcn_sched_barrier(0);
-      if (++a_t == nk) enter_a(a_it + 1);
-      // ---- H2: (t, 0), rows a = 2,3; fetch (t, ks=1)
-      NT_RA(0, 1) NT_RA(1, 1)
-      wait_lds<2>(fa[2], fa[3]);
-      __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 0) NT_RB(0, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 1) NT_RB(1, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 2) NT_RB(2, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 3) NT_RB(3, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 4) NT_RB(4, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 5) NT_RB(5, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 6) NT_RB(6, 1) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 7) NT_RB(7, 1) __builtin_amdgcn_sched_barrier(0);
-      // ---- H3: (t, 1), rows a = 0,1
-      NT_RA(2, 1) NT_RA(3, 1)
-      __builtin_amdgcn_sched_barrier(0);
-      NT_H13(0) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(1) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(2) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(3) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(4) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(5) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(6) __builtin_amdgcn_sched_barrier(0);
-      NT_H13(7) __builtin_amdgcn_sched_barrier(0);
-      // ---- barrier_g: A(g+1), B(g+1) have landed (outstanding, oldest first: A(g+1), B(g+1), A(g+2) [epilogue stores of the
-      // previous tile are older than A(g+2) and are simply waited for]); every wave holds all of step g in registers.
-      wait_vm<GL>();
-      wait_lds<0>(fa[2], fa[3]);
-      __builtin_amdgcn_s_barrier();
-      const char* b_k = b_base + (int64_t)b_t * (TK * 2);     // cursor position of B(g+2)
-      // ---- H4: (t, 1), rows a = 2,3; fetch (t+1, ks=0) -- of the next tile after the last step; LDS-DMA of B(g+2)
-      point_a(slot_na); point_b(slot_nb);
-      NT_RA(0, 0) NT_RA(1, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 0) NT_RB(0, 0) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 1) NT_RB(1, 0) glds(b_k, b_off[0], slot_b2, 0); __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 2) NT_RB(2, 0) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 3) NT_RB(3, 0) glds(b_k, b_off[1], slot_b2, 1); __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 4) NT_RB(4, 0) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 5) NT_RB(5, 0) glds(b_k, b_off[2], slot_b2, 2); __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 6) NT_RB(6, 0) __builtin_amdgcn_sched_barrier(0);
-      NT_MFMA2(2, 7) NT_RB(7, 0) glds(b_k, b_off[3], slot_b2, 3); __builtin_amdgcn_sched_barrier(0);
-      if (++b_t == nk) enter_b(b_it + 1);
+    // One k-step (g = global step across tiles).  H1: (t, ks=0), rows a = 0,1 + the LDS-DMA of A(g+2); H2: (t, 0), rows a = 2,3, fetch
+    // (t, ks=1); H3: (t, 1), rows a = 0,1; barrier_g: A(g+1), B(g+1) have landed (outstanding, oldest first: A(g+1), B(g+1), [the
+    // previous tile's epilogue], A(g+2)) and every wave holds all of step g in registers; H4: (t, 1), rows a = 2,3, fetch (t+1, ks=0)
+    // -- of the next tile after the last step -- and the LDS-DMA of B(g+2) into the slot of A(g), free since barrier_g.
+    // WAITVM = the vmcnt wait in front of barrier_g.
+#define NT_STEP(WAITVM) { \
+      const int slot_b2 = cs; \
+      const int slot_a2 = wrap(cs + 4); \
+      const int slot_na = wrap(cs + 2), slot_nb = wrap(cs + 3); \
+      cs = wrap(cs + 2); \
+      const char* a_k = a_base + (int64_t)a_t * (TK * 2); \
+      NT_RA(2, 0) NT_RA(3, 0) \
+      __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(0) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(1) glds(a_k, a_off[0], slot_a2, 0); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(2) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(3) glds(a_k, a_off[1], slot_a2, 1); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(4) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(5) glds(a_k, a_off[2], slot_a2, 2); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(6) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(7) glds(a_k, a_off[3], slot_a2, 3); __builtin_amdgcn_sched_barrier(0); \
+      if (++a_t == nk) enter_a(a_it + 1); \
+      NT_RA(0, 1) NT_RA(1, 1) \
+      wait_lds<2>(fa[2], fa[3]); \
+      __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 0) NT_RB(0, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 1) NT_RB(1, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 2) NT_RB(2, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 3) NT_RB(3, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 4) NT_RB(4, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 5) NT_RB(5, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 6) NT_RB(6, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 7) NT_RB(7, 1) __builtin_amdgcn_sched_barrier(0); \
+      NT_RA(2, 1) NT_RA(3, 1) \
+      __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(0) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(1) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(2) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(3) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(4) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(5) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(6) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(7) __builtin_amdgcn_sched_barrier(0); \
+      WAITVM; \
+      wait_lds<0>(fa[2], fa[3]); \
+      __builtin_amdgcn_s_barrier(); \
+      const char* b_k = b_base + (int64_t)b_t * (TK * 2); \
+      point_a(slot_na); point_b(slot_nb); \
+      NT_RA(0, 0) NT_RA(1, 0) \
+      __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 0) NT_RB(0, 0) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 1) NT_RB(1, 0) glds(b_k, b_off[0], slot_b2, 0); __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 2) NT_RB(2, 0) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 3) NT_RB(3, 0) glds(b_k, b_off[1], slot_b2, 1); __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 4) NT_RB(4, 0) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 5) NT_RB(5, 0) glds(b_k, b_off[2], slot_b2, 2); __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 6) NT_RB(6, 0) __builtin_amdgcn_sched_barrier(0); \
+      NT_MFMA2(2, 7) NT_RB(7, 0) glds(b_k, b_off[3], slot_b2, 3); __builtin_amdgcn_sched_barrier(0); \
+      if (++b_t == nk) enter_b(b_it + 1); \
     }
+    // The FIRST step of a tile is a separate copy of the body: the previous tile's epilogue issued `pn` VMEM instructions AFTER the
+    // panels this step waits for and vmcnt retires in order, so "all but the GL + pn youngest" is the exact wait.  vmcnt(GL) made
+    // every tile start by waiting for the COMPLETION of the previous tile's stores; now they have until barrier_(g+1).
+    // pn = 0 (unknown / variable count: partial tiles, bias, arg-max) keeps the conservative wait; an under-count is always safe.
+    int t = 0;
+#if NT_COUNTED_EPI
+    NT_STEP(wait_prev(pn))
+    t = 1;
+#endif
+    for (; t < nk; ++t) NT_STEP(wait_vm<GL>())
+#undef NT_STEP
 #undef NT_H13
 #undef NT_MFMA2
 #undef NT_RA
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     // ---------------- epilogue, straight from registers: acc[a][b][r] = C[m0 + wm*64 + a*16 + lg*4 + r][n0 + wn*128 + li*8 + b]:
     // a lane owns 8 consecutive columns, 16 lanes one 256-B (bf16) row segment, one 16-byte store instruction writes 4 full rows
     // of the wave tile.  The stores are not waited for here: they retire under the next tile's first one and a half sub-steps.
+    pn = 0;
     if (p.part_val) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
       const int64_t col0 = n0 + wn * 128 + li * 8;
 #pragma unroll
@@ -333,7 +354,45 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
-      if (p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only
+      if (p.geglu_hp && p.geglu_dg) {      // kernel-uniform; backward by recomputation
+        const int64_t j0 = col >> 1;
+        bf16_t* du = reinterpret_cast<bf16_t*>(p.C);
+        const bf16_t* dgp = p.geglu_dg + rbase * p.lddg + j0;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {          // eight rows of dg in flight per lane
+          u32x2 dv[2][4];
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[a2][r] = *reinterpret_cast<const u32x2*>(dgp + (int64_t)((2 * ah + a2) * 16 + r) * p.lddg);
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int a = 2 * ah + a2;
+              const int64_t row = rbase + a * 16 + r;
+              float dx[4], dgt[4];
+#pragma unroll
+              for (int b = 0; b < 4; ++b) {
+                const uint32_t w = dv[a2][r][b >> 1];
+                const float d = __uint_as_float((b & 1) ? (w & 0xffff0000u) : (w << 16));
+                const float x = acc[a][b][r] * p.alpha, gt = acc[a][4 + b][r] * p.alpha;
+                float y, dy;
+                gelu_erf_fast_both(gt, y, dy);
+                dx[b] = d * y; dgt[b] = d * x * dy;
+              }
+              const u32x2 ox = {pack2bf(dx[0], dx[1]), pack2bf(dx[2], dx[3])}, og = {pack2bf(dgt[0], dgt[1]), pack2bf(dgt[2], dgt[3])};
+              if (NONTEMPORAL) {
+                __builtin_nontemporal_store(ox, reinterpret_cast<u32x2*>(du + row * p.ldc + j0));
+                __builtin_nontemporal_store(og, reinterpret_cast<u32x2*>(du + row * p.ldc + p.geglu_hp + j0));
+              } else {
+                *reinterpret_cast<u32x2*>(du + row * p.ldc + j0) = ox;
+                *reinterpret_cast<u32x2*>(du + row * p.ldc + p.geglu_hp + j0) = og;
+              }
+            }
+        }
+        pn = 48;          // 16 loads of dg + 32 stores
+      } else if (p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only.  u (p.C) is optional: training keeps only g
         const int64_t j0 = col >> 1;              // first of the lane's four features
         bf16_t* u = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
@@ -344,18 +403,21 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
             float x[4], gt[4], g[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) { x[b] = acc[a][b][r] * p.alpha; gt[b] = acc[a][4 + b][r] * p.alpha; g[b] = x[b] * gelu_erf_fast(gt[b]); }
-            const u32x2 ux = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}, ug = {pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])};
             const u32x2 gg = {pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
-            if (NONTEMPORAL) {
-              __builtin_nontemporal_store(ux, reinterpret_cast<u32x2*>(u + row * p.ldc + j0));
-              __builtin_nontemporal_store(ug, reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0));
-              __builtin_nontemporal_store(gg, reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0));
-            } else {
-              *reinterpret_cast<u32x2*>(u + row * p.ldc + j0) = ux;
-              *reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0) = ug;
-              *reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0) = gg;
+            if (u) {
+              const u32x2 ux = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}, ug = {pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])};
+              if (NONTEMPORAL) {
+                __builtin_nontemporal_store(ux, reinterpret_cast<u32x2*>(u + row * p.ldc + j0));
+                __builtin_nontemporal_store(ug, reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0));
+              } else {
+                *reinterpret_cast<u32x2*>(u + row * p.ldc + j0) = ux;
+                *reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0) = ug;
+              }
             }
+            if (NONTEMPORAL) __builtin_nontemporal_store(gg, reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0));
+            else *reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0) = gg;
           }
+        pn = u ? 48 : 16;          // 16 rows x (x, gate, g) or g only, 8-byte stores
       } else if (fast_res) {
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + rbase * p.ldr + col;
 #pragma unroll
@@ -380,7 +442,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
               store16<NONTEMPORAL>(reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col, d);
             }
         }
+        pn = 32;          // 16 residual loads + 16 stores
       } else if (fast) {
+        pn = p.bias ? 0 : (p.out_dtype == DT_F32 ? 32 : 16);
         float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.bias) load8(p.bias + col, bv);
 #pragma unroll
@@ -520,14 +584,15 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
 }
 
 // Feed-forward in-projection with the GEGLU fused into the epilogue (attention.py:39-48).  B = the in-projection weight with its
-// rows interleaved in groups of four (ctclip_geglu_weight_interleave), N = 2 * hp.  Writes u (M, ldu >= 2 hp) = [x | gate] and
-// g (M, ldg >= hp) = x * gelu(gate), both bf16.  Returns 1 when the shape is not eligible (the caller runs GEMM + ctclip_geglu_fwd).
-int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
-                             int64_t ldu, int64_t ldg, hipStream_t stream) {
+// rows interleaved in groups of four (ctclip_geglu_weight_interleave), N = 2 * hp.  Forward (dG == nullptr): writes g (M, ldg >= hp) =
+// x * gelu(gate) and, when U is given, u (M, ldu >= 2 hp) = [x | gate], all bf16.  Backward by recomputation (dG given): writes
+// U = du = [dG * gelu(gate) | dG * x * gelu'(gate)] from the recomputed (x, gate).  Returns 1 when the shape is not eligible.
+int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
+                             int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream) {
   const int64_t N = 2 * (int64_t)hp;
-  if (K % TK || K / TK < 2 || M % TM || N % TN || hp % 4 || ldu % 4 || ldg % 4) return 1;
+  if (K % TK || K / TK < 2 || M % TM || N % TN || hp % 4 || ldu % 4 || ldg % 4 || lddg % 4) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
-  if ((reinterpret_cast<uintptr_t>(U) % 8) || (reinterpret_cast<uintptr_t>(G) % 8)) return 1;
+  if ((reinterpret_cast<uintptr_t>(U) % 8) || (reinterpret_cast<uintptr_t>(G) % 8) || (reinterpret_cast<uintptr_t>(dG) % 8)) return 1;
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
   const int64_t ntm = M / TM, ntn = N / TN;
   if (ntm * ntn < 160) return 1;
@@ -535,5 +600,7 @@ int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, int
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = U; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldu;
   p.out_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
   p.geglu_g = (bf16_t*)G; p.ldg = ldg; p.geglu_hp = hp;
-  return nt_launch(p, M * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
+  p.geglu_dg = (const bf16_t*)dG; p.lddg = lddg;
+  const int64_t out_bytes = (U ? M * N * 2 : 0) + (G ? M * (int64_t)hp * 2 : 0);
+  return nt_launch(p, out_bytes > ((int64_t)NT_STREAM_MB << 20), stream);
 }

@@ -10,6 +10,8 @@ Weight handling
     gradient buffer, accumulated with split-K atomics) when present -- autograd then sees ``None`` for that
     input; otherwise a fresh f32 gradient tensor is returned as usual.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -224,23 +226,31 @@ def linear_geglu_in(x, weight):
 
 class FfInGegluFn(Function):
     """FeedForward[1] + GEGLU in one GEMM launch (bf16, whole 256-row tiles): the in-projection weight's rows are interleaved in
-    groups of four so that the epilogue lane that owns an x column owns its gate; u = [x | gate] is still stored in the split
-    layout, so the backward is the unfused one (geglu_bwd, grad-input and weight-gradient GEMMs against the ordinary shadow)."""
+    groups of four so that the epilogue lane that owns an x column owns its gate.  Training keeps NOTHING but the layer input:
+    the backward launch recomputes (x, gate) with the same GEMM and writes du = [dg gelu(gate) | dg x gelu'(gate)] from its epilogue
+    (ctclip_gemm_geglu_bwd) -- no u (2 Hp values per token) is stored or re-read and the streaming geglu_bwd pass is gone.
+    CTCLIP_GEGLU_RECOMPUTE=0 restores the stored-u backward (geglu_bwd on u = [x | gate] written by the forward launch)."""
 
     @staticmethod
     def forward(ctx, x, weight, wsh, w_il, Hp, inner, K):
-        u, g = B().gemm_geglu(x, w_il, Hp)
-        ctx.save_for_backward(x, wsh, u)
+        recompute = os.environ.get("CTCLIP_GEGLU_RECOMPUTE", "1") != "0"
+        u, g = B().gemm_geglu(x, w_il, Hp, save_u=not recompute)
+        if recompute:
+            ctx.save_for_backward(x, wsh, w_il)
+        else:
+            ctx.save_for_backward(x, wsh, u)
+        ctx.recompute = recompute
         ctx.weight, ctx.dims = weight, (Hp, inner, K)
         ctx.wkey = (weight, tuple(wsh.shape))
         return g
 
     @staticmethod
     def backward(ctx, dg):
-        x, wsh, u = ctx.saved_tensors
+        x, wsh, third = ctx.saved_tensors
         Hp, inner, K = ctx.dims
         be = B()
-        du = be.geglu_bwd(dg.contiguous(), u)
+        dg = dg.contiguous()
+        du = be.gemm_geglu_bwd(x, third, dg, Hp) if ctx.recompute else be.geglu_bwd(dg, third)
         dx = None
         if ctx.needs_input_grad[0]:
             if du.shape[0] >= 4096:

@@ -125,6 +125,9 @@ int ctclip_geglu_weight_interleave(const float* w, void* out, int inner, int hp,
 /* Feed-forward in-projection + GEGLU in one launch (attention.py:39-48): u (M, ldu >= 2 hp) = [x | gate] = A B^T in the layout ctclip_geglu_bwd reads, g (M, ldg >= hp) = x * gelu_erf(gate); A (M, lda) bf16, B = the output of ctclip_geglu_weight_interleave.  Returns -2 (unsupported) when M or 2 hp is not a multiple of 256 or the shape does not fill the chip: the caller then runs ctclip_gemm + ctclip_geglu_fwd. */
 int ctclip_gemm_geglu(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu, int64_t ldg, int dtype, hipStream_t stream);
 
+/* Backward of ctclip_gemm_geglu through the GEGLU by RECOMPUTATION (replaces torch autograd through `x * F.gelu(gate)` of attention.py:39-42 and the activation it would keep): the same GEMM A B^T rebuilds (x, gate) in f32 and the epilogue writes dU (M, lddu >= 2 hp) = [dG * gelu(gate) | dG * x * gelu'(gate)] from dG (M, lddg >= hp), bf16.  The forward then stores no u (pass U = NULL to ctclip_gemm_geglu) and the streaming ctclip_geglu_bwd pass is not needed.  Same eligibility as ctclip_gemm_geglu (CTCLIP_EUNSUPPORTED otherwise). */
+int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* dG, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t lddg, int64_t lddu, int dtype, hipStream_t stream);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

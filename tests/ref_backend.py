@@ -351,14 +351,28 @@ class RefBackend:
         out[8 * (j // 4) + 4 + j % 4] = w[inner:].float()
         return out.to(dtype)
 
-    def gemm_geglu(self, x, w_il, hp):
-        if x.dtype != torch.bfloat16 or x.shape[0] % 256 or (2 * hp) % 256:
-            return None
+    def _geglu_parts(self, x, w_il, hp):
         y = _f(x) @ _f(w_il).t()                                  # interleaved columns
         y = y.view(x.shape[0], hp // 4, 2, 4)
-        xs, gate = y[:, :, 0, :].reshape(x.shape[0], hp), y[:, :, 1, :].reshape(x.shape[0], hp)
+        return y[:, :, 0, :].reshape(x.shape[0], hp), y[:, :, 1, :].reshape(x.shape[0], hp)
+
+    def gemm_geglu(self, x, w_il, hp, save_u=True):
+        if x.dtype != torch.bfloat16 or x.shape[0] % 256 or (2 * hp) % 256:
+            return None
+        xs, gate = self._geglu_parts(x, w_il, hp)
         g = xs * F.gelu(gate)
-        return torch.cat([xs, gate], dim=1).to(x.dtype), g.to(x.dtype)
+        return (torch.cat([xs, gate], dim=1).to(x.dtype) if save_u else None), g.to(x.dtype)
+
+    def gemm_geglu_bwd(self, x, w_il, dg, hp):
+        """du = [dg gelu(gate) | dg x gelu'(gate)] with (x, gate) recomputed in f32 from the layer input (no rounding of u to bf16)."""
+        if x.dtype != torch.bfloat16 or x.shape[0] % 256 or (2 * hp) % 256:
+            return None
+        xs, gate = self._geglu_parts(x, w_il, hp)
+        uu = torch.cat([xs, gate], dim=1).detach().requires_grad_(True)
+        with torch.enable_grad():
+            a, gt = uu.chunk(2, dim=-1)
+            (gu,) = torch.autograd.grad(a * F.gelu(gt), uu, _f(dg))
+        return gu.to(x.dtype)
 
     def geglu_fwd(self, u):
         a, g = _f(u).chunk(2, dim=-1)

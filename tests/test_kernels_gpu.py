@@ -194,6 +194,17 @@ def test_gemm_geglu_fused(hip, ref, M, inner, K):
     close(u[:, :inner], (x.float() @ w[:inner].to(bf).float().t()), rtol=2e-2, atol=2e-2)
     close(u[:, Hp:Hp + inner], (x.float() @ w[inner:].to(bf).float().t()), rtol=2e-2, atol=2e-2)
     assert float(u[:, inner:Hp].abs().max()) == 0.0 and float(g[:, inner:].abs().max()) == 0.0
+    # training variant: g only (bit-identical to the launch that also stores u) ...
+    u0, g0 = hip.gemm_geglu(x, w_il, Hp, save_u=False)
+    assert u0 is None and torch.equal(g0, g)
+    # ... and the backward by recomputation against (a) the checker on the unrounded (x, gate), (b) the streaming geglu_bwd on the stored u
+    dg = rnd(M, Hp, dtype=bf, seed=3, scale=0.5)
+    dg[:, inner:] = 0
+    du = hip.gemm_geglu_bwd(x, w_il, dg, Hp)
+    close(du, ref.gemm_geglu_bwd(x, w_il, dg, Hp), rtol=3e-2, atol=2e-2)
+    close(du, hip.geglu_bwd(dg, u), rtol=5e-2, atol=3e-2)
+    assert float(du[:, inner:Hp].abs().max()) == 0.0 and float(du[:, Hp + inner:].abs().max()) == 0.0
+    assert torch.equal(du, hip.gemm_geglu_bwd(x, w_il, dg, Hp))
 
 
 # ---------------------------------------------------------------- short-sequence cosine attention (csrc/attn_short.hip)
