@@ -38,8 +38,10 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH += 1
 
 
-def shadow(param, tag, dtype, maker):
-    """Cached derived tensor of a parameter (recomputed when the parameter is modified)."""
+def shadow(param, tag, dtype, maker, recipe=None):
+    """Cached derived tensor of a parameter (recomputed when the parameter is modified).
+    recipe: how the batched refresh (refresh_shadows) rebuilds this tensor from f32 master weights -- a list of jobs
+    (source parameter, first destination row, destination rows, destination columns, map, aux, transposed), see csrc/shadow.hip."""
     cache = param.__dict__.setdefault("_ctclip_shadow", {})
     key = (tag, dtype)
     ent = cache.get(key)
@@ -49,7 +51,60 @@ def shadow(param, tag, dtype, maker):
     with torch.no_grad():
         val = maker()
     cache[key] = (stamp, val)
+    if recipe is not None and dtype == torch.bfloat16 and val.dim() == 2 and val.stride(1) == 1 and _SHADOW_BATCH:
+        _register_shadow(param, key, recipe)
     return val
+
+
+# ---- batched refresh: one launch after the optimiser step instead of one small launch per shadow in front of its first GEMM
+_SHADOW_BATCH = os.environ.get("CTCLIP_SHADOW_BATCH", "1") != "0"
+_SHADOW_PLAN = {}            # (id(owner parameter), key) -> (weakref(owner), key, [(weakref(source), row0, rows, cols, map, aux, transposed)])
+_SHADOW_JOBS = None          # cached job list for the backend (None = rebuild)
+_SHADOW_VERSION = 0
+MAP_PLAIN, MAP_GEGLU_SPLIT, MAP_GEGLU_INTERLEAVE = 0, 1, 2
+
+
+def _register_shadow(param, key, recipe):
+    global _SHADOW_JOBS
+    import weakref
+    _SHADOW_PLAN[(id(param), key)] = (weakref.ref(param), key, [(weakref.ref(src),) + tuple(rest) for src, *rest in recipe])
+    _SHADOW_JOBS = None
+
+
+def refresh_shadows():
+    """Rebuild every registered bf16 weight shadow in place from the current f32 parameters (ONE launch) and stamp it valid.
+    Called by the fused optimiser right after the parameter update; shadows without a recipe stay lazy."""
+    global _SHADOW_JOBS, _SHADOW_VERSION
+    if not _SHADOW_BATCH or not _SHADOW_PLAN:
+        return
+    if _SHADOW_JOBS is None:
+        jobs, owners = [], []
+        for pk, (pref, key, recipe) in list(_SHADOW_PLAN.items()):
+            param = pref()
+            ent = param.__dict__.get("_ctclip_shadow", {}).get(key) if param is not None else None
+            srcs = [r[0]() for r in recipe]
+            if ent is None or any(s_ is None for s_ in srcs):
+                del _SHADOW_PLAN[pk]           # the module is gone
+                continue
+            val = ent[1]
+            for src, (_, row0, rows, cols, mp, aux, tr) in zip(srcs, recipe):
+                jobs.append(dict(src=src.detach(), dst=val[row0:row0 + rows, :cols], map=mp, aux=aux, transposed=bool(tr)))
+            owners.append((pref, key))
+        _SHADOW_JOBS = (jobs, owners)
+        _SHADOW_VERSION += 1
+    jobs, owners = _SHADOW_JOBS
+    if not jobs:
+        return
+    with torch.no_grad():
+        B().shadow_refresh(jobs, _SHADOW_VERSION)
+    for pref, key in owners:
+        param = pref()
+        if param is None:
+            continue
+        cache = param.__dict__.get("_ctclip_shadow", {})
+        ent = cache.get(key)
+        if ent is not None:
+            cache[key] = ((param._version, param.data_ptr(), _WEIGHT_EPOCH), ent[1])
 
 
 def plain_shadow(weight, dtype, kpad=None, npad=None):
@@ -62,7 +117,15 @@ def plain_shadow(weight, dtype, kpad=None, npad=None):
         if dtype == torch.float32 and Np == N and Kp == K and w.is_contiguous():
             return w
         return B().convert_pad(w, Np, Kp, dtype)
-    return shadow(weight, ("plain", Np, Kp), dtype, make)
+    return shadow(weight, ("plain", Np, Kp), dtype, make, recipe=[(weight, 0, Np, Kp, MAP_PLAIN, 0, False)] if weight.dim() == 2 else None)
+
+
+def transposed_shadow(weight, wsh, segments):
+    """(Kp, Np) transposed form of the (Np, Kp) shadow `wsh` of `weight` (both operands of the grad-input GEMM k-contiguous).
+    segments: the LinearFn row segments of wsh -- two segments = the padded [x | gate] layout of the GEGLU in-projection."""
+    split = len(segments) == 2
+    recipe = [(weight, 0, wsh.shape[1], wsh.shape[0], MAP_GEGLU_SPLIT if split else MAP_PLAIN, segments[0][1] if split else 0, True)]
+    return shadow(weight, ("T",) + tuple(wsh.shape), wsh.dtype, lambda: B().transpose2d(wsh), recipe=recipe if weight.dim() == 2 else None)
 
 
 def sink_of(param):
@@ -157,7 +220,6 @@ class LinearFn(Function):
         y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
                      out_dtype=out_dtype or x.dtype)
         ctx.save_for_backward(x, wsh)
-        ctx.wkey = (weight, tuple(wsh.shape))
         ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
         ctx.has_res = residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
@@ -181,8 +243,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             if dyc.dtype == torch.bfloat16 and dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0:
                 # big grad-input GEMM: use the transposed weight shadow so that both operands are k-contiguous (global_load_lds path)
-                w, shp = ctx.wkey
-                wt = shadow(w, ("T",) + shp, dyc.dtype, lambda: B().transpose2d(wsh))
+                wt = transposed_shadow(ctx.weight, wsh, ctx.segments)
                 dx = B().gemm(dyc, wt)
             else:
                 dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
@@ -220,7 +281,7 @@ def linear_geglu_in(x, weight):
         B().convert_pad(w[:inner], Hp, K, x.dtype, out=out[:Hp])
         B().convert_pad(w[inner:], Hp, K, x.dtype, out=out[Hp:])
         return out
-    wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make)
+    wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make, recipe=[(weight, 0, 2 * Hp, K, MAP_GEGLU_SPLIT, inner, False)])
     return LinearFn.apply(x, weight, None, None, wsh, [(0, inner, 0), (inner, inner, Hp)], K, None)
 
 
@@ -241,7 +302,6 @@ class FfInGegluFn(Function):
             ctx.save_for_backward(x, wsh, u)
         ctx.recompute = recompute
         ctx.weight, ctx.dims = weight, (Hp, inner, K)
-        ctx.wkey = (weight, tuple(wsh.shape))
         return g
 
     @staticmethod
@@ -254,8 +314,7 @@ class FfInGegluFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if du.shape[0] >= 4096:
-                w, shp = ctx.wkey
-                wt = shadow(w, ("T",) + shp, du.dtype, lambda: be.transpose2d(wsh))
+                wt = transposed_shadow(ctx.weight, wsh, [(0, inner, 0), (inner, inner, Hp)])
                 dx = be.gemm(du, wt)
             else:
                 dx = be.gemm(du, wsh, a_kc=True, b_kc=False)
@@ -276,8 +335,9 @@ def feed_forward_in(x, weight):
             B().convert_pad(w[:inner], Hp, K, x.dtype, out=out[:Hp])
             B().convert_pad(w[inner:], Hp, K, x.dtype, out=out[Hp:])
             return out
-        wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make)
-        w_il = shadow(weight, ("geglu_il", Hp), x.dtype, lambda: B().geglu_weight_interleave(weight.detach(), Hp, x.dtype))
+        wsh = shadow(weight, ("geglu_in", Hp), x.dtype, make, recipe=[(weight, 0, 2 * Hp, K, MAP_GEGLU_SPLIT, inner, False)])
+        w_il = shadow(weight, ("geglu_il", Hp), x.dtype, lambda: B().geglu_weight_interleave(weight.detach(), Hp, x.dtype),
+                      recipe=[(weight, 0, 2 * Hp, K, MAP_GEGLU_INTERLEAVE, inner, False)])
         return FfInGegluFn.apply(x, weight, wsh, w_il, Hp, inner, K)
     return GegluFn.apply(linear_geglu_in(x, weight))
 
@@ -614,7 +674,7 @@ class QkvSdpaFn(Function):
                 be.convert_pad(w.detach(), N, K, x.dtype, out=out[i * N:(i + 1) * N])
             return out
         # (the stamp of the cache entry is wq's; the fused optimiser bumps the weight epoch, load_state_dict touches all three)
-        wsh = shadow(wq, ("qkv", id(wk), id(wv)), x.dtype, make_w)
+        wsh = shadow(wq, ("qkv", id(wk), id(wv)), x.dtype, make_w, recipe=[(w, i * N, N, K, MAP_PLAIN, 0, False) for i, w in enumerate((wq, wk, wv))])
         bias = shadow(bq, ("qkv_bias", id(bk), id(bv)), torch.float32, lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]).float())
         qkv = be.gemm(x, wsh, bias=bias)
         q, k, v = qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]

@@ -113,6 +113,7 @@ class FusedAdam:
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                      self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4)
         Fn.bump_weight_epoch()
+        Fn.refresh_shadows()          # every bf16 GEMM operand rebuilt from the new f32 weights in one launch
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names,

@@ -242,6 +242,9 @@ int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);
 /* out[key[r]] (+)= rowscale[r] * x[r, :d] summed in ascending row order per segment (deterministic scatter-add: the EMA statistics of the vector quantiser and the embedding-table gradients of HF BertEmbeddings).  keys (M) int64 or null (then key(r) = r % key_mod); x (M, ldx) f32 / bf16; rowscale (M) f32 or null; out (nseg, d) f32; counts_f (nseg) f32 row counts or null; accumulate 0 overwrites. */
 int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* x, int64_t ldx, const float* rowscale, float* out, float* counts_f, int64_t M, int d, int nseg, int accumulate, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* Batched refresh of the bf16 weight shadows after the optimiser step (replaces the per-parameter `.to(bf16)` / `.t().contiguous()` / re-layout copies a torch module makes when its weights change; scripts/CTCLIPTrainer.py:259-263 is followed by nothing of the kind because torch computes from the f32 weights): jobs = DEVICE array of njobs records of 12 int64 {src, dst, src_ld, dst_ld, src_rows, src_cols, dst_rows, dst_cols, map, aux, transposed, tile0} sorted by tile0 (tile0 of job i = sum over the jobs before it of ceil(dst_rows / 64) * ceil(dst_cols / 64)), ntiles = the total.  src f32 (src_rows, src_cols), dst bf16 (dst_rows, dst_cols); plain: dst[r][c] = src[map(r)][c], transposed: dst[r][c] = src[map(c)][r], 0 outside the source.  map 0: identity; 1: GEGLU [x | pad | gate | pad] split (aux = inner, half = mapped extent / 2); 2: ctclip_geglu_weight_interleave's row order (aux = inner). */
+int ctclip_shadow_refresh(const void* jobs, int njobs, int64_t ntiles, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

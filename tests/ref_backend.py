@@ -351,6 +351,28 @@ class RefBackend:
         out[8 * (j // 4) + 4 + j % 4] = w[inner:].float()
         return out.to(dtype)
 
+    def shadow_refresh(self, jobs, version):
+        """csrc/shadow.hip restated: dst = gather (plain: dst[r][c] = src[map(r)][c]; transposed: dst[r][c] = src[map(c)][r]), 0 outside."""
+        for j in jobs:
+            src, dst, mp, aux, tr = j["src"].float(), j["dst"], j["map"], j["aux"], j["transposed"]
+            ext = dst.shape[1] if tr else dst.shape[0]          # the mapped extent
+            other = dst.shape[0] if tr else dst.shape[1]        # extent along the source columns
+            n = torch.arange(ext)
+            if mp == 0:
+                idx = torch.where(n < src.shape[0], n, torch.full_like(n, -1))
+            elif mp == 1:
+                hp = ext // 2
+                idx = torch.where(n < hp, torch.where(n < aux, n, torch.full_like(n, -1)),
+                                  torch.where(n - hp < aux, aux + n - hp, torch.full_like(n, -1)))
+            else:
+                jj, part = 4 * (n >> 3) + (n & 3), (n >> 2) & 1
+                idx = torch.where(jj < aux, part * aux + jj, torch.full_like(n, -1))
+            m = torch.zeros(ext, other, dtype=torch.float32, device=src.device)
+            ok = idx >= 0
+            kc = min(other, src.shape[1])
+            m[ok, :kc] = src[idx[ok].to(src.device)][:, :kc]
+            dst.copy_((m.t() if tr else m).to(dst.dtype))
+
     def _geglu_parts(self, x, w_il, hp):
         y = _f(x) @ _f(w_il).t()                                  # interleaved columns
         y = y.view(x.shape[0], hp // 4, 2, 4)

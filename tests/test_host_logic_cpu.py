@@ -157,3 +157,64 @@ def test_fused_geglu_in_projection_composition(ref_backend):
     # f32 (parity mode) and small token counts stay on the unfused path
     assert not type(Fn.feed_forward_in(x.float(), w).grad_fn).__name__.startswith("FfInGegluFn")
     assert not type(Fn.feed_forward_in(x[:512], w).grad_fn).__name__.startswith("FfInGegluFn")
+
+
+def _shadow_zoo(dev, dtype):
+    """Creates one shadow of every kind the batched refresh knows (through the product code paths) and returns
+    (parameters, getter) where getter() re-reads all of them through the cache."""
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(3)
+    mk = lambda *sh: torch.nn.Parameter((torch.randn(*sh) * 0.3).to(dev))
+    w_plain, w_pad, w_ff_in, w_ff_out = mk(256, 512), mk(512, 1365), mk(2 * 341, 128), mk(128, 341)
+    wq, wk, wv = mk(64, 96), mk(64, 96), mk(64, 96)
+    Hp = Fn.geglu_hidden_pad(341)
+
+    def get():
+        out = {}
+        out["plain"] = Fn.plain_shadow(w_plain, dtype)
+        out["plain_T"] = Fn.transposed_shadow(w_plain, out["plain"], [(0, 256, 0)])
+        out["kpad"] = Fn.plain_shadow(w_pad, dtype, kpad=1408)
+        out["kpad_T"] = Fn.transposed_shadow(w_pad, out["kpad"], [(0, 512, 0)])
+        out["ff_out"] = Fn.plain_shadow(w_ff_out, dtype, kpad=Hp)
+        mk_in = lambda: torch.cat([Fn.B().convert_pad(w_ff_in.detach()[:341], Hp, 128, dtype), Fn.B().convert_pad(w_ff_in.detach()[341:], Hp, 128, dtype)])
+        out["geglu_in"] = Fn.shadow(w_ff_in, ("geglu_in", Hp), dtype, mk_in, recipe=[(w_ff_in, 0, 2 * Hp, 128, Fn.MAP_GEGLU_SPLIT, 341, False)])
+        out["geglu_in_T"] = Fn.transposed_shadow(w_ff_in, out["geglu_in"], [(0, 341, 0), (341, 341, Hp)])
+        out["geglu_il"] = Fn.shadow(w_ff_in, ("geglu_il", Hp), dtype, lambda: Fn.B().geglu_weight_interleave(w_ff_in.detach(), Hp, dtype),
+                                    recipe=[(w_ff_in, 0, 2 * Hp, 128, Fn.MAP_GEGLU_INTERLEAVE, 341, False)])
+        mk_qkv = lambda: torch.cat([Fn.B().convert_pad(w.detach(), 64, 96, dtype) for w in (wq, wk, wv)])
+        out["qkv"] = Fn.shadow(wq, ("qkv", id(wk), id(wv)), dtype, mk_qkv,
+                               recipe=[(w, i * 64, 64, 96, Fn.MAP_PLAIN, 0, False) for i, w in enumerate((wq, wk, wv))])
+        return out
+    return [w_plain, w_pad, w_ff_in, w_ff_out, wq, wk, wv], get
+
+
+def check_batched_shadow_refresh(dev):
+    """functional.refresh_shadows (one launch, csrc/shadow.hip) rebuilds every registered shadow in place, bit for bit what the lazy
+    per-shadow makers (convert_pad, transpose2d, geglu_weight_interleave) produce, and stamps it valid."""
+    from ct_clip_amd import functional as Fn
+    bf = torch.bfloat16
+    params, get = _shadow_zoo(dev, bf)
+    first = get()
+    ptrs = {k: v.data_ptr() for k, v in first.items()}
+    with torch.no_grad():
+        for p_ in params:                       # what the fused optimiser does: raw update, invisible to torch's version counters
+            p_.data.mul_(0.5).add_(0.25)
+    stale = {k: v.clone() for k, v in first.items()}
+    Fn.bump_weight_epoch()
+    Fn.refresh_shadows()
+    got = get()                                 # cache hits: the refreshed tensors themselves
+    assert all(got[k].data_ptr() == ptrs[k] for k in got), "the refresh must work in place and re-stamp the cache entries"
+    assert any(not torch.equal(got[k], stale[k]) for k in got)
+    batched = {k: v.clone() for k, v in got.items()}
+    Fn.bump_weight_epoch()                      # now force the lazy makers on the same weights
+    prev, Fn._SHADOW_BATCH = Fn._SHADOW_BATCH, False
+    try:
+        lazy = get()
+    finally:
+        Fn._SHADOW_BATCH = prev
+    for k in lazy:
+        assert lazy[k].shape == batched[k].shape and torch.equal(lazy[k], batched[k]), k
+
+
+def test_batched_shadow_refresh_matches_lazy_makers(ref_backend):
+    check_batched_shadow_refresh(torch.device("cpu"))

@@ -681,3 +681,11 @@ def test_grad_norm_and_adam(hip, ref):
         hip.adam_step(p, g, m, v, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clip)
         ref.adam_step(pr, g, mr, vr, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clipr)
     close(p, pr, rtol=1e-6, atol=1e-7); close(m, mr, rtol=1e-4, atol=1e-9); close(v, vr, rtol=1e-4, atol=1e-12)
+
+
+# ---------------------------------------------------------------- batched weight-shadow refresh (csrc/shadow.hip)
+def test_batched_shadow_refresh(hip):
+    """One launch rebuilds every kind of bf16 GEMM operand from the f32 weights, bit for bit what convert_pad / transpose2d /
+    geglu_weight_interleave make one by one (the CPU twin of this test runs the same check against the torch restatement)."""
+    from tests.test_host_logic_cpu import check_batched_shadow_refresh
+    check_batched_shadow_refresh(torch.device(DEV))

@@ -52,4 +52,18 @@ for name, K, N in layers:
         out[f"{name} (K={K}, N={N}) {cname}"] = dict(us=round(us, 1), tflops=round(fl / us / 1e6), GBps=round(by / us / 1e3),
                                                      floor_us=round(max(t_mfma, t_hbm), 1), bound="mfma" if t_mfma > t_hbm else "hbm",
                                                      frac_of_floor=round(max(t_mfma, t_hbm) / us, 2))
+# the fused GEGLU launches of the feed-forward in-projection (forward with / without the stored u, backward by recomputation) and
+# the streaming backward they replace
+K, Hp, inner = 512, 1408, 1365
+x, w32 = rnd(M, K), (torch.rand(2 * inner, K, device=dev, generator=g) * 2 - 1) * K ** -0.5
+w_il = be.geglu_weight_interleave(w32, Hp, torch.bfloat16)
+dg = rnd(M, Hp)
+u, _ = be.gemm_geglu(x, w_il, Hp)
+fl = 2 * M * 2 * Hp * K
+for cname, fn, by in [("ff_in fused fwd (u + g)", lambda: be.gemm_geglu(x, w_il, Hp), (M * K + 2 * Hp * K + 3 * M * Hp) * 2),
+                      ("ff_in fused fwd (g only)", lambda: be.gemm_geglu(x, w_il, Hp, save_u=False), (M * K + 2 * Hp * K + M * Hp) * 2),
+                      ("ff_in geglu bwd by recomputation", lambda: be.gemm_geglu_bwd(x, w_il, dg, Hp), (M * K + 2 * Hp * K + 3 * M * Hp) * 2),
+                      ("geglu_bwd streaming (replaced)", lambda: be.geglu_bwd(dg, u), 5 * M * Hp * 2)]:
+    us = timeit(fn)
+    out[cname] = dict(us=round(us, 1), tflops=round(fl / us / 1e6) if "streaming" not in cname else 0, GBps=round(by / us / 1e3))
 print(json.dumps(out, indent=1))
