@@ -500,6 +500,6 @@ extern "C" int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* d
                                      int64_t ldb, int64_t lddg, int64_t lddu, int dtype, hipStream_t stream) {
   if (!A || !B || !dG || !dU || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu_bwd: bad args"); return CTCLIP_EBADARG; }
   if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
-  const int rc = ctclip_gemm_nt_geglu_try(A, B, dU, nullptr, dG, M, hp, K, lda, ldb, lddu, 4, lddg, stream);
+  const int rc = ctclip_gemm_nt_geglu_try(A, B, dU, nullptr, dG, M, hp, K, lda, ldb, lddu, 8, lddg, stream);
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }

@@ -29,8 +29,10 @@
 //
 // Tile 256 x 256, 8 waves (4 x 2), wave tile 64 x 128 = 4 x 8 fragments of mfma_f32_16x16x32_bf16, two k-sub-steps per step.
 #include "common.h"
+#include <type_traits>
 
-// Compile-time ablation masks (tools/build_ablation.py; never set in the product build): 1 = no global loads after the first
+// Compile-time ablation masks (tools/build_ablation.py; never set in the product build): 8 = no panel waits in the first two steps of a
+// tile (timing only, wrong results), 1 = no global loads after the first
 // prologue, 4 = epilogue unreachable, 64 = always non-temporal stores.  (Run-time switches are useless here:
 // the compiler unswitches the loop and the extra branches perturb the production code.)
 #ifndef NT_ABL
@@ -41,6 +43,9 @@
 #endif
 #ifndef NT_STREAM_MB
 #define NT_STREAM_MB 128     // outputs larger than this use non-temporal stores
+#endif
+#ifndef NT_GEGLU_ABL
+#define NT_GEGLU_ABL 0       // ablations of the GEGLU forward epilogue: 1 = x * gate instead of x * gelu(gate), 2 = no stores
 #endif
 #ifndef NT_COUNTED_EPI
 #define NT_COUNTED_EPI 1     // 1 = the first step of a tile waits for its panels only, not for the previous tile's epilogue stores
@@ -210,7 +215,25 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   int cs = 0;             // ring slot of A(g) for the consumer's current step g
   int pn = 0;             // VMEM instructions this wave issued in the previous tile's epilogue (exact or an under-count; 0 = unknown)
   auto wait_prev = [&](int n) {      // wave-uniform
-    if (n == 16) wait_vm<GL + 16>(); else if (n == 32) wait_vm<GL + 32>(); else if (n == 48) wait_vm<GL + 48>(); else wait_vm<GL>();
+    switch (n) {
+      case 8: wait_vm<GL + 8>(); break;
+      case 16: wait_vm<GL + 16>(); break;
+      case 24: wait_vm<GL + 24>(); break;
+      case 32: wait_vm<GL + 32>(); break;
+      case 48: wait_vm<GL + 48>(); break;
+      default: wait_vm<GL>();
+    }
+  };
+  // GEGLU epilogues: a lane owns FOUR features of a row (8 bytes).  The store path costs ~60-85 clk per store INSTRUCTION per CU whatever
+  // its width (measured: 128 dwordx2 stores of a tile take as long as 128 dwordx4 stores), so adjacent lanes swap one row of each row
+  // pair and every lane writes 16 bytes of ONE row: even lanes the pair's first row, odd lanes the second.
+  int odd_i = li & 1;
+  auto pair_rows = [&](u32x2 d0, u32x2 d1) -> u32x4 {      // this lane's 8 bytes of rows r0 (d0), r0 + 1 (d1) -> the 16 bytes it stores
+    const bool odd_lane = odd_i != 0;
+    const u32x2 snd = odd_lane ? d0 : d1;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd[0], 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd[1], 0xB1, 0xF, 0xF, true);
+    return odd_lane ? u32x4{r0, r1, d1[0], d1[1]} : u32x4{d0[0], d0[1], r0, r1};
   };
 
   for (int it = 0;; ++it) {
@@ -299,7 +322,11 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     // every tile start by waiting for the COMPLETION of the previous tile's stores; now they have until barrier_(g+1).
     // pn = 0 (unknown / variable count: partial tiles, bias, arg-max) keeps the conservative wait; an under-count is always safe.
     int t = 0;
-#if NT_COUNTED_EPI
+#if NT_ABL & 8      // TIMING ONLY (results are wrong): the first two steps of a tile do not wait for their panels at all -- what would the
+    NT_STEP(wait_vm<63>())      // kernel cost if the epilogue stores' acknowledgements never held back the next tile's loads?
+    NT_STEP(wait_vm<63>())
+    t = 2;
+#elif NT_COUNTED_EPI
     NT_STEP(wait_prev(pn))
     t = 1;
 #endif
@@ -351,12 +378,18 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       // general path below loads each row right before its use (one dependent round trip per row: +37 us on a 48-us launch)
       const bool fast_res = vec_ok && p.residual && p.res_dtype == DT_BF16 && p.out_dtype == DT_BF16 && !p.accumulate && !p.bias &&
                             (m0 + TM <= p.M) && cols_in;
+      if (p.geglu_hp) {      // the lane-pair bit, opaque to the optimiser: addresses derived from it are NOT hoisted out of the tile loop
+        odd_i = li & 1;      // (hoisted, they lived across the main loop and were spilled to scratch)
+        asm volatile("" : "+v"(odd_i));
+      }
+      const bool odd_lane = odd_i != 0;
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
       if (p.geglu_hp && p.geglu_dg) {      // kernel-uniform; backward by recomputation
         const int64_t j0 = col >> 1;
-        bf16_t* du = reinterpret_cast<bf16_t*>(p.C);
+        // this lane stores row (pair's first row + odd_lane) at the lane PAIR's eight features
+        bf16_t* dup = reinterpret_cast<bf16_t*>(p.C) + (rbase + (odd_lane ? 1 : 0)) * p.ldc + (j0 - (odd_lane ? 4 : 0));
         const bf16_t* dgp = p.geglu_dg + rbase * p.lddg + j0;
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah) {          // eight rows of dg in flight per lane
@@ -368,56 +401,75 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int rp = 0; rp < 2; ++rp) {
               const int a = 2 * ah + a2;
-              const int64_t row = rbase + a * 16 + r;
-              float dx[4], dgt[4];
+              u32x2 ox[2], og[2];
 #pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const uint32_t w = dv[a2][r][b >> 1];
-                const float d = __uint_as_float((b & 1) ? (w & 0xffff0000u) : (w << 16));
-                const float x = acc[a][b][r] * p.alpha, gt = acc[a][4 + b][r] * p.alpha;
-                float y, dy;
-                gelu_erf_fast_both(gt, y, dy);
-                dx[b] = d * y; dgt[b] = d * x * dy;
+              for (int q = 0; q < 2; ++q) {
+                const int r = 2 * rp + q;
+                float dx[4], dgt[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                  const uint32_t w = dv[a2][r][b >> 1];
+                  const float d = __uint_as_float((b & 1) ? (w & 0xffff0000u) : (w << 16));
+                  const float x = acc[a][b][r] * p.alpha, gt = acc[a][4 + b][r] * p.alpha;
+                  float y, dy;
+                  gelu_erf_fast_both(gt, y, dy);
+                  dx[b] = d * y; dgt[b] = d * x * dy;
+                }
+                ox[q] = u32x2{pack2bf(dx[0], dx[1]), pack2bf(dx[2], dx[3])}; og[q] = u32x2{pack2bf(dgt[0], dgt[1]), pack2bf(dgt[2], dgt[3])};
               }
-              const u32x2 ox = {pack2bf(dx[0], dx[1]), pack2bf(dx[2], dx[3])}, og = {pack2bf(dgt[0], dgt[1]), pack2bf(dgt[2], dgt[3])};
-              if (NONTEMPORAL) {
-                __builtin_nontemporal_store(ox, reinterpret_cast<u32x2*>(du + row * p.ldc + j0));
-                __builtin_nontemporal_store(og, reinterpret_cast<u32x2*>(du + row * p.ldc + p.geglu_hp + j0));
-              } else {
-                *reinterpret_cast<u32x2*>(du + row * p.ldc + j0) = ox;
-                *reinterpret_cast<u32x2*>(du + row * p.ldc + p.geglu_hp + j0) = og;
-              }
+              bf16_t* dst = dup + (int64_t)(a * 16 + 2 * rp) * p.ldc;
+              store16<NONTEMPORAL>(dst, pair_rows(ox[0], ox[1]));
+              store16<NONTEMPORAL>(dst + p.geglu_hp, pair_rows(og[0], og[1]));
             }
         }
-        pn = 48;          // 16 loads of dg + 32 stores
+        pn = 32;          // 16 loads of dg + 16 stores
       } else if (p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only.  u (p.C) is optional: training keeps only g
         const int64_t j0 = col >> 1;              // first of the lane's four features
         bf16_t* u = reinterpret_cast<bf16_t*>(p.C);
+        // (two copies of the row loop, each ONE basic block: with the `u` test inside it every row was a block of its own and the
+        // scheduler could not interleave the dependent chains of different rows)
+        bf16_t* up = u + (rbase + (odd_lane ? 1 : 0)) * p.ldc + (j0 - (odd_lane ? 4 : 0));
+        bf16_t* gp = p.geglu_g + (rbase + (odd_lane ? 1 : 0)) * p.ldg + (j0 - (odd_lane ? 4 : 0));
+        auto rows = [&](auto with_u) {
+          constexpr bool WU = decltype(with_u)::value;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+          for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = rbase + a * 16 + r;
-            float x[4], gt[4], g[4];
+            for (int rp = 0; rp < 2; ++rp) {
+              u32x2 ux[2], ug[2], gg[2];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { x[b] = acc[a][b][r] * p.alpha; gt[b] = acc[a][4 + b][r] * p.alpha; g[b] = x[b] * gelu_erf_fast(gt[b]); }
-            const u32x2 gg = {pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
-            if (u) {
-              const u32x2 ux = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}, ug = {pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])};
-              if (NONTEMPORAL) {
-                __builtin_nontemporal_store(ux, reinterpret_cast<u32x2*>(u + row * p.ldc + j0));
-                __builtin_nontemporal_store(ug, reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0));
-              } else {
-                *reinterpret_cast<u32x2*>(u + row * p.ldc + j0) = ux;
-                *reinterpret_cast<u32x2*>(u + row * p.ldc + p.geglu_hp + j0) = ug;
+              for (int q = 0; q < 2; ++q) {
+                const int r = 2 * rp + q;
+                float x[4], gt[4], g[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                  x[b] = acc[a][b][r] * p.alpha; gt[b] = acc[a][4 + b][r] * p.alpha;
+#if NT_GEGLU_ABL & 1
+                  g[b] = x[b] * gt[b];
+#else
+                  g[b] = x[b] * gelu_erf_fast(gt[b]);
+#endif
+                }
+                gg[q] = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
+                if (WU) { ux[q] = u32x2{pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}; ug[q] = u32x2{pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])}; }
+              }
+#if NT_GEGLU_ABL & 2
+              if (p.alpha == 1234.5f)
+#endif
+              {
+                const int64_t ro = a * 16 + 2 * rp;
+                if (WU) {
+                  store16<NONTEMPORAL>(up + ro * p.ldc, pair_rows(ux[0], ux[1]));
+                  store16<NONTEMPORAL>(up + ro * p.ldc + p.geglu_hp, pair_rows(ug[0], ug[1]));
+                }
+                store16<NONTEMPORAL>(gp + ro * p.ldg, pair_rows(gg[0], gg[1]));
               }
             }
-            if (NONTEMPORAL) __builtin_nontemporal_store(gg, reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0));
-            else *reinterpret_cast<u32x2*>(p.geglu_g + row * p.ldg + j0) = gg;
-          }
-        pn = u ? 48 : 16;          // 16 rows x (x, gate, g) or g only, 8-byte stores
+        };
+        if (u) rows(std::true_type{}); else rows(std::false_type{});
+        pn = u ? 24 : 8;          // 8 row pairs x (x, gate, g) or g only, 16-byte stores
       } else if (fast_res) {
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + rbase * p.ldr + col;
 #pragma unroll
@@ -590,9 +642,9 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
 int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream) {
   const int64_t N = 2 * (int64_t)hp;
-  if (K % TK || K / TK < 2 || M % TM || N % TN || hp % 4 || ldu % 4 || ldg % 4 || lddg % 4) return 1;
+  if (K % TK || K / TK < 2 || M % TM || N % TN || hp % 8 || ldu % 8 || ldg % 8 || lddg % 4) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
-  if ((reinterpret_cast<uintptr_t>(U) % 8) || (reinterpret_cast<uintptr_t>(G) % 8) || (reinterpret_cast<uintptr_t>(dG) % 8)) return 1;
+  if ((reinterpret_cast<uintptr_t>(U) % 16) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(dG) % 8)) return 1;
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
   const int64_t ntm = M / TM, ntn = N / TN;
   if (ntm * ntn < 160) return 1;

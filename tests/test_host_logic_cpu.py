@@ -137,14 +137,14 @@ def test_fused_geglu_in_projection_composition(ref_backend):
     g2 = Fn.GegluFn.apply(Fn.linear_geglu_in(x, w))
     g2.backward(dg)
     torch.testing.assert_close(g1.float(), g2.float(), rtol=2e-2, atol=2e-2)
-    # (the recomputing backward differentiates at the UNROUNDED (x, gate): du differs from the stored-u path by bf16 ulps)
+    # (a recomputing backward differentiates at the UNROUNDED (x, gate): du differs from the stored-u path by bf16 ulps)
     torch.testing.assert_close(dx1.float(), x.grad.float(), rtol=2e-2, atol=5e-2)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     assert rel(dw1, w.grad) < 5e-3, rel(dw1, w.grad)      # 13 824 bf16-ulp differences per entry, not an identical du any more
     assert float(g1[:, inner:].abs().max()) == 0.0
-    # the stored-u backward (CTCLIP_GEGLU_RECOMPUTE=0) is the same operator again
+    # the recomputing backward (CTCLIP_GEGLU_RECOMPUTE=1: nothing but the layer input is kept) is the same operator again
     import os
-    os.environ["CTCLIP_GEGLU_RECOMPUTE"] = "0"
+    os.environ["CTCLIP_GEGLU_RECOMPUTE"] = "1"
     try:
         x.grad = None; w.grad = None
         g3 = Fn.feed_forward_in(x, w)

@@ -32,6 +32,10 @@ def timeit(fn):
 M = 110592
 layers = [("to_q", 512, 256), ("to_kv", 512, 512), ("to_out", 256, 512), ("ff_in", 512, 2816), ("ff_out", 1408, 512)]
 out = {}
+if os.environ.get("SHAPES_ONLY") == "fused":      # only the fused GEGLU launches (ablation runs)
+    layers = []
+elif os.environ.get("SHAPES_ONLY") == "ff":       # feed-forward in-projection, plain and fused, + to_kv
+    layers = [l for l in layers if l[0] in ("ff_in", "to_kv")]
 for name, K, N in layers:
     x, w, dy = rnd(M, K), rnd(N, K), rnd(M, N)
     wt = w.t().contiguous()

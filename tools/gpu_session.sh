@@ -1,11 +1,13 @@
 #!/bin/bash
-# One GPU session through gpurun: kernel tests, the whole GPU suite, a short bench, rocprofv3 kernel statistics of the step -> gpurun_out/<tag>
+# One GPU session through gpurun: the whole GPU suite, the default bench (50 steps, PMC traffic, attention block, CPU baseline), a short
+# bench under rocprofv3 --kernel-trace for the per-kernel statistics -> gpurun_out/session
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/session; mkdir -p $O
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "geglu or gemm or latent or vlat or visual" > $O/t_geglu.log 2>&1; echo "geglu tests rc=$? $(tail -n 1 $O/t_geglu.log)" >> $O/summary.log
-timeout 1500 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; echo "all gpu tests rc=$? $(tail -n 1 $O/t_all.log)" >> $O/summary.log
-timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pmc --no-attn-block > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/summary.log
+timeout 1500 python -m pytest tests -q -m gpu -s > $O/t_all.log 2>&1; echo "all gpu tests rc=$? $(tail -n 1 $O/t_all.log)" >> $O/summary.log
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?" >> $O/summary.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+timeout 300 python tools/bench_gemm_shapes.py 10 > $O/shapes.json 2> $O/shapes.err; echo "shapes rc=$?" >> $O/summary.log
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-attn-block > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err
 cd $GRAFT_REPO_ROOT
@@ -19,12 +21,12 @@ for path in glob.glob("gpurun_out/session/prof/**/*kernel_trace.csv", recursive=
         rows[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
 print("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|")
-for n, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:70]:
+for n, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:75]:
     print(f"| `{n[:110]}` | {len(v)} | {sum(v)/1e3:.2f} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {100*sum(v)/tot:.1f} |")
 print(f"\ntotal kernel time {tot/1e3:.1f} ms over {sum(len(v) for v in rows.values())} dispatches")
 PY
-rm -rf $O/prof/*/*.db
-grep -h "FAILED\|Error" $O/t_geglu.log $O/t_all.log | head; cat $O/summary.log; python -c "
+rm -rf $O/prof/*/*.db $O/prof/*/*_agent_info.csv
+grep -h "FAILED\|Error" $O/t_all.log | head; cat $O/summary.log; python -c "
 import json
-b=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]);print(b['ms_per_step'],b['value'])"
-head -14 $O/prof_stats.md
+b=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]);print(b['ms_per_step'],b['value'],b['roofline']['kernel'],b['roofline']['frac'],b['roofline'].get('traffic_over_algorithmic'),b['attn_block'].get('mfma_util_fwd'),b['cpu_baseline'].get('value'))"
+head -12 $O/prof_stats.md
