@@ -66,6 +66,8 @@ class HipBackend:
                 nbytes = float((M * K + N * K + M * (N // 2)) * esz)
             elif variant == "geglu-bwd recompute":
                 nbytes += M * (N // 2) * esz                       # dg read, du written
+            elif variant == "+geglu-bwd":
+                nbytes = float((M * K + N * K + 4 * M * N) * esz)  # dy, W_out^T, u = [x | gate] read, du written (N = hp)
             groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}" + (f" [{variant}]" if variant else ""), launches=len(ms),
                                side_stream=side, avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops,
                                bytes_per_launch=nbytes))
@@ -420,6 +422,28 @@ class HipBackend:
                                "+geglu" if save_u else "+geglu(g only)"), []).append((e0, e1))
         _lib.check(rc, "ctclip_gemm_geglu")
         return u, g
+
+    def gemm_dgeglu(self, dy, wt, u):
+        """du (M, 2 hp) = [dg gelu(gate) | dg x gelu'(gate)] with dg = dy @ wt^T formed in the accumulators only (wt = the out-projection
+        weight transposed, (hp, K)) and u = [x | gate] (M, 2 hp) as stored by gemm_geglu; None when the shape is not served."""
+        M, K = dy.shape
+        hp = wt.shape[0]
+        if dy.dtype != torch.bfloat16 or u.dtype != torch.bfloat16 or tuple(u.shape) != (M, 2 * hp):
+            return None
+        du = torch.empty_like(u)
+        timing = self._gemm_events
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = self.lib.ctclip_gemm_dgeglu(_p(dy), _p(wt), _p(u), _p(du), M, hp, K, _rowmajor(dy, "dy"), _rowmajor(wt, "wt"), _rowmajor(u, "u"),
+                                         _rowmajor(du, "du"), dcode(dy.dtype), _stream())
+        if rc == -2:
+            return None
+        if timing is not None:
+            e1.record()
+            timing.setdefault(("NT", "bf16", M, hp, K, torch.cuda.current_stream() != torch.cuda.default_stream(), "+geglu-bwd"), []).append((e0, e1))
+        _lib.check(rc, "ctclip_gemm_dgeglu")
+        return du
 
     def shadow_refresh(self, jobs, version):
         """jobs: [dict(src f32 (rows, cols) parameter, dst bf16 2-D view, map, aux, transposed)] -> one launch (csrc/shadow.hip).  The

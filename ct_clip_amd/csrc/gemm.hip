@@ -456,6 +456,8 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
 // ---------------------------------------------------------------------------------------------------- fused GEGLU in-projection
 int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream);
+int ctclip_gemm_nt_dgeglu_try(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                              int64_t ldu, int64_t lddu, hipStream_t stream);
 
 namespace {
 __global__ __launch_bounds__(256) void geglu_weight_interleave_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int inner, int hp, int K, int64_t ldo) {
@@ -501,5 +503,18 @@ extern "C" int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* d
   if (!A || !B || !dG || !dU || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_geglu_bwd: bad args"); return CTCLIP_EBADARG; }
   if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
   const int rc = ctclip_gemm_nt_geglu_try(A, B, dU, nullptr, dG, M, hp, K, lda, ldb, lddu, 8, lddg, stream);
+  return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
+}
+
+// Backward of the feed-forward block between the out-projection and the GEGLU in ONE launch: dU (M, lddu >= 2 hp) =
+// [dg * gelu(gate) | dg * x * gelu'(gate)] where dg = dY W_out is formed in the accumulators only (A = dY (M, K = model width) bf16,
+// B = W_out^T (hp, ldb >= K): hidden feature j in row j) and u = [x | gate] (M, ldu >= 2 hp) is what ctclip_gemm_geglu stored.
+// Replaces the grad-input GEMM of FeedForward[4] + ctclip_geglu_bwd (dg: one write and one read of M x hp less, one pass over u and du
+// instead of two launches).  CTCLIP_EUNSUPPORTED when the shape does not fill whole 256-row tiles / 128-column halves.
+extern "C" int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda,
+                                  int64_t ldb, int64_t ldu, int64_t lddu, int dtype, hipStream_t stream) {
+  if (!A || !B || !U || !dU || M < 1 || hp < 1 || K < 1) { ctclip_set_error("gemm_dgeglu: bad args"); return CTCLIP_EBADARG; }
+  if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
+  const int rc = ctclip_gemm_nt_dgeglu_try(A, B, U, dU, M, hp, K, lda, ldb, ldu, lddu, stream);
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }

@@ -47,6 +47,9 @@
 #ifndef NT_GEGLU_ABL
 #define NT_GEGLU_ABL 0       // ablations of the GEGLU forward epilogue: 1 = x * gate instead of x * gelu(gate), 2 = no stores
 #endif
+#ifndef NT_DG_ROWS
+#define NT_DG_ROWS 2         // rows of u in flight per lane in the out-projection grad-input + GEGLU backward epilogue (1, 2 or 4)
+#endif
 #ifndef NT_COUNTED_EPI
 #define NT_COUNTED_EPI 1     // 1 = the first step of a tile waits for its panels only, not for the previous tile's epilogue stores
 #endif
@@ -75,6 +78,10 @@ struct NtParams {
   // GEGLU backward by recomputation (ctclip_gemm_geglu_bwd): the same GEMM recomputes (x, gate) in f32, the epilogue loads dg and
   // stores du = [dg * gelu(gate) | dg * x * gelu'(gate)] to C -- the forward then has no u to store and the backward no u to read.
   const bf16_t* geglu_dg; int64_t lddg;
+  // Grad-input GEMM of the feed-forward OUT-projection with the GEGLU backward in its epilogue (ctclip_gemm_dgeglu): the accumulators
+  // are dg = dy W_out (column j = hidden feature j); the epilogue loads u = [x | gate] (row stride dgeglu_ldu, gate at + dgeglu_hp) and
+  // stores du = [dg * gelu(gate) | dg * x * gelu'(gate)] to C (gate half at + dgeglu_hp).  dg itself never reaches memory.
+  const bf16_t* dgeglu_u; int64_t dgeglu_ldu; int dgeglu_hp;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -105,7 +112,10 @@ __device__ __forceinline__ void store16(void* c, u32x4 d) {
   else *reinterpret_cast<u32x4*>(c) = d;
 }
 
-template <bool NONTEMPORAL>
+// EPI selects the epilogue family compiled into the instantiation (each family alone: with all of them in one kernel the allocator
+// hoisted lane addresses of every variant out of the tile loop and spilled them): 0 = plain / bias / residual / accumulate / f32 /
+// partial tiles / arg-max, 1 = GEGLU forward and its recomputing backward, 2 = out-projection grad-input + GEGLU backward.
+template <bool NONTEMPORAL, int EPI>
 __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int ntiles = p.ntm * p.ntn;
@@ -341,8 +351,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     // a lane owns 8 consecutive columns, 16 lanes one 256-B (bf16) row segment, one 16-byte store instruction writes 4 full rows
     // of the wave tile.  The stores are not waited for here: they retire under the next tile's first one and a half sub-steps.
     pn = 0;
-    if (p.part_val) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
-      const int64_t col0 = n0 + wn * 128 + li * 8;
+    // the lane coordinates, opaque to the optimiser from here on: every per-lane address of the epilogue is then recomputed per tile
+    // (a few VALU operations) -- hoisted out of the tile loop as loop invariants they lived across the main loop and were spilled
+    // (and spilled; even li / lg themselves were: hence the lane id is read again from the hardware, inside a volatile asm)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int li_e = lane_e & 15, lg_e = lane_e >> 4;
+    if (EPI == 0 && p.part_val) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
+      const int64_t col0 = n0 + wn * 128 + li_e * 8;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -358,8 +374,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
             const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bidx, o, 64);
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
           }
-          const int64_t row = m0 + wm * 64 + a * 16 + lg * 4 + r;
-          if (li == 0 && row < p.M) {
+          const int64_t row = m0 + wm * 64 + a * 16 + lg_e * 4 + r;
+          if (li_e == 0 && row < p.M) {
             const int64_t slot = row * p.nparts + (n0 / TN) * 2 + wn;
             p.part_val[slot] = best; p.part_idx[slot] = bidx;
           }
@@ -367,8 +383,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     } else {
       const bool vec_ok = ((p.ldc % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.C) % 16) == 0) &&
                           (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
-      const int64_t col = n0 + wn * 128 + li * 8;
-      const int64_t rbase = m0 + wm * 64 + lg * 4;
+      const int64_t col = n0 + wn * 128 + li_e * 8;
+      const int64_t rbase = m0 + wm * 64 + lg_e * 4;
       // (wave-uniform conditions.  A wave owns 128 of the tile's 256 columns: in the last, half-filled column tile of N = 1408 the
       // waves of the filled half keep the fast path and the others have nothing to store)
       const bool cols_in = n0 + wn * 128 + 128 <= p.N, cols_out = n0 + wn * 128 >= p.N;
@@ -378,15 +394,12 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       // general path below loads each row right before its use (one dependent round trip per row: +37 us on a 48-us launch)
       const bool fast_res = vec_ok && p.residual && p.res_dtype == DT_BF16 && p.out_dtype == DT_BF16 && !p.accumulate && !p.bias &&
                             (m0 + TM <= p.M) && cols_in;
-      if (p.geglu_hp) {      // the lane-pair bit, opaque to the optimiser: addresses derived from it are NOT hoisted out of the tile loop
-        odd_i = li & 1;      // (hoisted, they lived across the main loop and were spilled to scratch)
-        asm volatile("" : "+v"(odd_i));
-      }
+      odd_i = li_e & 1;      // the lane-pair bit of the GEGLU epilogues
       const bool odd_lane = odd_i != 0;
 #if NT_ABL & 4
       if (p.alpha == 1234.5f)
 #endif
-      if (p.geglu_hp && p.geglu_dg) {      // kernel-uniform; backward by recomputation
+      if (EPI == 1 && p.geglu_hp && p.geglu_dg) {      // kernel-uniform; backward by recomputation
         const int64_t j0 = col >> 1;
         // this lane stores row (pair's first row + odd_lane) at the lane PAIR's eight features
         bf16_t* dup = reinterpret_cast<bf16_t*>(p.C) + (rbase + (odd_lane ? 1 : 0)) * p.ldc + (j0 - (odd_lane ? 4 : 0));
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
             }
         }
         pn = 32;          // 16 loads of dg + 16 stores
-      } else if (p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only.  u (p.C) is optional: training keeps only g
+      } else if (EPI == 1 && p.geglu_hp) {      // kernel-uniform; the launcher admits full tiles only.  u (p.C) is optional: training keeps only g
         const int64_t j0 = col >> 1;              // first of the lane's four features
         bf16_t* u = reinterpret_cast<bf16_t*>(p.C);
         // (two copies of the row loop, each ONE basic block: with the `u` test inside it every row was a block of its own and the
@@ -470,6 +483,49 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
         };
         if (u) rows(std::true_type{}); else rows(std::false_type{});
         pn = u ? 24 : 8;          // 8 row pairs x (x, gate, g) or g only, 16-byte stores
+      } else if (EPI == 2 && p.dgeglu_u) {      // kernel-uniform; the launcher admits full row tiles and whole 128-column halves only
+        if (!cols_out) {
+          const bf16_t* up = p.dgeglu_u + rbase * p.dgeglu_ldu + col;
+          bf16_t* dp = reinterpret_cast<bf16_t*>(p.C) + rbase * p.ldc + col;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {          // NT_DG_ROWS rows of u (x and gate: 16-byte loads) in flight per lane
+#pragma unroll
+            for (int rh = 0; rh < 4; rh += NT_DG_ROWS) {
+              u32x4 xv[NT_DG_ROWS], gv[NT_DG_ROWS];
+#pragma unroll
+              for (int q = 0; q < NT_DG_ROWS; ++q) {
+                xv[q] = *reinterpret_cast<const u32x4*>(up + (int64_t)(a * 16 + rh + q) * p.dgeglu_ldu);
+                gv[q] = *reinterpret_cast<const u32x4*>(up + (int64_t)(a * 16 + rh + q) * p.dgeglu_ldu + p.dgeglu_hp);
+              }
+#pragma unroll
+              for (int q = 0; q < NT_DG_ROWS; ++q) {
+                const int r = rh + q;
+                u32x4 ox, og;
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) {
+                  float o1[2], o2[2];
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const int b = 2 * b2 + h;
+                    const float d = acc[a][b][r] * p.alpha;
+                    const float x = __uint_as_float(h ? (xv[q][b2] & 0xffff0000u) : (xv[q][b2] << 16));
+                    const float gt = __uint_as_float(h ? (gv[q][b2] & 0xffff0000u) : (gv[q][b2] << 16));
+                    float y, dy;
+                    gelu_erf_fast_both(gt, y, dy);
+                    o1[h] = d * y; o2[h] = d * x * dy;
+                  }
+                  ox[b2] = pack2bf(o1[0], o1[1]); og[b2] = pack2bf(o2[0], o2[1]);
+                }
+                bf16_t* dst = dp + (int64_t)(a * 16 + r) * p.ldc;
+                store16<NONTEMPORAL>(dst, ox);
+                store16<NONTEMPORAL>(dst + p.dgeglu_hp, og);
+              }
+            }
+          }
+          pn = 48;          // 32 loads + 32 stores: more than vmcnt can count, an under-count is safe
+        }
+      } else if (EPI != 0) {
+        // (the launchers set the parameters of the instantiation's own family)
       } else if (fast_res) {
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + rbase * p.ldr + col;
 #pragma unroll
@@ -584,16 +640,22 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 }  // namespace
 
 static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
+  const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : 0);
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
+    const void* fns[6] = {(const void*)gemm_nt_kernel<false, 0>, (const void*)gemm_nt_kernel<true, 0>, (const void*)gemm_nt_kernel<false, 1>,
+                          (const void*)gemm_nt_kernel<true, 1>, (const void*)gemm_nt_kernel<false, 2>, (const void*)gemm_nt_kernel<true, 2>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
     raised = true;
   }
   static int ncu = 0;
   if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? (prop.multiProcessorCount & ~7) : 256; }
-  if (nontemporal) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
-  else hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)ncu), dim3(NTH), NPANEL * PANEL, stream, p);
+  const dim3 grid((unsigned)ncu), block(NTH);
+#define NT_GO(E) do { if (nontemporal) hipLaunchKernelGGL((gemm_nt_kernel<true, E>), grid, block, NPANEL * PANEL, stream, p); \
+                      else hipLaunchKernelGGL((gemm_nt_kernel<false, E>), grid, block, NPANEL * PANEL, stream, p); } while (0)
+  if (epi == 1) NT_GO(1); else if (epi == 2) NT_GO(2); else NT_GO(0);
+#undef NT_GO
   return ctclip_check_launch("gemm_nt");
 }
 
@@ -655,4 +717,23 @@ int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, con
   p.geglu_dg = (const bf16_t*)dG; p.lddg = lddg;
   const int64_t out_bytes = (U ? M * N * 2 : 0) + (G ? M * (int64_t)hp * 2 : 0);
   return nt_launch(p, out_bytes > ((int64_t)NT_STREAM_MB << 20), stream);
+}
+
+// Grad-input GEMM of the feed-forward out-projection + GEGLU backward (attention.py:39-51, backward): dU (M, lddu >= 2 hp) =
+// [dg * gelu(gate) | dg * x * gelu'(gate)] with dg = A B^T (A = dy (M, K), B = the out-projection weight TRANSPOSED (hp, K), hidden
+// feature j in row j) and u = [x | gate] (M, ldu >= 2 hp) the tensor ctclip_gemm_geglu stored.  Returns 1 when the shape is not eligible.
+int ctclip_gemm_nt_dgeglu_try(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                              int64_t ldu, int64_t lddu, hipStream_t stream) {
+  const int64_t N = hp;
+  if (K % TK || K / TK < 2 || M % TM || N % 128 || ldu % 8 || lddu % 8) return 1;
+  if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
+  if ((reinterpret_cast<uintptr_t>(U) % 16) || (reinterpret_cast<uintptr_t>(dU) % 16)) return 1;
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
+  const int64_t ntm = M / TM, ntn = cdiv(N, TN);
+  if (ntm * ntn < 160) return 1;
+  NtParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = dU; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = lddu;
+  p.out_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
+  p.dgeglu_u = (const bf16_t*)U; p.dgeglu_ldu = ldu; p.dgeglu_hp = hp;
+  return nt_launch(p, M * 2 * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
 }

@@ -157,8 +157,7 @@ class Transformer(nn.Module):
             x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
             y, x = Fn.layer_norm_branch(x, ff[0].weight, ff[0].bias, 1)
-            g = Fn.feed_forward_in(y, ff[1].weight)
-            x = Fn.linear_geglu_out(g, ff[4].weight, residual=x)
+            x = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x)
         return Fn.layer_norm(x, self.norm_out.gamma, None)
 
 

@@ -343,6 +343,71 @@ def feed_forward_in(x, weight):
     return GegluFn.apply(linear_geglu_in(x, weight))
 
 
+class FeedForwardFn(Function):
+    """FeedForward[1..4] (attention.py:44-52 without its LayerNorm) + the residual add as ONE autograd node on the fused bf16 path:
+      forward   u = [x | gate], g = x gelu(gate)   (one launch, GEGLU in the in-projection epilogue);   out = g W_out^T + residual
+      backward  dW_out = dout^T g;   du = [dg gelu(gate) | dg x gelu'(gate)] with dg = dout W_out formed ONLY in the accumulators of the
+                grad-input GEMM (ctclip_gemm_dgeglu: no dg tensor, no streaming geglu_bwd pass);   dy = du W_in;   dW_in = du^T y.
+    CTCLIP_GEGLU_RECOMPUTE=1: u is not stored; the backward recomputes it (ctclip_gemm_geglu_bwd) from y after an ordinary dg GEMM."""
+
+    @staticmethod
+    def forward(ctx, y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K):
+        be = B()
+        recompute = os.environ.get("CTCLIP_GEGLU_RECOMPUTE", "0") == "1"
+        u, g = be.gemm_geglu(y, w_il, Hp, save_u=not recompute)
+        out = be.gemm(g, wsh_out, residual=residual)
+        ctx.save_for_backward(y, g, wsh_in, wsh_out, w_il if recompute else u)
+        ctx.recompute, ctx.has_res = recompute, residual is not None
+        ctx.w_in, ctx.w_out, ctx.dims = w_in, w_out, (Hp, inner, K)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, g, wsh_in, wsh_out, last = ctx.saved_tensors
+        Hp, inner, K = ctx.dims
+        be = B()
+        dout = dout.contiguous()
+        N = ctx.w_out.shape[0]
+        dw_out = weight_grad(dout, g, ctx.w_out, [(0, N, 0)], inner) if ctx.w_out.requires_grad else None
+        wt_out = transposed_shadow(ctx.w_out, wsh_out, [(0, N, 0)])                   # (Hp, N): hidden feature j in row j
+        du = None
+        if not ctx.recompute:
+            du = be.gemm_dgeglu(dout, wt_out, last)
+        if du is None:
+            dg = be.gemm(dout, wt_out)
+            du = be.gemm_geglu_bwd(y, last, dg, Hp) if ctx.recompute else be.geglu_bwd(dg, last)
+        segs = [(0, inner, 0), (inner, inner, Hp)]
+        dy = be.gemm(du, transposed_shadow(ctx.w_in, wsh_in, segs)) if ctx.needs_input_grad[0] else None
+        dw_in = weight_grad(du, y, ctx.w_in, segs, K) if ctx.w_in.requires_grad else None
+        dres = dout if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dy, dw_in, dw_out, dres, None, None, None, None, None, None
+
+
+def feed_forward(y, w_in, w_out, residual=None):
+    """LayerNormed tokens -> FeedForward output (+ residual).  One autograd node with the fused launches when the large-tile kernel
+    serves the shape (bf16, whole 256-row tiles), otherwise the composition of the separate pieces."""
+    two_inner, K = w_in.shape
+    inner = two_inner // 2
+    Hp = geglu_hidden_pad(inner)
+    M = y.shape[0]
+    fused = (y.dtype == torch.bfloat16 and M % 256 == 0 and (2 * Hp) % 256 == 0 and (M // 256) * (2 * Hp // 256) >= 160 and K % 64 == 0 and K >= 128
+             and (residual is None or residual.dtype == y.dtype) and os.environ.get("CTCLIP_FF_NODE", "1") != "0")
+    if not fused:
+        return linear_geglu_out(feed_forward_in(y, w_in), w_out, residual)
+
+    def make():
+        w = w_in.detach()
+        out = torch.empty((2 * Hp, K), dtype=y.dtype, device=w.device)
+        B().convert_pad(w[:inner], Hp, K, y.dtype, out=out[:Hp])
+        B().convert_pad(w[inner:], Hp, K, y.dtype, out=out[Hp:])
+        return out
+    wsh_in = shadow(w_in, ("geglu_in", Hp), y.dtype, make, recipe=[(w_in, 0, 2 * Hp, K, MAP_GEGLU_SPLIT, inner, False)])
+    w_il = shadow(w_in, ("geglu_il", Hp), y.dtype, lambda: B().geglu_weight_interleave(w_in.detach(), Hp, y.dtype),
+                  recipe=[(w_in, 0, 2 * Hp, K, MAP_GEGLU_INTERLEAVE, inner, False)])
+    wsh_out = plain_shadow(w_out, y.dtype, kpad=Hp)
+    return FeedForwardFn.apply(y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K)
+
+
 def linear_geglu_out(g, weight, residual):
     """FeedForward[4]: Linear(inner, d, no bias) (attention.py:51) consuming the padded hidden (M, Hp), + residual."""
     N, inner = weight.shape

@@ -128,6 +128,9 @@ int ctclip_gemm_geglu(const void* A, const void* B, void* U, void* G, int64_t M,
 /* Backward of ctclip_gemm_geglu through the GEGLU by RECOMPUTATION (replaces torch autograd through `x * F.gelu(gate)` of attention.py:39-42 and the activation it would keep): the same GEMM A B^T rebuilds (x, gate) in f32 and the epilogue writes dU (M, lddu >= 2 hp) = [dG * gelu(gate) | dG * x * gelu'(gate)] from dG (M, lddg >= hp), bf16.  The forward then stores no u (pass U = NULL to ctclip_gemm_geglu) and the streaming ctclip_geglu_bwd pass is not needed.  Same eligibility as ctclip_gemm_geglu (CTCLIP_EUNSUPPORTED otherwise). */
 int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* dG, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t lddg, int64_t lddu, int dtype, hipStream_t stream);
 
+/* Backward of the feed-forward block between FeedForward[4] and the GEGLU in ONE launch (replaces torch autograd through `Linear(inner, dim)` and `x * F.gelu(gate)`, attention.py:39-51): dU (M, lddu >= 2 hp) = [dg * gelu(gate) | dg * x * gelu'(gate)] where dg = dY W_out exists only in the accumulators (A = dY (M, K = model width) bf16, B = W_out^T (hp, ldb >= K), hidden feature j in row j) and U = [x | gate] (M, ldu >= 2 hp) is what ctclip_gemm_geglu stored.  No dg tensor, no ctclip_geglu_bwd pass.  CTCLIP_EUNSUPPORTED when the shape does not fill whole 256-row tiles / 128-column halves (caller: ctclip_gemm + ctclip_geglu_bwd). */
+int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu, int64_t lddu, int dtype, hipStream_t stream);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

@@ -373,6 +373,17 @@ class RefBackend:
             m[ok, :kc] = src[idx[ok].to(src.device)][:, :kc]
             dst.copy_((m.t() if tr else m).to(dst.dtype))
 
+    def gemm_dgeglu(self, dy, wt, u):
+        """out-projection grad-input + GEGLU backward: dg = dy wt^T stays f32 (never rounded to the storage dtype)."""
+        if dy.dtype != torch.bfloat16 or dy.shape[0] % 256 or wt.shape[0] % 128:
+            return None
+        dg = _f(dy) @ _f(wt).t()
+        uu = _f(u).detach().requires_grad_(True)
+        with torch.enable_grad():
+            a, gt = uu.chunk(2, dim=-1)
+            (gu,) = torch.autograd.grad(a * F.gelu(gt), uu, dg)
+        return gu.to(u.dtype)
+
     def _geglu_parts(self, x, w_il, hp):
         y = _f(x) @ _f(w_il).t()                                  # interleaved columns
         y = y.view(x.shape[0], hp // 4, 2, 4)

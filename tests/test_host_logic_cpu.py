@@ -159,6 +159,46 @@ def test_fused_geglu_in_projection_composition(ref_backend):
     assert not type(Fn.feed_forward_in(x[:512], w).grad_fn).__name__.startswith("FfInGegluFn")
 
 
+def test_feed_forward_node_composition(ref_backend):
+    """functional.feed_forward: the single autograd node of the fused path (FeedForwardFn: GEGLU in the in-projection epilogue, GEGLU
+    backward in the out-projection grad-input epilogue) is the same operator as linear_geglu_out(feed_forward_in(.)) -- output and the
+    gradients of the input, of both weights and of the residual; also with the recomputing backward."""
+    import os
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(1)
+    M, K, inner = 256 * 54, 128, 341
+    w_in = (torch.randn(2 * inner, K) * K ** -0.5).requires_grad_(True)
+    w_out = (torch.randn(K, inner) * inner ** -0.5).requires_grad_(True)
+    y = torch.randn(M, K).to(torch.bfloat16).requires_grad_(True)
+    res = torch.randn(M, K).to(torch.bfloat16).requires_grad_(True)
+    dout = torch.randn(M, K).to(torch.bfloat16)
+    leaves = (y, res, w_in, w_out)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+
+    def run(fn):
+        for t in leaves:
+            t.grad = None
+        out = fn()
+        out.backward(dout)
+        return [out.detach()] + [t.grad.clone() for t in leaves]
+    ref = run(lambda: Fn.linear_geglu_out(Fn.feed_forward_in(y, w_in), w_out, res))
+    node = run(lambda: Fn.feed_forward(y, w_in, w_out, residual=res))
+    assert type(Fn.feed_forward(y, w_in, w_out, residual=res).grad_fn).__name__.startswith("FeedForwardFn")
+    assert torch.equal(node[0], ref[0]) and torch.equal(node[2], ref[2])           # same forward launches; the residual gradient is dout
+    for a, b in zip(node[1:], ref[1:]):                                                # du: dg is not rounded to bf16 on the fused path
+        assert rel(a, b) < 6e-3, rel(a, b)
+    os.environ["CTCLIP_GEGLU_RECOMPUTE"] = "1"
+    try:
+        rec = run(lambda: Fn.feed_forward(y, w_in, w_out, residual=res))
+    finally:
+        del os.environ["CTCLIP_GEGLU_RECOMPUTE"]
+    assert torch.equal(rec[0], ref[0])
+    for a, b in zip(rec[1:], ref[1:]):
+        assert rel(a, b) < 6e-3, rel(a, b)
+    # f32 (parity mode) and small token counts compose the separate pieces
+    assert not type(Fn.feed_forward(y.float(), w_in, w_out, residual=res.float()).grad_fn).__name__.startswith("FeedForwardFn")
+
+
 def _shadow_zoo(dev, dtype):
     """Creates one shadow of every kind the batched refresh knows (through the product code paths) and returns
     (parameters, getter) where getter() re-reads all of them through the cache."""

@@ -207,6 +207,28 @@ def test_gemm_geglu_fused(hip, ref, M, inner, K):
     assert torch.equal(du, hip.gemm_geglu_bwd(x, w_il, dg, Hp))
 
 
+@pytest.mark.parametrize("M,inner,K", [(256 * 40, 1365, 512), (256 * 90, 341, 128), (256 * 14, 1365, 512)])
+def test_gemm_dgeglu_fused(hip, ref, M, inner, K):
+    """Backward of the feed-forward block between the out-projection and the GEGLU in one launch: du = [dg gelu(gate) | dg x gelu'(gate)]
+    with dg = dy W_out in the accumulators only -- against the checker and against the two launches it replaces (GEMM + geglu_bwd);
+    Hp = 1408 ends in a half-filled column tile; the last shape does not fill the chip and must be declined."""
+    bf = torch.bfloat16
+    Hp = (inner + 127) // 128 * 128
+    dy = rnd(M, K, dtype=bf, seed=1, scale=0.5)
+    wt = torch.zeros(Hp, K, dtype=bf, device=DEV)
+    wt[:inner] = rnd(inner, K, seed=2, scale=inner ** -0.5).to(bf)                   # W_out^T, zero rows for the padded features
+    u = rnd(M, 2 * Hp, dtype=bf, seed=3)
+    u[:, inner:Hp] = 0; u[:, Hp + inner:] = 0
+    du = hip.gemm_dgeglu(dy, wt, u)
+    if (M // 256) * ((Hp + 255) // 256) < 160:
+        assert du is None
+        return
+    close(du, ref.gemm_dgeglu(dy, wt, u), rtol=3e-2, atol=2e-2)
+    close(du, hip.geglu_bwd(hip.gemm(dy, wt), u), rtol=5e-2, atol=3e-2)
+    assert float(du[:, inner:Hp].abs().max()) == 0.0 and float(du[:, Hp + inner:].abs().max()) == 0.0
+    assert torch.equal(du, hip.gemm_dgeglu(dy, wt, u))
+
+
 # ---------------------------------------------------------------- short-sequence cosine attention (csrc/attn_short.hip)
 @pytest.mark.parametrize("nseq,H,L,strided", [(5, 8, 24, False), (3, 2, 32, False), (7, 3, 1, False), (4, 8, 2, True), (300, 8, 24, True),
                                               (2, 1, 9, False), (1100, 8, 24, False)])

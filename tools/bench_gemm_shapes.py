@@ -70,4 +70,10 @@ for cname, fn, by in [("ff_in fused fwd (u + g)", lambda: be.gemm_geglu(x, w_il,
                       ("geglu_bwd streaming (replaced)", lambda: be.geglu_bwd(dg, u), 5 * M * Hp * 2)]:
     us = timeit(fn)
     out[cname] = dict(us=round(us, 1), tflops=round(fl / us / 1e6) if "streaming" not in cname else 0, GBps=round(by / us / 1e3))
+# the grad-input GEMM of the out-projection with the GEGLU backward in its epilogue, and the two launches it replaces
+dy, wt = rnd(M, K), rnd(Hp, K)
+for cname, fn in [("ff_out dgrad + geglu bwd (one launch)", lambda: be.gemm_dgeglu(dy, wt, u)),
+                  ("ff_out dgrad, then geglu_bwd (two launches)", lambda: be.geglu_bwd(be.gemm(dy, wt), u))]:
+    us = timeit(fn)
+    out[cname] = dict(us=round(us, 1), tflops=round(2 * M * Hp * K / us / 1e6), GBps=round((M * K + Hp * K + 4 * M * Hp) * 2 / us / 1e3))
 print(json.dumps(out, indent=1))
