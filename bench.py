@@ -8,11 +8,14 @@ gathered-negatives CLIP loss, backward, gradient all-reduce (N > 1), global grad
 already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- the GEMM shape with the largest total time in the timed steps: algorithmic FLOPs per launch / mean launch duration
-                  measured with events on the launch stream around every launch, vs the 2.5 PFLOP/s dense bf16 peak; top5 = the other
-                  shapes.  `traffic` = HBM bytes per launch of that kernel at that shape MEASURED in this run: after the timed region
-                  rank 0 re-runs the one GEMM under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, FETCH_SIZE x2
-                  for gfx950 as MI355X_MICROARCH.md prescribes); null with a reason when rocprofv3 is unavailable (--no-pmc skips it).
+  roofline     -- the GEMM launch group with the largest total time in the timed steps (main stream), timed with an event pair on the
+                  launch stream around every launch.  Each group is priced against both floors -- algorithmic FLOPs / 2.5 PFLOP/s dense
+                  bf16 and algorithmic bytes / 8 TB/s -- and the larger one names its bound: the feed-forward GEMMs with a GEGLU
+                  epilogue move 1.0-1.4 GB per launch and are HBM-bound, the plain ones MFMA-bound.  `achieved` / `peak` / `unit` are
+                  in the bound's unit, `tflops` and `algorithmic_GBps` give both; top5 = the other groups.  `traffic` = HBM bytes per
+                  launch of that launch group MEASURED in this run: after the timed region rank 0 re-runs the one launch under
+                  `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, FETCH_SIZE x2 for gfx950 as MI355X_MICROARCH.md
+                  prescribes); null with a reason when rocprofv3 is unavailable (--no-pmc skips it).
   attn_block   -- the second half of BASELINE.json's metric ("CTViT MFMA util %"): one spatial attention block (LayerNorm, to_q / to_kv
                   projections, cosine attention with position bias, to_out + residual; attention.py:127-181) at the bench batch, timed
                   with event pairs around the block, forward and forward+backward; FLOPs per SURVEY.md 8(d) (22.65 GF / volume / layer
@@ -176,14 +179,25 @@ def run_cpu_baseline_bounded(args, sdepth, tdepth):
 
 # ----------------------------------------------------------------------------------------------------------------- PMC companion
 def gemm_probe(spec, iters=6):
-    """Child mode: run ONE GEMM shape through the C ABI a few times (under rocprofv3 --pmc).  spec = 'NT|NN|TN M N K'."""
+    """Child mode: run ONE GEMM launch group through the C ABI a few times (under rocprofv3 --pmc).
+    spec = 'NT|NN|TN M N K variant' (variant '-' = plain, or the fused GEGLU launches of backend.py's timing keys)."""
     from ct_clip_amd import backend
     be = backend.get()
-    layout, M, N, K = spec.split()
+    layout, M, N, K, variant = (spec.split() + ["-"])[:5]
     M, N, K = int(M), int(N), int(K)
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *sh: (torch.rand(*sh, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
-    if layout == "NT":
+    if variant.startswith("+geglu") and variant != "+geglu-bwd" or variant == "geglu-bwd_recompute":
+        hp = N // 2
+        x, w = rnd(M, K), (torch.rand(2 * hp, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5
+        w_il = be.geglu_weight_interleave(w, hp, torch.bfloat16)
+        dg = rnd(M, hp)
+        fn = {"+geglu": lambda: be.gemm_geglu(x, w_il, hp), "+geglu(g_only)": lambda: be.gemm_geglu(x, w_il, hp, save_u=False),
+              "geglu-bwd_recompute": lambda: be.gemm_geglu_bwd(x, w_il, dg, hp)}[variant]
+    elif variant == "+geglu-bwd":
+        dy, wt, u = rnd(M, K), rnd(N, K), rnd(M, 2 * N)
+        fn = lambda: be.gemm_dgeglu(dy, wt, u)
+    elif layout == "NT":
         a, b = rnd(M, K), rnd(N, K)
         fn = lambda: be.gemm(a, b)
     elif layout == "NN":
@@ -198,19 +212,17 @@ def gemm_probe(spec, iters=6):
     torch.cuda.synchronize()
 
 
-def measure_traffic(kernel_label, timeout=150.0):
-    """HBM bytes per launch of the dominant GEMM, from two rocprofv3 --pmc passes over `bench.py --gemm-probe` (rank 0, N = 1)."""
+def measure_traffic(spec, timeout=150.0):
+    """HBM bytes per launch of the dominant GEMM launch group, from two rocprofv3 --pmc passes over `bench.py --gemm-probe` (rank 0, N = 1)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
-    m = __import__("re").match(r"gemm_kernel<\w+,(\w+)> M=(\d+) N=(\d+) K=(\d+)", kernel_label)
-    if not m:
+    if not spec:
         return None, "dominant kernel is not a GEMM"
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    spec = " ".join(m.groups())
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -421,7 +433,7 @@ def main():
     if timing:
         timing["traffic"] = None
         if rank == 0 and world == 1 and not args.no_pmc:
-            tr, why = measure_traffic(timing["kernel"])
+            tr, why = measure_traffic(timing.get("probe_spec"))
             if tr is not None:
                 timing["traffic"] = tr.pop("bytes")
                 timing["traffic_detail"] = tr

@@ -49,14 +49,17 @@ class HipBackend:
         """Record an event pair on the launch stream around every ctclip_gemm launch until stop_gemm_timing()."""
         self._gemm_events = {}
 
-    def stop_gemm_timing(self, peak_tflops=2500.0):
+    def stop_gemm_timing(self, peak_tflops=2500.0, peak_gbps=8000.0):
+        """-> the roofline record of the GEMM launch group with the largest total time on the main stream.  Each group is priced
+        against BOTH floors (algorithmic FLOPs / dense MFMA peak, algorithmic bytes / HBM peak); the larger floor names its bound:
+        the fused launches (GEGLU epilogues) move 1.0-1.4 GB per launch and are HBM-bound, the plain feed-forward GEMMs MFMA-bound."""
         ev, self._gemm_events = self._gemm_events, None
         torch.cuda.synchronize()
         groups = []
         for key, pairs in ev.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
             layout, dt, M, N, K, side = key[:6]
-            variant = key[6] if len(key) > 6 else ""       # fused GEGLU launches: forward (u and / or g written), backward recomputation
+            variant = key[6] if len(key) > 6 else ""       # fused GEGLU launches: forward (u and / or g written), backward
             flops = 2.0 * M * N * K
             esz = 2 if dt == "bf16" else 4
             nbytes = float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))
@@ -68,22 +71,26 @@ class HipBackend:
                 nbytes += M * (N // 2) * esz                       # dg read, du written
             elif variant == "+geglu-bwd":
                 nbytes = float((M * K + N * K + 4 * M * N) * esz)  # dy, W_out^T, u = [x | gate] read, du written (N = hp)
+            avg_us = sum(ms) / len(ms) * 1e3
+            peak_tf = peak_tflops if dt == "bf16" else 157.3
+            t_mfma, t_hbm = flops / (peak_tf * 1e12) * 1e6, nbytes / (peak_gbps * 1e9) * 1e6
             groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}" + (f" [{variant}]" if variant else ""), launches=len(ms),
-                               side_stream=side, avg_us=sum(ms) / len(ms) * 1e3, total_ms=sum(ms), flops_per_launch=flops,
-                               bytes_per_launch=nbytes))
+                               side_stream=side, avg_us=avg_us, total_ms=sum(ms), flops_per_launch=flops, bytes_per_launch=nbytes,
+                               tflops=flops / (avg_us * 1e-6) / 1e12, gbps=nbytes / (avg_us * 1e-6) / 1e9, peak_tflops=peak_tf,
+                               bound="mfma" if t_mfma >= t_hbm else "hbm", frac=max(t_mfma, t_hbm) / avg_us,
+                               spec=f"{layout} {M} {N} {K} {variant.replace(' ', '_') or '-'}"))
         # launches on the text tower's side stream wait for the image tower's kernels between their two events: their event time is
         # not kernel time, so the dominant kernel is picked among the launches of the main stream
         groups.sort(key=lambda g: (g["side_stream"], -g["total_ms"]))
         top = groups[0]
-        ach = top["flops_per_launch"] / (top["avg_us"] * 1e-6) / 1e12
-        bf = "bf16" in top["kernel"]
-        peak = peak_tflops if bf else 157.3
-        return dict(bound="mfma", kernel=top["kernel"], achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
-                    frac=round(ach / peak, 4), traffic=None, launches=top["launches"], avg_us=round(top["avg_us"], 1),
+        mf = top["bound"] == "mfma"
+        return dict(bound=top["bound"], kernel=top["kernel"], achieved=round(top["tflops"] if mf else top["gbps"], 1),
+                    peak=top["peak_tflops"] if mf else peak_gbps, unit="TFLOP/s" if mf else "GB/s", frac=round(top["frac"], 4), traffic=None,
+                    launches=top["launches"], avg_us=round(top["avg_us"], 1), tflops=round(top["tflops"], 1), algorithmic_GBps=round(top["gbps"], 1),
                     algorithmic_flops_per_launch=top["flops_per_launch"], algorithmic_bytes_per_launch=top["bytes_per_launch"],
-                    gemm_total_ms=round(sum(g["total_ms"] for g in groups if not g["side_stream"]), 2),
-                    top5=[dict(kernel=g["kernel"], launches=g["launches"], avg_us=round(g["avg_us"], 1),
-                               tflops=round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)) for g in groups[:5]])
+                    probe_spec=top["spec"], gemm_total_ms=round(sum(g["total_ms"] for g in groups if not g["side_stream"]), 2),
+                    top5=[dict(kernel=g["kernel"], launches=g["launches"], avg_us=round(g["avg_us"], 1), tflops=round(g["tflops"], 1),
+                               GBps=round(g["gbps"], 1), bound=g["bound"], frac=round(g["frac"], 3)) for g in groups[:5]])
 
     # ------------------------------------------------------------------ helpers
     def workspace(self, device, nbytes):
