@@ -9,7 +9,8 @@ already resident in HBM when the timed region starts.  Ra
 
 Extra objects on the line:
   roofline     -- the GEMM launch group with the largest total time in the timed steps (main stream), timed with an event pair on the
-                  launch stream around every launch.  Each group is priced against both floors -- algorithmic FLOPs / 2.5 PFLOP/s dense
+                  launch stream around every launch (in `--profile-steps` extra steps after the timed region, with the weight-gradient
+                  side stream switched off so that one event pair spans one kernel).  Each group is priced against both floors -- algorithmic FLOPs / 2.5 PFLOP/s dense
                   bf16 and algorithmic bytes / 8 TB/s -- and the larger one names its bound: the feed-forward GEMMs with a GEGLU
                   epilogue move 1.0-1.4 GB per launch and are HBM-bound, the plain ones MFMA-bound.  `achieved` / `peak` / `unit` are
                   in the bound's unit, `tflops` and `algorithmic_GBps` give both; top5 = the other groups.  `traffic` = HBM bytes per
@@ -333,6 +334,7 @@ def main():
     ap.add_argument("--cpu-timeout", type=float, default=150.0, help="wall-clock bound (s) for the CPU baseline subprocess")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc companion passes that measure roofline.traffic")
     ap.add_argument("--no-attn-block", action="store_true", help="skip the attention-block MFMA utilisation measurement")
+    ap.add_argument("--profile-steps", type=int, default=10, help="extra steps after the timed region in which every GEMM launch is event-timed (roofline)")
     ap.add_argument("--gemm-probe", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help="additionally time the reference-true 4+4-layer model")
@@ -388,8 +390,6 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        if profile_gemm:
-            be.start_gemm_timing()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
@@ -398,7 +398,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        timing = be.stop_gemm_timing() if profile_gemm else None
+        timing = None
+        if profile_gemm and args.profile_steps > 0:
+            # Per-launch durations for `roofline`: the timed steps run the weight-gradient GEMMs on a side stream UNDER the grad-input
+            # GEMMs (functional.wgrad_stream_begin), so an event pair around one launch there spans two kernels sharing the chip.  The
+            # launches are therefore timed in extra steps AFTER the timed region with that overlap switched off (same kernels, same
+            # shapes, one stream): kernel efficiency, not the schedule, is what the roofline fraction states.
+            prev = os.environ.get("CTCLIP_WGRAD_STREAM")
+            os.environ["CTCLIP_WGRAD_STREAM"] = "0"
+            try:
+                step()
+                torch.cuda.synchronize()
+                be.start_gemm_timing()
+                for _ in range(args.profile_steps):
+                    step()
+                timing = be.stop_gemm_timing()
+                timing["timed_in"] = (f"{args.profile_steps} extra steps after the timed region with the weight-gradient stream off "
+                                      "(CTCLIP_WGRAD_STREAM=0: launches serialised on one stream)")
+            finally:
+                if prev is None:
+                    del os.environ["CTCLIP_WGRAD_STREAM"]
+                else:
+                    os.environ["CTCLIP_WGRAD_STREAM"] = prev
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

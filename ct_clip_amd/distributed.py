@@ -135,15 +135,19 @@ class GradReducer:
                 self.pending.append(seg)
 
     def _launch(self, a, b):
-        evt = None
+        evt, wg_evts = None, None
         if self.comm_stream is not None:
-            evt = torch.cuda.current_stream().record_event()      # everything that wrote flat[a:b] is in front of this event
+            evt = torch.cuda.current_stream().record_event()      # everything that wrote flat[a:b] is in front of this event ...
+            from . import functional as Fn
+            wg_evts = Fn.wgrad_event()                            # ... or of these (weight gradients written on their own stream)
         for s in range(a, b, self.max_elems):
             e = min(b, s + self.max_elems)
             self.log.append((s, e))
             self.launched.append((s, e))
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(evt)
+                for e in (wg_evts or ()):
+                    self.comm_stream.wait_event(e)
                 with torch.cuda.stream(self.comm_stream):
                     self._reduce_slice(s, e)
             else:

@@ -139,9 +139,59 @@ def _split_k_for(n_rows, n_cols, K, dtype):
     return max(1, min(ktiles, 1024 // max(tiles, 1)))
 
 
+# ---- weight-gradient stream.  dW = dy^T x is a leaf of the backward graph: nothing downstream of it runs before the optimiser (or the
+# gradient all-reduce of its bucket).  Between wgrad_stream_begin() and wgrad_stream_end() (the trainer brackets loss.backward() with
+# them) the big split-K GEMMs that write into the flat gradient buffer are launched on a side stream, UNDER the grad-input GEMMs of the
+# main stream: the persistent kernels leave CUs idle in their last partial round (864 tiles on 256 CUs = 3.375 rounds) and the other
+# stream's workgroups start there.  Off outside the bracket: a caller that reads gradients right after backward() sees them complete.
+_WG = {"on": False, "streams": {}, "used": set()}
+
+
+def wgrad_stream_begin():
+    _WG["on"] = os.environ.get("CTCLIP_WGRAD_STREAM", "1") != "0"
+
+
+def _wgrad_side(t):
+    if not (_WG["on"] and t.is_cuda):
+        return None
+    dev = t.device
+    if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
+        return None            # the text tower's backward already runs on its own side stream
+    st = _WG["streams"].get(dev.index)
+    if st is None:
+        st = _WG["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def wgrad_event():
+    """An event behind everything launched on the weight-gradient stream(s) so far (for the gradient all-reduce), or None."""
+    evs = [_WG["streams"][i].record_event() for i in _WG["used"]]
+    return evs or None
+
+
+def wgrad_stream_end():
+    """Join: the current stream waits for the weight-gradient stream."""
+    for i in _WG["used"]:
+        torch.cuda.current_stream(torch.device("cuda", i)).wait_stream(_WG["streams"][i])
+    _WG["used"].clear()
+    _WG["on"] = False
+
+
 def weight_grad(dy, x, weight, segments, K):
     """dW[r0:r0+n, :K] (+)= dy[:, c0:c0+n]^T @ x[:, :K]   for (r0, n, c0) in segments.  Returns grad or None (sink)."""
     sink = sink_of(weight)
+    side = _wgrad_side(dy) if (sink is not None and dy.shape[0] >= 4096) else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dy.device))      # dy and x were produced on the main stream
+        dy.record_stream(side); x.record_stream(side)               # ... and may be freed there while the side stream still reads them
+        _WG["used"].add(dy.device.index)
+        with torch.cuda.stream(side):
+            _weight_grad(dy, x, weight, segments, K, sink)
+        return None
+    return _weight_grad(dy, x, weight, segments, K, sink)
+
+
+def _weight_grad(dy, x, weight, segments, K, sink):
     if sink is None:
         dst = torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
     else:
@@ -239,6 +289,9 @@ class LinearFn(Function):
             dyc = B().convert_pad(dy, dy.shape[0], round_up(nout, 8), x.dtype)[:, :nout]
         else:
             dyc = dy
+        dw = None
+        if ctx.weight.requires_grad:      # first: on the weight-gradient stream it then runs under the grad-input GEMM below
+            dw = weight_grad(dyc, x, ctx.weight, ctx.segments, ctx.K)
         dx = None
         if ctx.needs_input_grad[0]:
             if dyc.dtype == torch.bfloat16 and dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0:
@@ -249,9 +302,6 @@ class LinearFn(Function):
                 dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
             if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
                 dx = dx[:, :x.shape[1]]
-        dw = None
-        if ctx.weight.requires_grad:
-            dw = weight_grad(dyc, x, ctx.weight, ctx.segments, ctx.K)
         db = None
         if ctx.bias is not None and ctx.bias.requires_grad:
             db = vec_grad(ctx.bias, lambda dst: B().colsum(dyc, dst, N=ctx.bias.numel()))
@@ -312,6 +362,7 @@ class FfInGegluFn(Function):
         be = B()
         dg = dg.contiguous()
         du = be.gemm_geglu_bwd(x, third, dg, Hp) if ctx.recompute else be.geglu_bwd(dg, third)
+        dw = weight_grad(du, x, ctx.weight, [(0, inner, 0), (inner, inner, Hp)], K) if ctx.weight.requires_grad else None
         dx = None
         if ctx.needs_input_grad[0]:
             if du.shape[0] >= 4096:
@@ -319,7 +370,6 @@ class FfInGegluFn(Function):
                 dx = be.gemm(du, wt)
             else:
                 dx = be.gemm(du, wsh, a_kc=True, b_kc=False)
-        dw = weight_grad(du, x, ctx.weight, [(0, inner, 0), (inner, inner, Hp)], K) if ctx.weight.requires_grad else None
         return dx, dw, None, None, None, None, None
 
 
@@ -377,8 +427,8 @@ class FeedForwardFn(Function):
             dg = be.gemm(dout, wt_out)
             du = be.gemm_geglu_bwd(y, last, dg, Hp) if ctx.recompute else be.geglu_bwd(dg, last)
         segs = [(0, inner, 0), (inner, inner, Hp)]
+        dw_in = weight_grad(du, y, ctx.w_in, segs, K) if ctx.w_in.requires_grad else None      # (weight-gradient stream: under the next GEMM)
         dy = be.gemm(du, transposed_shadow(ctx.w_in, wsh_in, segs)) if ctx.needs_input_grad[0] else None
-        dw_in = weight_grad(du, y, ctx.w_in, segs, K) if ctx.w_in.requires_grad else None
         dres = dout if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dy, dw_in, dw_out, dres, None, None, None, None, None, None
 

@@ -228,7 +228,11 @@ class CTClipTrainer(nn.Module):
     def forward_backward(self, video, text_tokens):
         """fwd + bwd + gradient all-reduce; returns the (device) loss."""
         loss = self.CTClip(text_tokens, video, return_loss=True, device=self.device)
-        loss.backward()          # announces finished layers to the reducer as it goes (functional.grad_ready)
+        Fn.wgrad_stream_begin()  # the big weight-gradient GEMMs go to a side stream, under the grad-input GEMMs of the main stream
+        try:
+            loss.backward()      # announces finished layers to the reducer as it goes (functional.grad_ready)
+        finally:
+            Fn.wgrad_stream_end()
         self.reducer.finish()
         return loss
 

@@ -9,7 +9,8 @@ timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; ech
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
 timeout 300 python tools/bench_gemm_shapes.py 10 > $O/shapes.json 2> $O/shapes.err; echo "shapes rc=$?" >> $O/summary.log
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-attn-block > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err
+# (per-kernel durations: with the weight-gradient stream off, so that no two big kernels share the chip inside one duration)
+CTCLIP_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-attn-block > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err
 cd $GRAFT_REPO_ROOT
 python - <<'PY' > $O/prof_stats.md 2>&1
 import csv, glob, re, collections
