@@ -225,10 +225,11 @@ class HipBackend:
         _lib.check(rc, "ctclip_peg_fwd")
         return y
 
-    def peg_bwd(self, dy, x, w, dw=None, db=None):
+    def peg_bwd(self, dy, x, w, dw=None, db=None, want_dx=True):
+        """want_dx=False: weight gradient only (returns None); dw=None: grad-input only."""
         B, D1, D2, D3, C = x.shape
         assert dy.is_contiguous() and x.is_contiguous()
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if want_dx else None
         ws = self.workspace(x.device, self.lib.ctclip_peg_bwd_workspace(B, D1, D2, C)) if dw is not None else None
         rc = self.lib.ctclip_peg_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, D1, D2, D3, C, dcode(x.dtype), _p(ws),
                                      ws.numel() if ws is not None else 0, _stream())
@@ -360,10 +361,19 @@ class HipBackend:
         _lib.check(rc, "ctclip_attn2_fwd")
         return o, lse2
 
-    def attn2_bwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab):
+    def attn2_bwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab, defer_dtab=False):
+        """defer_dtab: skip the table-gradient pass and return (dqh, dkh, dvh, ws) with ws = a workspace tensor of this call's own that
+        attn2_bwd_dbias finishes the job from (on another stream, later)."""
         H, M, _ = qh.shape
         gh, gw = bias_grid if tab is not None else (0, 0)
         dqh, dkh, dvh = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
+        if defer_dtab:
+            ws = torch.empty(self.lib.ctclip_attn2_bwd_workspace(nseq, H, L, gh, gw), dtype=torch.uint8, device=qh.device)
+            rc = self.lib.ctclip_attn2_bwd(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o),
+                                           _rowmajor(o, "o"), _p(dout), _rowmajor(dout, "dout"), _p(lse2), _p(dqh), _p(dkh), _p(dvh), None,
+                                           nseq, H, L, _p(ws), ws.numel(), _stream())
+            _lib.check(rc, "ctclip_attn2_bwd")
+            return dqh, dkh, dvh, ws
         dtab = torch.empty_like(tab) if (want_dtab and tab is not None) else None
         ws = self.workspace(qh.device, self.lib.ctclip_attn2_bwd_workspace(nseq, H, L, gh if dtab is not None else 0, gw))
         rc = self.lib.ctclip_attn2_bwd(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o),
@@ -371,6 +381,16 @@ class HipBackend:
                                        nseq, H, L, _p(ws), ws.numel(), _stream())
         _lib.check(rc, "ctclip_attn2_bwd")
         return dqh, dkh, dvh, dtab
+
+    def attn2_bwd_dbias(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, lse2, nseq, L, ws):
+        """The table gradient (ncls, H) from the workspace a deferred attn2_bwd left behind."""
+        H = qh.shape[0]
+        gh, gw = bias_grid
+        dtab = torch.empty_like(tab)
+        rc = self.lib.ctclip_attn2_bwd_dbias(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(lse2), _p(dtab),
+                                             nseq, H, L, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "ctclip_attn2_bwd_dbias")
+        return dtab
 
     def attn2_unprep(self, dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale):
         H, M, _ = qh.shape

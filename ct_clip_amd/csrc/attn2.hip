@@ -753,6 +753,37 @@ extern "C" int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, 
   return ctclip_dbias_fold(p.dbias_part, p.nsplit, bins, dtab, H, bias_gh, bias_gw, stream);
 }
 
+// The position-bias table gradient of ctclip_attn2_bwd as a call of its own: dtab (ncls, H) OVERWRITTEN.  `workspace` must be the SAME
+// buffer (>= ctclip_attn2_bwd_workspace(nseq, H, L, bias_gh, bias_gw)) a preceding ctclip_attn2_bwd(..., dtab = NULL, ...) of the same
+// problem was given: its first two regions hold dO' and delta' published by the query pass.  The table gradient is a leaf of the backward
+// graph; the host runs this call on a side stream under the rest of the layer's backward.
+extern "C" int ctclip_attn2_bwd_dbias(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw,
+                                      const float* q_scale, const float* k_scale, float scale, const float* lse2, float* dtab, int nseq, int H,
+                                      int L, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (!qh || !kh || !vh || !tab || !dtab || !lse2 || !q_scale || !k_scale) { ctclip_set_error("attn2_bwd_dbias: bad args"); return CTCLIP_EBADARG; }
+  if (!shape_ok(H, L, bias_gh, bias_gw, tab)) { ctclip_set_error("attn2_bwd_dbias: unsupported shape"); return CTCLIP_EUNSUPPORTED; }
+  if (!workspace || workspace_bytes < ctclip_attn2_bwd_workspace(nseq, H, L, bias_gh, bias_gw)) { ctclip_set_error("attn2_bwd_dbias: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int64_t M = (int64_t)nseq * L;
+  Params p{};
+  p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
+  p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = M; p.c = scale * LOG2E;
+  p.lse2 = const_cast<float*>(lse2);
+  char* w = (char*)workspace;
+  p.dop = (bf16_t*)w; w += a256(H * M * D * 2);
+  p.deltap = (float*)w; w += a256(H * M * 4);
+  p.nsplit = dbias_splits(nseq, H, L);
+  p.dbias_part = (float*)w; w += a256((int64_t)p.nsplit * H * L * L * 4);
+  float* bins = (float*)w;
+  const int nkb = L / 32;
+  int rc = attn2_slab_bwd_dbias(p, stream);
+  if (rc == 1) {
+    hipLaunchKernelGGL(attn2_bwd_dbias_kernel, dim3((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, p.nsplit), dim3(512), 0, stream, p);
+    rc = ctclip_check_launch("attn2_bwd_dbias");
+  }
+  if (rc) return rc;
+  return ctclip_dbias_fold(p.dbias_part, p.nsplit, bins, dtab, H, bias_gh, bias_gw, stream);
+}
+
 extern "C" int64_t ctclip_attn2_unprep_workspace(void) { return (int64_t)UNPREP_BLOCKS * 2 * 32 * 4; }
 
 // l2norm backward (attention.py:152-154) + layout: head-planar dq^, dk^, dv -> row-major dq (M, lddq), dk (M, lddk), dv (M, lddv);

@@ -287,14 +287,15 @@ extern "C" int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C) {
 }
 
 // dx = dy + conv^T(dy) ; dw (C,27) and db (C) f32 are ACCUMULATED (+=) when non-null (two stages, fixed summation order).
+// dx may be NULL (weight gradient only) and dw may be NULL (grad-input only): the host launches the two halves on different streams.
 extern "C" int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2,
                               int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
-  if (!dy || !x || !w || !dx || C % 8) { ctclip_set_error("peg_bwd: bad args"); return CTCLIP_EBADARG; }
+  if (!dy || !x || !w || (!dx && !dw) || C % 8) { ctclip_set_error("peg_bwd: bad args"); return CTCLIP_EBADARG; }
   if (dw && (!workspace || workspace_bytes < ctclip_peg_bwd_workspace(B, D1, D2, C))) { ctclip_set_error("peg_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
   if (peg_lds_supported(B, D1, D2, D3, C, dtype)) {
     // marching kernels: grad-in, then the weight gradient (per-workgroup partials + the same ordered second stage)
     int groups = 0;
-    const bool dx_done = peg_lds_march(dy, w, nullptr, dx, B, D1, D2, D3, C, -1, stream) == 0;
+    const bool dx_done = !dx || peg_lds_march(dy, w, nullptr, dx, B, D1, D2, D3, C, -1, stream) == 0;
     const bool dw_done = dx_done && dw && peg_lds_wgrad(dy, x, (float*)workspace, B, D1, D2, D3, C, &groups, stream) == 0;
     if (dw_done) hipLaunchKernelGGL(peg_wgrad_reduce_kernel, dim3((unsigned)cdiv(C * 28, 256)), dim3(256), 0, stream, (const float*)workspace, groups, C, dw, db);
     if (dx_done && (dw_done || !dw)) return ctclip_check_launch("peg_bwd");
@@ -311,10 +312,10 @@ extern "C" int ctclip_peg_bwd(const void* dy, const void* x, const float* w, voi
   dim3 grid((unsigned)(cdiv(nrows, 16) * cdiv(C, CCH)));
   dim3 gridw((unsigned)(cdiv(nrows, 16 * WG_ROWS) * cdiv(C, CCH) * 3));
   if (dtype == DT_F32) {
-    hipLaunchKernelGGL((peg_kernel<float, -1>), grid, dim3(256), 0, stream, (const float*)dy, w, nullptr, (float*)dx, nrows, D1, D2, D3, C);
+    if (dx) hipLaunchKernelGGL((peg_kernel<float, -1>), grid, dim3(256), 0, stream, (const float*)dy, w, nullptr, (float*)dx, nrows, D1, D2, D3, C);
     if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<float>, gridw, dim3(256), 0, stream, (const float*)dy, (const float*)x, (float*)workspace, nrows, D1, D2, D3, C);
   } else if (dtype == DT_BF16) {
-    hipLaunchKernelGGL((peg_kernel<bf16_t, -1>), grid, dim3(256), 0, stream, (const bf16_t*)dy, w, nullptr, (bf16_t*)dx, nrows, D1, D2, D3, C);
+    if (dx) hipLaunchKernelGGL((peg_kernel<bf16_t, -1>), grid, dim3(256), 0, stream, (const bf16_t*)dy, w, nullptr, (bf16_t*)dx, nrows, D1, D2, D3, C);
     if (dw) hipLaunchKernelGGL(peg_wgrad_kernel<bf16_t>, gridw, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, nrows, D1, D2, D3, C);
   } else return CTCLIP_EUNSUPPORTED;
   if (dw) hipLaunchKernelGGL(peg_wgrad_reduce_kernel, dim3((unsigned)cdiv(C * 28, 256)), dim3(256), 0, stream, (const float*)workspace,

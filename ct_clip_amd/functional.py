@@ -612,7 +612,18 @@ class PegFn(Function):
         ws, bs = sink_of(w), sink_of(b)
         dw = ws.view(-1, 27) if ws is not None else torch.zeros((w.shape[0], 27), dtype=torch.float32, device=dy.device)
         db = bs if bs is not None else torch.zeros_like(b)
-        dx = B().peg_bwd(dy.contiguous(), x5, w.detach().reshape(w.shape[0], 27), dw, db)
+        dy = dy.contiguous()
+        w27 = w.detach().reshape(w.shape[0], 27)
+        side = _wgrad_side(dy) if (ws is not None and bs is not None) else None
+        if side is not None:       # the weight / bias gradient is a leaf: on the weight-gradient stream, under the grad-input kernel
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            dy.record_stream(side); x5.record_stream(side)
+            _WG["used"].add(dy.device.index)
+            with torch.cuda.stream(side):
+                B().peg_bwd(dy, x5, w27, dw, db, want_dx=False)
+            dx = B().peg_bwd(dy, x5, w27, None, None)
+        else:
+            dx = B().peg_bwd(dy, x5, w27, dw, db)
         return dx, (None if ws is not None else dw.view_as(w)), (None if bs is not None else db)
 
 
@@ -687,6 +698,13 @@ class CosineAttn2Fn(Function):
         ctx.save_for_backward(qh, kh, vh, qinv, kinv, o, lse2, tabc if tabc is not None else q.new_empty(0))
         ctx.scales = (q_scale, k_scale)
         ctx.dims = (nseq, L, H, D, scale, tab is not None, bias_grid, q.dtype)
+        # the layers that share one table (ctvit.py:293): the table gradient of all of them is handed to autograd by the FIRST layer (the
+        # last one in backward) when the weight-gradient stream is on -- see backward
+        ctx.tab_users = None
+        if tab is not None and tab.requires_grad:
+            st = tab.__dict__.setdefault("_ctclip_tab_users", {"n": 0, "acc": None})
+            ctx.tab_users, ctx.tab_index = st, st["n"]
+            st["n"] += 1
         return o
 
     @staticmethod
@@ -698,8 +716,33 @@ class CosineAttn2Fn(Function):
         qs, ks = q_scale.detach(), k_scale.detach()
         HD = H * D
         do = do.contiguous()
-        dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L,
-                                           has_tab and ctx.needs_input_grad[4])
+        want_dtab = has_tab and ctx.needs_input_grad[4]
+        side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
+        if side is not None:
+            # The table gradient is a leaf until the position-bias MLP's backward, which runs after the FIRST layer's attention backward.
+            # Its pass (a third recomputation of S and dP) goes to the weight-gradient stream, under the rest of this layer's backward;
+            # the layers' tables are summed there, in backward order, and the first layer joins the stream and returns the sum.
+            dqh, dkh, dvh, ws = be.attn2_bwd(qh, kh, vh, tab, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, True, defer_dtab=True)
+            st = ctx.tab_users
+            side.wait_stream(torch.cuda.current_stream(do.device))
+            for t in (qh, kh, vh, lse2, tab, ws):
+                t.record_stream(side)
+            _WG["used"].add(do.device.index)
+            with torch.cuda.stream(side):
+                d = be.attn2_bwd_dbias(qh, kh, vh, tab, bias_grid, qs, ks, scale, lse2, nseq, L, ws)
+                if st["acc"] is None:
+                    st["acc"] = d
+                else:
+                    be.accumulate(st["acc"], d)
+            dtab = None
+            if ctx.tab_index == 0:
+                torch.cuda.current_stream(do.device).wait_stream(side)
+                dtab, st["acc"], st["n"] = st["acc"], None, 0
+                dtab.record_stream(torch.cuda.current_stream(do.device))
+        else:
+            dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, want_dtab)
+            if ctx.tab_users is not None and ctx.tab_index == 0:
+                ctx.tab_users["n"], ctx.tab_users["acc"] = 0, None
         M = o.shape[0]
         dq = torch.empty((M, HD), dtype=dtype, device=o.device)
         dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)

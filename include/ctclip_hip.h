@@ -59,6 +59,9 @@ int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_gh, int bias
 /* backward of ctclip_attn2_fwd: head-planar dq~, dk^, dv [H][M][32] bf16 (the l2norm / scale backward is ctclip_attn2_unprep) and, when dtab is non-null, the gradient of the position-bias table (nclass, H) f32, ACCUMULATED (+=) in a fixed summation order. */
 int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, void* dqh, void* dkh, void* dvh, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* The position-bias table gradient of ctclip_attn2_bwd as a call of its own (the scatter-add of dBias over the (2h-1)(2w-1) offset classes that autograd performs through `ContinuousPositionBias`, attention.py:257-276): dtab (ncls, H) OVERWRITTEN.  `workspace` must be the SAME buffer (>= ctclip_attn2_bwd_workspace(nseq, H, L, bias_gh, bias_gw)) a preceding ctclip_attn2_bwd(..., dtab = NULL, ...) of the same problem was given: its first two regions hold dO' and delta' of the query pass.  The host runs this call on a side stream, under the rest of the layer's backward. */
+int ctclip_attn2_bwd_dbias(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const float* lse2, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* bytes of workspace ctclip_attn2_unprep needs for the partial sums of the q_scale / k_scale gradients. */
 int64_t ctclip_attn2_unprep_workspace(void);
 

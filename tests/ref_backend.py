@@ -110,7 +110,7 @@ class RefBackend:
         y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C)
         return (y.permute(0, 2, 3, 4, 1) + _f(x)).to(x.dtype).contiguous()
 
-    def peg_bwd(self, dy, x, w, dw=None, db=None):
+    def peg_bwd(self, dy, x, w, dw=None, db=None, want_dx=True):
         C = x.shape[-1]
         xx = _f(x).detach().requires_grad_(True)
         ww = w.detach().clone().requires_grad_(True)
@@ -123,7 +123,7 @@ class RefBackend:
             dw += gw
         if db is not None:
             db += gb
-        return gx.to(x.dtype).contiguous()
+        return gx.to(x.dtype).contiguous() if want_dx else None
 
     # ---- attention
     def head_transpose(self, x, nseq, H, L, D):

@@ -131,3 +131,35 @@ def test_bf16_full_size_free_running(full):
     print(f"[full1 bf16 free-running] loss rel {rel:.2e}, grad-norm rel {gn_rel:.2e}, code agreement {agree:.4f}, "
           f"latent cosine image {cos_i:.5f} text {cos_t:.5f}")
     assert agree >= 0.95 and rel < 3e-2 and cos_t > 0.999
+
+
+def test_zz_side_stream_backward_is_bit_identical(full, tmp_path, monkeypatch):
+    """Inside the trainer's backward the weight-gradient GEMMs, the PEG weight gradient and the position-bias table gradient run on a
+    side stream under the grad-input chain (functional.wgrad_stream_begin).  Same kernels, same order of every sum: the flat gradient
+    buffer must be bit-identical to the single-stream backward (CTCLIP_WGRAD_STREAM=0), and so must the loss."""
+    import ct_clip_amd
+    g, clip, text, video = prepare(full, torch.bfloat16, True)
+    vq = clip.visual_transformer.vq._codebook
+    vq0 = (vq.embed.clone(), vq.cluster_size.clone())
+    data0 = {id(p): p.data for p in clip.parameters()}
+    trainer = ct_clip_amd.CTClipTrainer(clip, num_train_steps=1, batch_size=2, tokenizer=object(), lr=1e-6, train_dataset=[0], evaluate=False,
+                                        checkpoint=False, results_folder=str(tmp_path), num_workers=0)
+    try:
+        out = []
+        for mode in ("0", "1", "1"):
+            monkeypatch.setenv("CTCLIP_WGRAD_STREAM", mode)
+            trainer.optim.zero_grad()
+            vq.embed.copy_(vq0[0]); vq.cluster_size.copy_(vq0[1])      # the forward's EMA update must not carry over
+            loss = trainer.forward_backward(video, text)
+            torch.cuda.synchronize()
+            out.append((float(loss), trainer.optim.flat_grad.clone()))
+        assert out[0][0] == out[1][0] == out[2][0]
+        assert float(out[0][1].abs().max()) > 0
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[1][1], out[2][1])
+    finally:      # the module-scoped model goes back to ordinary parameters for whoever uses the fixture next
+        for p in clip.parameters():
+            p.__dict__.pop("_ctclip_grad_sink", None)
+            p.grad = None
+            if id(p) in data0:
+                p.data = data0[id(p)]
+        vq.embed.copy_(vq0[0]); vq.cluster_size.copy_(vq0[1])

@@ -711,3 +711,17 @@ def test_batched_shadow_refresh(hip):
     geglu_weight_interleave make one by one (the CPU twin of this test runs the same check against the torch restatement)."""
     from tests.test_host_logic_cpu import check_batched_shadow_refresh
     check_batched_shadow_refresh(torch.device(DEV))
+
+
+def test_peg_bwd_split_halves(hip):
+    """ctclip_peg_bwd with dx = NULL (weight / bias gradient only) and with dw = NULL (grad-input only) give, together, exactly what
+    the single call gives (the trainer launches the two halves on different streams)."""
+    bf = torch.bfloat16
+    x, dy = rnd(2, 24, 24, 24, 512, dtype=bf, seed=1), rnd(2, 24, 24, 24, 512, dtype=bf, seed=2)
+    w = rnd(512, 27, seed=3, scale=0.2)
+    dw0, db0 = torch.zeros(512, 27, device=DEV), torch.zeros(512, device=DEV)
+    dx0 = hip.peg_bwd(dy, x, w, dw0, db0)
+    dw1, db1 = torch.zeros(512, 27, device=DEV), torch.zeros(512, device=DEV)
+    assert hip.peg_bwd(dy, x, w, dw1, db1, want_dx=False) is None
+    dx1 = hip.peg_bwd(dy, x, w, None, None)
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
