@@ -401,10 +401,12 @@ class FeedForwardFn(Function):
     CTCLIP_GEGLU_RECOMPUTE=1: u is not stored; the backward recomputes it (ctclip_gemm_geglu_bwd) from y after an ordinary dg GEMM."""
 
     @staticmethod
-    def forward(ctx, y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K):
+    def forward(ctx, y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd=True):
         be = B()
         recompute = os.environ.get("CTCLIP_GEGLU_RECOMPUTE", "0") == "1"
-        u, g = be.gemm_geglu(y, w_il, Hp, save_u=not recompute)
+        u, g = be.gemm_geglu(y, w_il, Hp, save_u=need_bwd and not recompute)      # inference / frozen towers: u is never read, not written
+        if not need_bwd:
+            return be.gemm(g, wsh_out, residual=residual)
         out = be.gemm(g, wsh_out, residual=residual)
         ctx.save_for_backward(y, g, wsh_in, wsh_out, w_il if recompute else u)
         ctx.recompute, ctx.has_res = recompute, residual is not None
@@ -430,7 +432,7 @@ class FeedForwardFn(Function):
         dw_in = weight_grad(du, y, ctx.w_in, segs, K) if ctx.w_in.requires_grad else None      # (weight-gradient stream: under the next GEMM)
         dy = be.gemm(du, transposed_shadow(ctx.w_in, wsh_in, segs)) if ctx.needs_input_grad[0] else None
         dres = dout if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dy, dw_in, dw_out, dres, None, None, None, None, None, None
+        return dy, dw_in, dw_out, dres, None, None, None, None, None, None, None
 
 
 def feed_forward(y, w_in, w_out, residual=None):
@@ -455,7 +457,9 @@ def feed_forward(y, w_in, w_out, residual=None):
     w_il = shadow(w_in, ("geglu_il", Hp), y.dtype, lambda: B().geglu_weight_interleave(w_in.detach(), Hp, y.dtype),
                   recipe=[(w_in, 0, 2 * Hp, K, MAP_GEGLU_INTERLEAVE, inner, False)])
     wsh_out = plain_shadow(w_out, y.dtype, kpad=Hp)
-    return FeedForwardFn.apply(y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K)
+    need_bwd = torch.is_grad_enabled() and (y.requires_grad or w_in.requires_grad or w_out.requires_grad or
+                                            (residual is not None and residual.requires_grad))
+    return FeedForwardFn.apply(y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd)
 
 
 def linear_geglu_out(g, weight, residual):

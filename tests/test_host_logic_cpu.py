@@ -195,6 +195,9 @@ def test_feed_forward_node_composition(ref_backend):
     assert torch.equal(rec[0], ref[0])
     for a, b in zip(rec[1:], ref[1:]):
         assert rel(a, b) < 6e-3, rel(a, b)
+    # inference (no_grad) takes the same launches but never writes u
+    with torch.no_grad():
+        assert torch.equal(Fn.feed_forward(y, w_in, w_out, residual=res), ref[0])
     # f32 (parity mode) and small token counts compose the separate pieces
     assert not type(Fn.feed_forward(y.float(), w_in, w_out, residual=res.float()).grad_fn).__name__.startswith("FeedForwardFn")
 
