@@ -56,6 +56,8 @@ SIGNATURES = {
     "ctclip_attn2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _I, _I, _I, _P]),
     "ctclip_attn2_bwd_workspace": (_L, [_I, _I, _I, _I, _I]),
     "ctclip_attn2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "ctclip_clip_loss_logits": (_I, [_P, _L, _P, _P, _P, _I, _P, _L, _P]),
+    "ctclip_l2norm_bwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "ctclip_attn2_bwd_dbias": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _P, _I, _I, _I, _P, _L, _P]),
     "ctclip_attn2_unprep_workspace": (_L, []),
     "ctclip_attn2_unprep": (_I, [_P] * 9 + [_F, _P, _P, _P, _L, _L, _L, _P, _P, _L, _I, _P, _L, _P]),

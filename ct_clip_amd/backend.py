@@ -668,10 +668,14 @@ class HipBackend:
             _lib.check(rc, "ctclip_visual_latent_bwd")
         return dx
 
+    CLIP_LOSS_ONE_BLOCK = 128      # gathered batch the single-block kernel serves (its G x G logits live in LDS)
+
     def clip_loss(self, tl, il, temperature, want_grads=True, want_logits=False):
         G, Dl = tl.shape
         assert tl.dtype == torch.float32 and il.dtype == torch.float32 and tl.is_contiguous() and il.is_contiguous()
         dev = tl.device
+        if G > self.CLIP_LOSS_ONE_BLOCK or Dl > 1024:
+            return self._clip_loss_large(tl, il, temperature, want_grads, want_logits)
         out = torch.empty(2, dtype=torch.float32, device=dev)
         logits = torch.empty((G, G), dtype=torch.float32, device=dev) if want_logits else None
         dtl = torch.empty_like(tl) if want_grads else None
@@ -680,6 +684,32 @@ class HipBackend:
         rc = self.lib.ctclip_clip_loss(_p(tl), _p(il), _p(temperature), _p(out), _p(logits), _p(dtl), _p(dil), _p(dtemp), G, Dl,
                                        _stream())
         _lib.check(rc, "ctclip_clip_loss")
+        return out, logits, dtl, dil, dtemp
+
+    def _clip_loss_large(self, tl, il, temperature, want_grads, want_logits):
+        """Any gathered batch: logits and their gradient in global memory, f32 GEMMs around ctclip_clip_loss_logits (csrc/head.hip)."""
+        G, Dl = tl.shape
+        dev = tl.device
+        ut, tinv = self.l2norm_rows(tl, torch.float32, eps=1e-12)
+        uv, iinv = self.l2norm_rows(il, torch.float32, eps=1e-12)
+        Gp = (G + 3) // 4 * 4                    # 16-byte aligned rows: S is a k-contiguous operand of the gradient GEMMs
+        S = torch.zeros((G, Gp), dtype=torch.float32, device=dev)[:, :G]
+        self.gemm(ut, uv, out=S)                 # (G, G) f32 cosines; exp(temperature) is applied on the device
+        logits = S.clone() if want_logits else None
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        dtemp = torch.zeros(1, dtype=torch.float32, device=dev) if want_grads else None
+        ws = torch.empty(4 * G, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.ctclip_clip_loss_logits(_p(S), S.stride(0), _p(temperature), _p(out), _p(dtemp), G, _p(ws), ws.numel() * 4, _stream()),
+                   "ctclip_clip_loss_logits")
+        if logits is not None:
+            self.scale_by_scalar(logits, out[1:2])
+        if not want_grads:
+            return out, logits, None, None, None
+        dut = self.gemm(S, uv, a_kc=True, b_kc=False)                              # (temp dS) Uv
+        duv = self.gemm(S, ut, a_kc=False, b_kc=False, M=G, N=Dl, K=G)             # (temp dS)^T Ut
+        dtl, dil = torch.empty_like(tl), torch.empty_like(il)
+        for raw, inv, du, dst in ((tl, tinv, dut, dtl), (il, iinv, duv, dil)):
+            _lib.check(self.lib.ctclip_l2norm_bwd_rows(_p(raw), _p(inv), _p(du), _p(dst), G, Dl, _stream()), "ctclip_l2norm_bwd_rows")
         return out, logits, dtl, dil, dtemp
 
     def scale_by_scalar(self, x, scalar):

@@ -228,6 +228,72 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------- CLIP loss, any G (logits in global memory)
+// The single-block kernel above keeps the G x G logits in LDS (G <= 128 = 16 ranks x batch 8).  Larger gathered batches run as a few
+// launches around the f32 GEMMs the host issues: S = temp * Ut Uv^T (ctclip_gemm), then the kernels below, then dUt = temp dS Uv,
+// dUv = temp dS^T Ut (ctclip_gemm) and the l2norm backward.  Every sum has a fixed order.
+// rsum[i] = sum_j exp(S_ij) (one wave per row); csum[j] = sum_i exp(S_ij) (one thread per column, coalesced across the block)
+__global__ __launch_bounds__(256) void clip_rowcol_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ temperature, int G,
+                                                          float* __restrict__ rsum, float* __restrict__ csum) {
+  const int nrowblocks = (G + 3) / 4;
+  const float temp = __expf(temperature[0]);
+  if ((int)blockIdx.x < nrowblocks) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= G) return;
+    float s = 0.f;
+    for (int j = lane; j < G; j += 64) s += __expf(S[(int64_t)i * ld + j] * temp);
+    s = wave_sum(s);
+    if (lane == 0) rsum[i] = s;
+  } else {
+    const int j = (blockIdx.x - nrowblocks) * 256 + threadIdx.x;
+    if (j >= G) return;
+    float s = 0.f;
+    for (int i = 0; i < G; ++i) s += __expf(S[(int64_t)i * ld + j] * temp);
+    csum[j] = s;
+  }
+}
+// S (cosines) -> temp * d loss / d logits in place (the factor the latent gradients carry); per row: loss term and sum_j dS_ij logit_ij
+// (for d temperature).  One wave per row.
+__global__ __launch_bounds__(256) void clip_ds_kernel(float* __restrict__ S, int64_t ld, const float* __restrict__ temperature, int G, const float* __restrict__ rsum,
+                                                      const float* __restrict__ csum, float* __restrict__ row_loss, float* __restrict__ row_dth) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= G) return;
+  const float temp = __expf(temperature[0]);
+  const float eps = 1e-20f, ri = rsum[i] + eps, inv2g = 1.f / (2.f * G);
+  float dth = 0.f, diag = 0.f;
+  for (int j = lane; j < G; j += 64) {
+    const float sv = S[(int64_t)i * ld + j] * temp, e = __expf(sv);
+    float d = e / ri + e / (csum[j] + eps);
+    if (i == j) { d -= 2.f * e / (e + eps); diag = e; }
+    d *= inv2g;
+    dth += d * sv;
+    S[(int64_t)i * ld + j] = d * temp;
+  }
+  dth = wave_sum(dth); diag = wave_sum(diag);
+  if (lane == 0) { row_dth[i] = dth; row_loss[i] = -2.f * __logf(diag + eps) + __logf(ri) + __logf(csum[i] + eps); }
+}
+__global__ __launch_bounds__(256) void clip_final_kernel(const float* __restrict__ row_loss, const float* __restrict__ row_dth, int G,
+                                                         const float* __restrict__ temperature, float* __restrict__ out, float* __restrict__ dtemp) {
+  __shared__ float red[16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < G; i += 256) { a += row_loss[i]; b += row_dth[i]; }
+  const float ta = block_sum(a, red);
+  __syncthreads();
+  const float tb = block_sum(b, red);
+  if (threadIdx.x == 0) { out[0] = ta / (2.f * G); out[1] = __expf(temperature[0]); if (dtemp) dtemp[0] += tb; }
+}
+// d raw = inv * (du - u <u, du>), u = raw * inv (backward of F.normalize).  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_bwd_rows_kernel(const float* __restrict__ raw, const float* __restrict__ inv, const float* __restrict__ du,
+                                                              float* __restrict__ out, int rows, int cols) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float iv = inv[r];
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += raw[(int64_t)r * cols + c] * iv * du[(int64_t)r * cols + c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) out[(int64_t)r * cols + c] = iv * (du[(int64_t)r * cols + c] - raw[(int64_t)r * cols + c] * iv * dot);
+}
+
 __global__ __launch_bounds__(256) void accumulate_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 a = reinterpret_cast<f32x4*>(dst)[i];
@@ -281,7 +347,8 @@ extern "C" int ctclip_visual_latent_bwd(const float* dY, const void* X, const vo
   else return CTCLIP_EUNSUPPORTED;
   return ctclip_check_launch("visual_latent_bwd");
 }
-// CLIP symmetric InfoNCE forward + backward.  G <= 128, Dl <= 1024.  out: [loss, exp(temperature)].
+// CLIP symmetric InfoNCE forward + backward in ONE launch.  G <= 128, Dl <= 1024 (the G x G logits live in LDS: 16 ranks x batch 8);
+// larger gathered batches: ctclip_clip_loss_logits between f32 ctclip_gemm launches (backend._clip_loss_large).  out: [loss, exp(temperature)].
 extern "C" int ctclip_clip_loss(const float* text_latents, const float* image_latents, const float* temperature, float* out, float* logits,
                                 float* d_text, float* d_image, float* d_temperature, int G, int Dl, hipStream_t s) {
   if (!text_latents || !image_latents || !temperature || !out || G < 1 || G > 128 || Dl > 1024) { ctclip_set_error("clip_loss: G <= 128 and Dl <= 1024 required"); return CTCLIP_EBADARG; }
@@ -292,6 +359,26 @@ extern "C" int ctclip_clip_loss(const float* text_latents, const float* image_la
   }
   hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(256), shm, s, text_latents, image_latents, temperature, out, logits, d_text, d_image, d_temperature, G, Dl);
   return ctclip_check_launch("clip_loss");
+}
+// The middle of the CLIP loss for ANY gathered batch size (ct_clip.py:845-901 with G = world size x batch beyond the single-block
+// kernel's 128): S (G, G) f32 holds the cosines <u_t, u_v> of the l2-normalised latents on entry (the host's f32 ctclip_gemm) and
+// exp(temperature) * d loss / d logits on return (the factor both latent-gradient GEMMs need); out = [loss, exp(temperature)];
+// d_temperature (+=) = sum dS * logits.  lds = row stride of S in elements (>= G; a multiple of 4 keeps the rows 16-byte aligned for the
+// GEMMs).  workspace >= 4 * G floats.
+extern "C" int ctclip_clip_loss_logits(float* S, int64_t lds, const float* temperature, float* out, float* d_temperature, int G, float* workspace,
+                                       int64_t workspace_bytes, hipStream_t s) {
+  if (!S || lds < G || !temperature || !out || G < 1 || !workspace || workspace_bytes < (int64_t)4 * G * 4) { ctclip_set_error("clip_loss_logits: bad args / workspace < 16 G bytes"); return CTCLIP_EBADARG; }
+  float *rsum = workspace, *csum = rsum + G, *row_loss = csum + G, *row_dth = row_loss + G;
+  hipLaunchKernelGGL(clip_rowcol_kernel, dim3((unsigned)((G + 3) / 4 + (G + 255) / 256)), dim3(256), 0, s, S, lds, temperature, G, rsum, csum);
+  hipLaunchKernelGGL(clip_ds_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, s, S, lds, temperature, G, rsum, csum, row_loss, row_dth);
+  hipLaunchKernelGGL(clip_final_kernel, dim3(1), dim3(256), 0, s, row_loss, row_dth, G, temperature, out, d_temperature);
+  return ctclip_check_launch("clip_loss_logits");
+}
+// Backward of F.normalize on rows (ct_clip.py:49-50,771): out = inv * (du - u <u, du>) with u = raw * inv; all f32, (rows, cols) contiguous.
+extern "C" int ctclip_l2norm_bwd_rows(const float* raw, const float* inv, const float* du, float* out, int rows, int cols, hipStream_t s) {
+  if (!raw || !inv || !du || !out || rows < 1 || cols < 1) { ctclip_set_error("l2norm_bwd_rows: bad args"); return CTCLIP_EBADARG; }
+  hipLaunchKernelGGL(l2norm_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, raw, inv, du, out, rows, cols);
+  return ctclip_check_launch("l2norm_bwd_rows");
 }
 // dst[i] += src[i] (f32, n % 4 == 0, 16-byte aligned): row blocks of a stacked weight gradient into the flat gradient buffer
 extern "C" int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s) {

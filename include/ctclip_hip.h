@@ -146,6 +146,12 @@ int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void
 /* l2norm + logits*exp(temperature) + symmetric InfoNCE, forward and backward (ct_clip.py:771,796,845-901). */
 int ctclip_clip_loss(const float* text_latents, const float* image_latents, const float* temperature, float* out, float* logits, float* d_text, float* d_image, float* d_temperature, int G, int Dl, hipStream_t s);
 
+/* The middle of the CLIP loss for ANY gathered batch size (ct_clip.py:845-901 with G = world size x batch beyond the 128 pairs ctclip_clip_loss keeps in LDS): S (G, G) f32 holds the cosines <u_t, u_v> of the l2-normalised latents on entry (f32 ctclip_gemm) and exp(temperature) * d loss / d logits on return (the factor both latent-gradient GEMMs need); out = [loss, exp(temperature)]; d_temperature (+=) = sum dS * logits.  workspace >= 16 * G bytes.  Fixed summation order. */
+int ctclip_clip_loss_logits(float* S, int64_t lds, const float* temperature, float* out, float* d_temperature, int G, float* workspace, int64_t workspace_bytes, hipStream_t s);
+
+/* Backward of F.normalize on rows (ct_clip.py:49-50,771): out = inv * (du - u <u, du>) with u = raw * inv; all f32, (rows, cols) contiguous. */
+int ctclip_l2norm_bwd_rows(const float* raw, const float* inv, const float* du, float* out, int rows, int cols, hipStream_t s);
+
 /* dst[i] += src[i] over n f32 values (n % 4 == 0, 16-byte aligned): the row blocks of a stacked weight gradient (one GEMM over [x | gate]) added into the flat gradient buffer. */
 int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s);
 

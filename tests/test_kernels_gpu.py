@@ -725,3 +725,23 @@ def test_peg_bwd_split_halves(hip):
     assert hip.peg_bwd(dy, x, w, dw1, db1, want_dx=False) is None
     dx1 = hip.peg_bwd(dy, x, w, None, None)
     assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+
+
+@pytest.mark.parametrize("G,Dl", [(200, 512), (513, 64), (64, 512)])
+def test_clip_loss_any_batch(hip, ref, monkeypatch, G, Dl):
+    """ct_clip.py:771-901 beyond the single-block kernel's 128 pairs (16 ranks x batch 8): logits and their gradient in global memory,
+    f32 GEMMs around ctclip_clip_loss_logits, l2norm backward -- against the checker; at G = 64 the two paths against each other."""
+    tl, il = rnd(G, Dl, seed=1), rnd(G, Dl, seed=2)
+    temp = torch.tensor([1.3], device=DEV)
+    want = ref.clip_loss(tl, il, temp, want_logits=True)
+    if G <= 128:
+        small = hip.clip_loss(tl, il, temp, want_logits=True)
+        monkeypatch.setattr(type(hip), "CLIP_LOSS_ONE_BLOCK", 0)
+    got = hip.clip_loss(tl, il, temp, want_logits=True)
+    for a, b, name in zip(got, want, ("out", "logits", "dtl", "dil", "dtemp")):
+        close(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-6 if name in ("dtl", "dil") else 2e-5)
+    if G <= 128:
+        for a, b in zip(got, small):
+            close(a.reshape(-1), b.reshape(-1), rtol=2e-4, atol=2e-6)
+    out2 = hip.clip_loss(tl, il, temp, want_grads=False)
+    assert out2[2] is None and torch.equal(out2[0], got[0])
