@@ -146,8 +146,8 @@ class GradReducer:
             self.launched.append((s, e))
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(evt)
-                for e in (wg_evts or ()):
-                    self.comm_stream.wait_event(e)
+                for wev in (wg_evts or ()):
+                    self.comm_stream.wait_event(wev)
                 with torch.cuda.stream(self.comm_stream):
                     self._reduce_slice(s, e)
             else:
