@@ -79,7 +79,7 @@ class CTCLIP(nn.Module):
             return None
         st = self.__dict__.get("_side_stream")
         if st is None:
-            st = torch.cuda.Stream(device=device)
+            st = Fn.register_side_stream(torch.cuda.Stream(device=device))      # (the fused optimiser joins it before reading gradients)
             self.__dict__["_side_stream"] = st
         return st
 

@@ -172,6 +172,9 @@ class GradReducer:
         W = world_size()
         if W == 1:
             return
+        if self.comm_stream is not None:
+            from . import functional as Fn
+            Fn.join_side_streams()      # gradients written from the text tower's stream: the events below are recorded on the current stream
         for seg in self.pending:
             self._launch(seg[0], seg[1])
         self.pending = []

@@ -139,6 +139,23 @@ def _split_k_for(n_rows, n_cols, K, dtype):
     return max(1, min(ktiles, 1024 // max(tiles, 1)))
 
 
+# ---- side streams whose kernels write parameter gradients straight into the flat gradient buffer (the text tower's stream): autograd's
+# end-of-backward synchronisation only covers gradients it accumulates itself, so the optimiser joins these explicitly.
+_SIDE_STREAMS = []
+
+
+def register_side_stream(st):
+    if all(st is not x for x in _SIDE_STREAMS):
+        _SIDE_STREAMS.append(st)
+    return st
+
+
+def join_side_streams():
+    """The current stream of each device waits for every registered side stream of that device."""
+    for st in _SIDE_STREAMS:
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
 # ---- weight-gradient stream.  dW = dy^T x is a leaf of the backward graph: nothing downstream of it runs before the optimiser (or the
 # gradient all-reduce of its bucket).  Between wgrad_stream_begin() and wgrad_stream_end() (the trainer brackets loss.backward() with
 # them) the big split-K GEMMs that write into the flat gradient buffer are launched on a side stream, UNDER the grad-input GEMMs of the

@@ -107,6 +107,8 @@ class FusedAdam:
     def step(self, max_grad_norm=None, extra_sq=None):
         be = _be.get()
         self.step_count += 1
+        # the text tower's backward writes its gradients into the flat buffer from its own stream; autograd never saw them
+        Fn.join_side_streams()
         clip = be.grad_norm_clip(self.flat_grad, max_grad_norm or 0.0, extra_sq)
         self.last_norm = clip
         self.lr = self.param_groups[0]["lr"]          # learning-rate schedules write param_groups (finetune.cosine_lr)
