@@ -51,7 +51,12 @@
 #define NT_DG_ROWS 2         // rows of u in flight per lane in the out-projection grad-input + GEGLU backward epilogue (1, 2 or 4)
 #endif
 #ifndef NT_COUNTED_EPI
-#define NT_COUNTED_EPI 1     // 1 = the first step of a tile waits for its panels only, not for the previous tile's epilogue stores
+// 1 = the first step of a tile waits with vmcnt(GL + n) for its panels only, not for the previous tile's epilogue stores (n = the VMEM
+// instructions of that epilogue).  Measured +1..3 % on the GEMMs (profiles/r02_gemm_epilogue_experiments.md) and bit-identical results in
+// 60 of 60 full-geometry training steps -- but it needs loads and stores to RETIRE IN ISSUE ORDER RELATIVE TO EACH OTHER (the panels it
+// waits for are OLDER than the stores it no longer waits for), which the old vmcnt(GL) does not.  OFF until that order is settled (a rare
+// run-to-run difference of the bf16 step is open).
+#define NT_COUNTED_EPI 0
 #endif
 
 namespace {
