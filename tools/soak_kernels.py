@@ -1,0 +1,115 @@
+"""Bit-reproducibility soak of the hot kernels: every kernel is launched REPS times on the same inputs and a checksum of all its outputs is
+compared with the first launch's.  A kernel with a timing-dependent race (a counted vmcnt that is one too generous, a missing barrier, an
+LDS-DMA prefetch overtaking a store) shows up as a handful of deviating launches out of thousands; a deterministic kernel never deviates.
+Written for DESIGN.md section 8 item 7 (a rare run-to-run difference of the bf16 training step).
+
+usage: python tools/soak_kernels.py [reps] [kernel-name-substring]      shapes = the bench shapes (B = 8 volumes, 12+12 layers irrelevant)
+       CTCLIP_LIB=ct_clip_amd/libctclip_<abl>.so python tools/soak_kernels.py ...      (ablation builds of tools/build_ablation.py)
+A second stream keeps the chip busy with an unrelated GEMM while the kernel under test runs (SOAK_NOISE=0 switches that off): races hide on
+an idle chip."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from ct_clip_amd import backend  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+be = backend.get()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev).manual_seed(0)
+bf = torch.bfloat16
+
+
+def rnd(*sh, scale=1.0, dtype=bf):
+    return ((torch.rand(*sh, device=dev, generator=gen) * 2 - 1) * scale).to(dtype)
+
+
+def checksum(outs):
+    """order-sensitive 64-bit checksum of the raw bits of every output tensor"""
+    acc = 0
+    for t in outs:
+        if t is None:
+            continue
+        raw = t.detach().contiguous().view(torch.uint8)
+        n = raw.numel() // 8 * 8
+        w = raw[:n].view(torch.int64)
+        idx = torch.arange(1, w.numel() + 1, device=dev, dtype=torch.int64)
+        acc = (acc * 1000003 + int((w * (idx | 1)).sum().item()) + int(raw[n:].to(torch.int64).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return acc
+
+
+noise_stream = torch.cuda.Stream(device=dev)
+na, nb = rnd(8192, 2048), rnd(4096, 2048)
+
+
+def soak(name, fn):
+    if only and only not in name:
+        return
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ref = checksum(fn())
+    bad = 0
+    for i in range(reps):
+        if os.environ.get("SOAK_NOISE", "1") != "0":
+            with torch.cuda.stream(noise_stream):
+                be.gemm(na, nb)
+        outs = fn()
+        torch.cuda.synchronize()
+        if checksum(outs) != ref:
+            bad += 1
+    print(f"{name:60s} {reps} launches, {bad} deviating", flush=True)
+
+
+def as_list(x):
+    return list(x) if isinstance(x, (tuple, list)) else [x]
+
+
+M, D = 110592, 512
+# ---- GEMMs (csrc/gemm_nt.hip, gemm_tn.hip)
+x512, w_q, w_kv, w_ffout = rnd(M, 512), rnd(256, 512, scale=0.05), rnd(512, 512, scale=0.05), rnd(512, 1408, scale=0.03)
+res = rnd(M, 512)
+g1408 = rnd(M, 1408)
+soak("gemm NT to_q (N=256, K=512)", lambda: [be.gemm(x512, w_q)])
+soak("gemm NT to_kv (N=512, K=512)", lambda: [be.gemm(x512, w_kv)])
+soak("gemm NT ff_out + residual (N=512, K=1408)", lambda: [be.gemm(g1408, w_ffout, residual=res)])
+w32 = (torch.rand(2730, 512, device=dev, generator=gen) * 2 - 1) * 0.05
+w_il = be.geglu_weight_interleave(w32, 1408, bf)
+soak("gemm NT in-projection + GEGLU (u, g)", lambda: as_list(be.gemm_geglu(x512, w_il, 1408)))
+u, _ = be.gemm_geglu(x512, w_il, 1408)
+wt_out = rnd(1408, 512, scale=0.03)
+soak("gemm NT out-projection grad-input + GEGLU backward", lambda: [be.gemm_dgeglu(x512, wt_out, u)])
+du = be.gemm_dgeglu(x512, wt_out, u)
+w_in_t = rnd(512, 2816, scale=0.02)
+soak("gemm NT in-projection grad-input (K=2816)", lambda: [be.gemm(du, w_in_t)])
+dw = torch.zeros(2816, 512, device=dev)
+soak("gemm TN weight gradient (M=2816, N=512, K=110592)",
+     lambda: [be.gemm(du, x512, a_kc=False, b_kc=False, out=dw.zero_(), accumulate=True, split_k=0, M=2816, N=512, K=M)])
+# ---- vector-quantiser code search (arg-max epilogue)
+xs, es = be.l2norm_split3(rnd(M, 512, dtype=torch.float32), 0)[0], be.l2norm_split3(rnd(8192, 512, dtype=torch.float32), 1)[0]
+soak("gemm_argmax (110592 x 8192 x 1536)", lambda: as_list(be.gemm_argmax(xs, es)))
+# ---- LayerNorm, PEG
+gamma, beta = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev)
+soak("layernorm_fwd", lambda: as_list(be.layernorm_fwd(x512, gamma, beta, 1e-5)))
+x5, w27, b27 = rnd(8, 24, 24, 24, 512), rnd(512, 27, scale=0.2, dtype=torch.float32), rnd(512, dtype=torch.float32)
+soak("peg_fwd", lambda: [be.peg_fwd(x5, w27, b27)])
+dw27, db27 = torch.zeros(512, 27, device=dev), torch.zeros(512, device=dev)
+soak("peg_bwd (grad-input + weight gradient)", lambda: [be.peg_bwd(x5, x5, w27, dw27.zero_(), db27.zero_()), dw27, db27])
+# ---- spatial attention (csrc/attn2*.hip): 192 sequences x 576 tokens, 8 heads x 32, position-bias table 47 x 47
+nseq, L, H, Dh = 192, 576, 8, 32
+q, kv = rnd(nseq * L, 256), rnd(nseq * L, 512)
+qs, ks = torch.rand(Dh, device=dev) + 0.5, torch.rand(Dh, device=dev) + 0.5
+tab = rnd(47 * 47, H, scale=0.5, dtype=torch.float32)
+qh, kh, vh, qinv, kinv = be.attn2_prep(q, kv[:, :256], kv[:, 256:], qs, ks, 8.0, H)
+soak("attn2_prep", lambda: as_list(be.attn2_prep(q, kv[:, :256], kv[:, 256:], qs, ks, 8.0, H)))
+soak("attn2_fwd (slab)", lambda: as_list(be.attn2_fwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, nseq, L)))
+o, lse2 = be.attn2_fwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, nseq, L)
+do = rnd(nseq * L, 256, scale=0.1)
+soak("attn2_bwd (dq, dkv, dbias)", lambda: as_list(be.attn2_bwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, nseq, L, True)))
+# ---- temporal attention (csrc/attn_short.hip): 4608 sequences x 24 tokens
+nseq_t, L_t = 4608, 24
+soak("attn_short_fwd", lambda: [be.attn_short_fwd(q, kv, qs, ks, nseq_t, L_t, H, 8.0)])
+dqs, dks = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
+soak("attn_short_bwd", lambda: as_list(be.attn_short_bwd(q, kv, qs, ks, do, nseq_t, L_t, H, 8.0, dqs.zero_(), dks.zero_())) + [dqs, dks])
