@@ -35,6 +35,32 @@ def _rowmajor(t, what):
     return t.stride(0)
 
 
+def price_gemm_group(key, ms, peak_tflops=2500.0, peak_gbps=8000.0):
+    """One GEMM launch group of the per-launch timing (key = (layout, dtype, M, N, K, side stream[, fused variant]), ms = event times)
+    against both floors: algorithmic FLOPs / dense MFMA peak and algorithmic bytes / HBM peak; the larger floor names the bound."""
+    layout, dt, M, N, K, side = key[:6]
+    variant = key[6] if len(key) > 6 else ""       # fused GEGLU launches: forward (u and / or g written), backward
+    flops = 2.0 * M * N * K
+    esz = 2 if dt == "bf16" else 4
+    nbytes = float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))
+    if variant == "+geglu":
+        nbytes += M * (N // 2) * esz                       # u and g
+    elif variant == "+geglu(g only)":
+        nbytes = float((M * K + N * K + M * (N // 2)) * esz)
+    elif variant == "geglu-bwd recompute":
+        nbytes += M * (N // 2) * esz                       # dg read, du written
+    elif variant == "+geglu-bwd":
+        nbytes = float((M * K + N * K + 4 * M * N) * esz)  # dy, W_out^T, u = [x | gate] read, du written (N = hp)
+    avg_us = sum(ms) / len(ms) * 1e3
+    peak_tf = peak_tflops if dt == "bf16" else 157.3
+    t_mfma, t_hbm = flops / (peak_tf * 1e12) * 1e6, nbytes / (peak_gbps * 1e9) * 1e6
+    return dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}" + (f" [{variant}]" if variant else ""), launches=len(ms),
+                side_stream=side, avg_us=avg_us, total_ms=sum(ms), flops_per_launch=flops, bytes_per_launch=nbytes,
+                tflops=flops / (avg_us * 1e-6) / 1e12, gbps=nbytes / (avg_us * 1e-6) / 1e9, peak_tflops=peak_tf,
+                bound="mfma" if t_mfma >= t_hbm else "hbm", frac=max(t_mfma, t_hbm) / avg_us,
+                spec=f"{layout} {M} {N} {K} {variant.replace(' ', '_') or '-'}")
+
+
 class HipBackend:
     name = "hip"
 
@@ -55,30 +81,7 @@ class HipBackend:
         the fused launches (GEGLU epilogues) move 1.0-1.4 GB per launch and are HBM-bound, the plain feed-forward GEMMs MFMA-bound."""
         ev, self._gemm_events = self._gemm_events, None
         torch.cuda.synchronize()
-        groups = []
-        for key, pairs in ev.items():
-            ms = [a.elapsed_time(b) for a, b in pairs]
-            layout, dt, M, N, K, side = key[:6]
-            variant = key[6] if len(key) > 6 else ""       # fused GEGLU launches: forward (u and / or g written), backward
-            flops = 2.0 * M * N * K
-            esz = 2 if dt == "bf16" else 4
-            nbytes = float((M * K + N * K) * esz + M * N * (4 if layout == "TN" else esz))
-            if variant == "+geglu":
-                nbytes += M * (N // 2) * esz                       # u and g
-            elif variant == "+geglu(g only)":
-                nbytes = float((M * K + N * K + M * (N // 2)) * esz)
-            elif variant == "geglu-bwd recompute":
-                nbytes += M * (N // 2) * esz                       # dg read, du written
-            elif variant == "+geglu-bwd":
-                nbytes = float((M * K + N * K + 4 * M * N) * esz)  # dy, W_out^T, u = [x | gate] read, du written (N = hp)
-            avg_us = sum(ms) / len(ms) * 1e3
-            peak_tf = peak_tflops if dt == "bf16" else 157.3
-            t_mfma, t_hbm = flops / (peak_tf * 1e12) * 1e6, nbytes / (peak_gbps * 1e9) * 1e6
-            groups.append(dict(kernel=f"gemm_kernel<{dt},{layout}> M={M} N={N} K={K}" + (f" [{variant}]" if variant else ""), launches=len(ms),
-                               side_stream=side, avg_us=avg_us, total_ms=sum(ms), flops_per_launch=flops, bytes_per_launch=nbytes,
-                               tflops=flops / (avg_us * 1e-6) / 1e12, gbps=nbytes / (avg_us * 1e-6) / 1e9, peak_tflops=peak_tf,
-                               bound="mfma" if t_mfma >= t_hbm else "hbm", frac=max(t_mfma, t_hbm) / avg_us,
-                               spec=f"{layout} {M} {N} {K} {variant.replace(' ', '_') or '-'}"))
+        groups = [price_gemm_group(key, [a.elapsed_time(b) for a, b in pairs], peak_tflops, peak_gbps) for key, pairs in ev.items()]
         # launches on the text tower's side stream wait for the image tower's kernels between their two events: their event time is
         # not kernel time, so the dominant kernel is picked among the launches of the main stream
         groups.sort(key=lambda g: (g["side_stream"], -g["total_ms"]))

@@ -261,3 +261,21 @@ def check_batched_shadow_refresh(dev):
 
 def test_batched_shadow_refresh_matches_lazy_makers(ref_backend):
     check_batched_shadow_refresh(torch.device("cpu"))
+
+
+def test_roofline_pricing_of_gemm_launch_groups():
+    """bench.py's roofline object: every GEMM launch group is priced against both floors (backend.price_gemm_group); the numbers of the
+    committed round-2 bench line (profiles/r02_bench_default_1gpu.json) reproduce from the shapes alone."""
+    from ct_clip_amd.backend import price_gemm_group
+    M = 110592
+    plain = price_gemm_group(("NT", "bf16", M, 512, 2816, False), [0.2812])                     # in-projection grad-input: MFMA-bound
+    assert plain["bound"] == "mfma" and abs(plain["tflops"] - 1134.0) < 2 and abs(plain["frac"] - 0.4536) < 2e-3
+    fused = price_gemm_group(("NT", "bf16", M, 2816, 512, False, "+geglu"), [0.3286])          # u and g written: 1.05 GB, HBM-bound
+    assert fused["bound"] == "hbm" and fused["bytes_per_launch"] == (M * 512 + 2816 * 512 + M * 2816 + M * 1408) * 2
+    assert abs(fused["gbps"] - 3196.6) < 5 and abs(fused["frac"] - 0.3996) < 2e-3 and fused["spec"] == "NT 110592 2816 512 +geglu"
+    bwd = price_gemm_group(("NT", "bf16", M, 1408, 512, False, "+geglu-bwd"), [0.3295, 0.3295])  # dy, W^T, u read; du written: 1.36 GB
+    assert bwd["bound"] == "hbm" and bwd["launches"] == 2 and abs(bwd["gbps"] - 4128.9) < 5 and abs(bwd["frac"] - 0.516) < 2e-3
+    wgrad = price_gemm_group(("TN", "bf16", 2773, 512, M, True), [0.267])                      # f32 result; launched on a side stream
+    assert wgrad["bound"] == "mfma" and wgrad["side_stream"] and abs(wgrad["tflops"] - 1176.1) < 2
+    f32 = price_gemm_group(("NT", "f32", 1024, 1024, 1024, False), [0.1])
+    assert f32["peak_tflops"] == 157.3
