@@ -313,6 +313,21 @@ def attention_block_util(args, device, dtype, iters=10):
                                        "(once per forward for all layers) is outside")
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: run this same command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and pass the ranks'
+    output through (rank 0 prints the one JSON line).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,10 +362,13 @@ def main():
         gemm_probe(args.gemm_probe)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (rank 0 prints the line)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # CTCLIP_BENCH_BACKEND=gloo CTCLIP_BENCH_SINGLE_DEVICE=1: rehearsal of the multi-rank code path on a ONE-GPU box (all ranks on
     # cuda:0, collectives staged through the host) -- used to check the N > 1 path where no multi-GPU node is available
     backend_name = os.environ.get("CTCLIP_BENCH_BACKEND", "nccl")

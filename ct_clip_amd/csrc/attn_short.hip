@@ -98,8 +98,22 @@ __device__ __forceinline__ void tile_store(const char* tile, bf16_t* seq_base, i
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
   }
 }
-template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }   // vmcnt(N) only
-__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }   // lgkmcnt(0) only
+#ifndef STRICT_VMCNT
+#define STRICT_VMCNT 0      // 1 = every counted vmcnt wait becomes vmcnt(0) (determinism bisection builds, tools/trace_determinism.py)
+#endif
+// vmcnt(M) only.  An asm statement with a memory clobber, not the s_waitcnt builtin: the optimiser may move the builtin across LDS reads
+// (see rows_landed below)
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STRICT_VMCNT ? 0 : N) : "memory"); }
+// "The tile reads have returned": lgkmcnt(0) as an asm statement that CARRIES the rows and clobbers memory.  The next instruction after it
+// is the LDS-DMA of the wave's next problem INTO THE SAME TILES (write after read).  The first version was the bare builtin
+// __builtin_amdgcn_s_waitcnt(0xC07F): hipcc sank it below the conditional fetch block (the builtin touches no memory as far as the
+// optimiser knows), so in the steady-state loop the DMA was issued with the four ds_reads of q / k still in flight.  Almost always
+// harmless -- the reads return in ~100 cycles, the DMA needs an L2 round trip -- but about one problem in 10^7 read the NEXT problem's
+// bytes: the rare run-to-run difference of the bf16 step in rounds 1-2 (located with tools/trace_determinism.py,
+// profiles/r03_determinism.md).  Operands pin the loads in front of the wait, the memory clobber pins the DMA behind it.
+__device__ __forceinline__ void rows_landed(Row& a, Row& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]) :: "memory");
+}
 
 // Transposed fragment of a tile: MFMA row m = lane & 31 is head dim m, contraction slot (t, i) is token 8 (2t + i/4) + 4 half + i%4.
 // ds_read_b64_tr_b16 (measured, tools/tr_probe.hip): in each 16-lane group, output lane i element j = element i & 3 of the 8 bytes
@@ -196,8 +210,8 @@ __global__ __launch_bounds__(WPB_F * 64) void attn_short_fwd_kernel(ShortParams 
     const int64_t s = it / p.H; const int h = (int)(it % p.H);
     if (first) wait_vm<0>(); else wait_vm<2>();
     first = false;
-    const Row rq = tile_read(tq, row, half), rk = tile_read(tk, row, half);
-    wait_lds();
+    Row rq = tile_read(tq, row, half), rk = tile_read(tk, row, half);
+    rows_landed(rq, rk);
     if (it + stride < nitems) fetch(it + stride, vb ^ 1);
     float xn[16], inv;
     const Frag Qt = frag_of(norm_row(rq, sq, p.scale * LOG2E, xn, inv));
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(WPB_B * 64, 2) void attn_short_bwd_kernel(ShortPara
     const int64_t s = it / p.H; const int h = (int)(it % p.H);
     if (first) wait_vm<0>(); else wait_vm<6>();
     first = false;
-    const Row rq = tile_read(rawq, row, half), rk = tile_read(rawk, row, half), rv = tile_read(rawv, row, half), rdo = tile_read(rawdo, row, half);
-    wait_lds();
+    Row rq = tile_read(rawq, row, half), rk = tile_read(rawk, row, half), rv = tile_read(rawv, row, half), rdo = tile_read(rawdo, row, half);
+    rows_landed(rq, rk); rows_landed(rv, rdo);
     if (it + stride < nitems) fetch(it + stride);
     float qn[16], kn[16], invq, invk;
     Row rqt, rks;

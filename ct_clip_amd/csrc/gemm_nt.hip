@@ -98,7 +98,10 @@ __device__ __forceinline__ const char* to_sgpr(const char* ptr) {
   return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
 
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+#ifndef STRICT_VMCNT
+#define STRICT_VMCNT 0      // 1 = every counted vmcnt wait becomes vmcnt(0) (determinism bisection builds, tools/trace_determinism.py)
+#endif
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STRICT_VMCNT ? 0 : N) : "memory"); }
 
 // Fragment reads go through inline asm with the kernel's own counted lgkmcnt waits (LDS returns in order): left to the compiler
 // every half sub-step began with s_waitcnt lgkmcnt(0) right after two fresh reads were issued, i.e. exposed their latency.

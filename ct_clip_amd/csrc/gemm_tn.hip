@@ -37,7 +37,10 @@ __device__ __forceinline__ const char* to_sgpr(const char* ptr) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+#ifndef STRICT_VMCNT
+#define STRICT_VMCNT 0      // 1 = every counted vmcnt wait becomes vmcnt(0) (determinism bisection builds, tools/trace_determinism.py)
+#endif
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STRICT_VMCNT ? 0 : N) : "memory"); }
 
 // One fragment (8 k-slots x 16 columns) = two transposing reads 16 k-rows (2048 B) apart.  Inline asm on purpose: through the
 // builtin the compiler cannot tell these reads from the LDS-DMA writes in flight and drains vmcnt to 0 before every one of them

@@ -65,7 +65,7 @@ struct Geo {
 template <int N> __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   constexpr int M = (PEG_ABL & 2) ? 0 : N;
-  __builtin_amdgcn_s_waitcnt((M & 15) | ((M >> 4) << 14) | 0x0F70);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(M) : "memory");      // (asm + memory clobber: the optimiser may move the s_waitcnt builtin across LDS accesses)
 }
 
 struct Tile { int64_t b; int beta0, c0; };

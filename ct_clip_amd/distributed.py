@@ -110,44 +110,60 @@ class GradReducer:
         self.register(model.to_text_latent, model.to_text_latent.parameters())
         self.register(model.to_visual_latent, model.to_visual_latent.parameters())
         if world_size() > 1 and self.overlap:
-            Fn.set_grad_ready_hook(self.ready)
+            self._prev_hook = Fn.set_grad_ready_hook(self.ready)
+            self._hooked = True
         return self
 
+    def uninstall(self):
+        """Restore the grad-ready hook that was active before install() (a later model / trainer in the same process must not call
+        into this reducer)."""
+        if getattr(self, "_hooked", False):
+            from . import functional as Fn
+            Fn.set_grad_ready_hook(self._prev_hook)
+            self._hooked = False
+
     # ---- backward-time
+    def _events_now(self):
+        """Events behind everything that may have written the range announced right now: the announcing stream (the image tower's
+        main stream or the text tower's side stream -- whichever backward is running on) and the weight-gradient stream(s)."""
+        if self.comm_stream is None:
+            return []
+        from . import functional as Fn
+        return [torch.cuda.current_stream().record_event()] + list(Fn.wgrad_event() or ())
+
     def ready(self, tag):
         r = self.ranges.get(self._key(tag))
         if r is None or world_size() == 1:
             return
         a, b = r
-        self.pending.append([a, b])
-        self.pending.sort()
+        # the events travel WITH the segment: a segment announced on stream A and merged into a run launched from a notification on
+        # stream B is still ordered behind A's kernels
+        self.pending.append([a, b, self._events_now()])
+        self.pending.sort(key=lambda seg: seg[0])
         merged = []
         for seg in self.pending:
             if merged and merged[-1][1] == seg[0]:
                 merged[-1][1] = seg[1]
+                merged[-1][2] = merged[-1][2] + seg[2]
             else:
                 merged.append(seg)
         self.pending = []
         for seg in merged:
             if seg[1] - seg[0] >= self.min_elems:
-                self._launch(seg[0], seg[1])
+                self._launch(seg[0], seg[1], seg[2])
             else:
                 self.pending.append(seg)
 
-    def _launch(self, a, b):
-        evt, wg_evts = None, None
-        if self.comm_stream is not None:
-            evt = torch.cuda.current_stream().record_event()      # everything that wrote flat[a:b] is in front of this event ...
-            from . import functional as Fn
-            wg_evts = Fn.wgrad_event()                            # ... or of these (weight gradients written on their own stream)
+    def _launch(self, a, b, events=None):
+        if events is None:
+            events = self._events_now()
         for s in range(a, b, self.max_elems):
             e = min(b, s + self.max_elems)
             self.log.append((s, e))
             self.launched.append((s, e))
             if self.comm_stream is not None:
-                self.comm_stream.wait_event(evt)
-                for wev in (wg_evts or ()):
-                    self.comm_stream.wait_event(wev)
+                for ev in events:
+                    self.comm_stream.wait_event(ev)
                 with torch.cuda.stream(self.comm_stream):
                     self._reduce_slice(s, e)
             else:
@@ -176,7 +192,7 @@ class GradReducer:
             from . import functional as Fn
             Fn.join_side_streams()      # gradients written from the text tower's stream: the events below are recorded on the current stream
         for seg in self.pending:
-            self._launch(seg[0], seg[1])
+            self._launch(seg[0], seg[1], seg[2] + self._events_now())
         self.pending = []
         done = sorted(self.launched)
         pos, n = 0, self.flat.numel()

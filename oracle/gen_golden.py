@@ -165,7 +165,13 @@ def fingerprint(t):
                 head=t.detach().reshape(-1)[:4].clone(), tail=t.detach().reshape(-1)[-4:].clone())
 
 
-def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000):
+# The BENCHMARKED stack (bench.py default = BASELINE.json configs[1] "24 layers"): the same geometry with 12+12 layers, B = 2.  Pins the
+# error growth through 24 layers and the VQ agreement after them; every layer's feed-forward output is sampled (`s{i}_ff`, `t{i}_ff`) so
+# that a test can show WHERE a low-precision run leaves the reference.
+FULL2_CASE = dict(FULL_CASE, seed=3, sdepth=12, tdepth=12)
+
+
+def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000, every_layer=False):
     import time
     t0 = time.time()
     clip, t, hw = build(c)
@@ -209,6 +215,11 @@ def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000)
           vt.enc_temporal_transformer.layers[0][0].register_forward_hook(hook("t0_peg")),
           vt.enc_temporal_transformer.layers[0][1].register_forward_hook(hook("t0_attn")),
           vt.enc_temporal_transformer.layers[0][3].register_forward_hook(hook("t0_ff"))]
+    if every_layer:
+        for i in range(1, c["sdepth"]):
+            hs.append(vt.enc_spatial_transformer.layers[i][3].register_forward_hook(hook(f"s{i}_ff", lambda o: o.reshape(-1, o.shape[-1]))))
+        for i in range(1, c["tdepth"]):
+            hs.append(vt.enc_temporal_transformer.layers[i][3].register_forward_hook(hook(f"t{i}_ff", lambda o: o.reshape(-1, o.shape[-1]))))
     vq_out = {}
 
     def vq_hook(_m, _i, o):
@@ -392,6 +403,8 @@ if __name__ == "__main__":
             continue
         if name == "full1":
             run_full_case()
+        elif name == "full2":
+            run_full_case("full2", FULL2_CASE, every_layer=True)
         elif name == "finetune_tiny":
             run_finetune_case()
         else:

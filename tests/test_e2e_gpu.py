@@ -121,24 +121,3 @@ def test_one_training_step_matches_oracle(golden, tmp_path):
         torch.testing.assert_close(delta, delta_ref, rtol=2e-2, atol=2e-2 * float(delta_ref.abs().max()) + 6e-2 * lr)
         checked += 1
     assert checked > 40
-
-
-def test_two_rank_rehearsal_on_one_device(tmp_path):
-    """The N > 1 path on a real device: two ranks on cuda:0 with gloo collectives (bench.py's rehearsal hook) -- gathered-negatives loss,
-    gradient buckets launched from backward on the communication stream behind the main and weight-gradient streams, VQ statistics
-    all-reduce.  The CPU gloo tests never enter the CUDA-only branches of GradReducer (that is where a round-2 bug sat)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CTCLIP_BENCH_BACKEND="gloo", CTCLIP_BENCH_SINGLE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--spatial-depth", "1", "--temporal-depth", "1",
-           "--no-attn-block", "--profile-steps", "0"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
-    assert res.returncode == 0, res.stderr[-3000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4
-    assert abs(rec["loss"] - 1.386) < 0.2          # ln 4 for random towers: the loss saw the gathered batch

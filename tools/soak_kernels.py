@@ -32,7 +32,7 @@ def checksum(outs):
     for t in outs:
         if t is None:
             continue
-        raw = t.detach().contiguous().view(torch.uint8)
+        raw = t.detach().contiguous().reshape(-1).view(torch.uint8)
         n = raw.numel() // 8 * 8
         w = raw[:n].view(torch.int64)
         idx = torch.arange(1, w.numel() + 1, device=dev, dtype=torch.int64)
