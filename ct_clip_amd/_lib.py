@@ -71,6 +71,7 @@ SIGNATURES = {
     "ctclip_leaky_relu_bwd": (_I, [_P, _P, _P, _L, _F, _P]),
     "ctclip_colsum_workspace": (_L, [_L, _I]),
     "ctclip_colsum": (_I, [_P, _P, _L, _I, _L, _I, _P, _L, _P]),
+    "ctclip_patch_embed_param_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ctclip_permute0213": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "ctclip_transpose2d": (_I, [_P, _P, _I, _I, _L, _L, _I, _P]),
     "ctclip_pool_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),

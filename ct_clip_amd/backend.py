@@ -557,6 +557,18 @@ class HipBackend:
                    "ctclip_colsum")
         return out
 
+    def patch_embed_param_bwd(self, G, W, g1, b1, dbp, dW, dg1, db1, accumulate):
+        """Parameter-space epilogue of the patch-embedding backward: dW (+)= G * gamma1 + dbp (x) beta1, dgamma1 (+)= sum_n W G,
+        dbeta1 (+)= W^T dbp (all f32, written / accumulated in place)."""
+        N, K = W.shape
+        for t in (G, W, dW):
+            assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (N, K)
+        for t in (g1, b1, dg1, db1):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == K
+        assert dbp.dtype == torch.float32 and dbp.numel() == N
+        _lib.check(self.lib.ctclip_patch_embed_param_bwd(_p(G), _p(W), _p(g1), _p(b1), _p(dbp), _p(dW), _p(dg1), _p(db1), N, K, int(accumulate),
+                                                         _stream()), "ctclip_patch_embed_param_bwd")
+
     def permute0213(self, x):
         A, B, C, D = x.shape
         assert x.is_contiguous()

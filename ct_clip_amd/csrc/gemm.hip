@@ -6,7 +6,7 @@
 // so that the three products of a Linear layer share one kernel body:
 //   forward  y  = x  W^T   : (a_kc, b_kc) = (1, 1)
 //   grad-in  dx = dy W     : (1, 0)
-//   grad-w   dW = dy^T x   : (0, 0)   (contraction over the token axis; split-K + f32 atomics)
+//   grad-w   dW = dy^T x   : (0, 0)   (contraction over the token axis; split-K slabs + ordered reduce)
 //
 // Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, k-tile = 128 bytes per row
 // (64 bf16 / 32 f32).  Tiles are staged global -> VGPR -> LDS ([row][8 x 16-B chunks], chunk index
@@ -46,8 +46,8 @@ enum { EPI_STD = 0, EPI_ARGMAX = 1 };
 struct GemmParams {
   const void* A; const void* B; void* C; const float* bias; const void* residual;
   int64_t M, N, K, lda, ldb, ldc, ldr;
-  int out_dtype, res_dtype, accumulate, atomic_out;
-  float* slab;      // split-K partial results [split][M][N] (deterministic reduce afterwards); null = f32 atomics into C
+  int out_dtype, res_dtype, accumulate;
+  float* slab;      // split-K partial results [split][M][N] (deterministic reduce afterwards); null = no split
   float alpha;
   int k_per_split;  // multiple of the k-tile
   int ntm, ntn;
@@ -258,7 +258,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
           if (p.out_dtype == DT_F32) {
             float* c = reinterpret_cast<float*>(p.C) + row * p.ldc + col;
             if (p.slab) p.slab[((int64_t)blockIdx.y * p.M + row) * p.N + col] = v;
-            else if (p.atomic_out) atomicAdd(c, v);
             else *c = p.accumulate ? (*c + v) : v;
           } else {
             bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col;
@@ -393,11 +392,10 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   p.ntm = (int)cdiv(M, BM); p.ntn = (int)cdiv(N, BN);
   if (split_k > 1 && out_dtype != DT_F32) { ctclip_set_error("gemm: split-K needs f32 output"); return CTCLIP_EUNSUPPORTED; }
   split_k = generic_split(M, N, K, in_dtype, out_dtype, split_k, &p.k_per_split);
-  p.atomic_out = split_k > 1;
   const int64_t slab_bytes = (int64_t)split_k * M * N * 4;
-  if (split_k > 1 && workspace && workspace_bytes >= slab_bytes) p.slab = (float*)workspace;    // deterministic: slabs + ordered reduce
-  if (p.atomic_out && !p.slab && !accumulate) {
-    if (hipMemset2DAsync(C, ldc * 4, 0, N * 4, M, stream) != hipSuccess) { ctclip_set_error("gemm: memset failed"); return -1000; }
+  if (split_k > 1) {      // split-K partial sums go to slabs and are reduced in a fixed order: there is no float-atomic path in this library
+    if (!workspace || workspace_bytes < slab_bytes) { ctclip_set_error("gemm: split-K needs ctclip_gemm_workspace() bytes of workspace"); return CTCLIP_EWORKSPACE; }
+    p.slab = (float*)workspace;
   }
   dim3 grid(p.ntm * p.ntn, split_k);
   rc = in_dtype == DT_F32 ? launch_layout<float, EPI_STD>(p, a_kc, b_kc, grid, stream) : launch_layout<bf16_t, EPI_STD>(p, a_kc, b_kc, grid, stream);
@@ -410,7 +408,7 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
 // bytes of optional workspace for ctclip_gemm (split-K partial slabs of the large-tile bf16 path); split_k <= 0 means "auto"
 extern "C" int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k) {
   const int gs = generic_split(M, N, K, in_dtype, DT_F32, split_k, nullptr);
-  const int64_t wgen = gs > 1 ? (int64_t)gs * M * N * 4 : 0;         // generic kernel: split-K slabs (without them: f32 atomics)
+  const int64_t wgen = gs > 1 ? (int64_t)gs * M * N * 4 : 0;         // generic kernel: split-K slabs
   if (in_dtype != DT_BF16) return wgen;
   const int64_t w256 = ctclip_gemm256_workspace(M, N, K, split_k), wtn = ctclip_gemm_tn_workspace(M, N, K, split_k);
   const int64_t w = w256 > wtn ? w256 : wtn;

@@ -16,7 +16,7 @@
 //     rows x 8 k, transposed in registers (v_perm-style packs) and written with ds_write_b128 into the same image.
 //   The next stage's loads are issued before the current stage's MFMAs; one barrier per k-step.
 // Epilogue: accumulators -> LDS (per-wave 128 x 64 tile) -> 16-byte coalesced row stores with bias / residual fused;
-//   split-K partial sums go out as f32 atomics.
+//   split-K partial sums go to per-split f32 slabs + an ordered reduce (no atomics).
 #include "common.h"
 
 namespace {

@@ -431,3 +431,49 @@ extern "C" int ctclip_vq_ema_update(float* cluster, float* embed, const float* b
   hipLaunchKernelGGL(vq_ema_update_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, cluster, embed, bins, esum, C, d, decay);
   return ctclip_check_launch("vq_ema_update");
 }
+
+// ---- parameter-space epilogue of the patch-embedding backward (ctvit.py:170-175 with LayerNorm(K)'s affine folded into the Linear:
+// W' = W * gamma1 per column, b' = W beta1 + b).  G = dZ^T xhat (N x K, f32) and dbp = colsum(dZ) are in hand; this turns them into
+//   dW[n][k] (+)= G[n][k] * gamma1[k] + dbp[n] * beta1[k],   dgamma1[k] (+)= sum_n W[n][k] G[n][k],   dbeta1[k] (+)= sum_n W[n][k] dbp[n].
+// One workgroup owns 64 columns; eight row groups walk N / 8 rows each and are folded through LDS in a fixed order (deterministic).
+namespace {
+__global__ __launch_bounds__(512) void patch_param_bwd_kernel(const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ g1,
+                                                              const float* __restrict__ b1, const float* __restrict__ dbp, float* __restrict__ dW,
+                                                              float* __restrict__ dg1, float* __restrict__ db1, int N, int K, int accumulate) {
+  __shared__ float red[2][8][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  const bool on = k < K;
+  const int kk = on ? k : K - 1;
+  const float gam = g1[kk], bet = b1[kk];
+  float sg = 0.f, sb = 0.f;
+  const int per = (N + 7) / 8;
+  const int n1 = (rg + 1) * per < N ? (rg + 1) * per : N;
+  for (int n = rg * per; n < n1; ++n) {
+    const float g = G[(int64_t)n * K + kk], w = W[(int64_t)n * K + kk], d = dbp[n];
+    sg = fmaf(w, g, sg);
+    sb = fmaf(w, d, sb);
+    if (on) {
+      const float v = fmaf(g, gam, d * bet);
+      float* o = dW + (int64_t)n * K + k;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+  red[0][rg][c] = sg; red[1][rg][c] = sb;
+  __syncthreads();
+  if (rg == 0 && on) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a += red[0][j][c]; b += red[1][j][c]; }
+    dg1[k] = accumulate ? dg1[k] + a : a;
+    db1[k] = accumulate ? db1[k] + b : b;
+  }
+}
+}  // namespace
+
+extern "C" int ctclip_patch_embed_param_bwd(const float* G, const float* W, const float* gamma1, const float* beta1, const float* dbp, float* dW,
+                                            float* dgamma1, float* dbeta1, int N, int K, int accumulate, hipStream_t s) {
+  if (!G || !W || !gamma1 || !beta1 || !dbp || !dW || !dgamma1 || !dbeta1 || N <= 0 || K <= 0) { ctclip_set_error("patch_embed_param_bwd: bad args"); return CTCLIP_EBADARG; }
+  hipLaunchKernelGGL(patch_param_bwd_kernel, dim3((unsigned)cdiv(K, 64)), dim3(512), 0, s, G, W, gamma1, beta1, dbp, dW, dgamma1, dbeta1, N, K, accumulate);
+  return ctclip_check_launch("patch_embed_param_bwd");
+}

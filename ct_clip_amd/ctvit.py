@@ -143,8 +143,11 @@ class Transformer(nn.Module):
         """x: (nseq*L, dim) activation in compute dtype (flat view of the reference's (nseq, L, dim))."""
         b, t, h, w = video_shape
         d = x.shape[1]
-        for layer in self.layers:
+        tap = self.__dict__.get("layer_tap")      # test hook (never set by the product): tap(i, x) sees the residual stream at every layer boundary
+        for i, layer in enumerate(self.layers):
             peg, attn, _, ff = layer
+            if tap is not None:
+                tap(i, x)
             x = Fn.grad_ready(x, layer)     # backward passing this point = the layer's parameter gradients are final
             # x = peg(x) + x  -- PEG sees the buffer flat-reinterpreted as (b, t, h, w, d) (attention.py:69-70)
             x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)

@@ -599,19 +599,17 @@ class PatchEmbedFn(Function):
         G = torch.zeros((N, K), dtype=torch.float32, device=dz.device)
         be.gemm(dz, xhat[:, :K], a_kc=False, b_kc=False, out=G, accumulate=True,
                 split_k=0, M=N, N=K, K=dz.shape[0])
-        # parameter-space epilogue (N x K elementwise, tiny next to the token stream)
-        Wd, g1d, b1d = W.detach(), g1.detach(), b1.detach()
-        dW = G * g1d[None, :] + dbp[:, None] * b1d[None, :]
-        dg1 = (Wd * G).sum(0)
-        db1 = Wd.t() @ dbp
-
-        def give(param, val):
-            s = sink_of(param)
-            if s is None:
-                return val
-            s.add_(val.view_as(s))
-            return None
-        return (None, give(g1, dg1), give(b1, db1), give(W, dW), give(bl, dbp),
+        # parameter-space epilogue (N x K elementwise + two column reductions, one launch): straight into the flat gradient buffer
+        def sink_or_zeros(param):
+            s_ = sink_of(param)
+            return (s_, True) if s_ is not None else (torch.zeros_like(param, dtype=torch.float32), False)
+        (dW, w_sunk), (dg1, g_sunk), (db1, b_sunk) = sink_or_zeros(W), sink_or_zeros(g1), sink_or_zeros(b1)
+        assert w_sunk == g_sunk == b_sunk, "the patch-embedding parameters are registered with the optimiser together or not at all"
+        be.patch_embed_param_bwd(G, W.detach().contiguous(), g1.detach(), b1.detach(), dbp, dW, dg1, db1, accumulate=w_sunk)
+        bls = sink_of(bl)
+        if bls is not None:
+            be.accumulate(bls, dbp)
+        return (None, None if g_sunk else dg1, None if b_sunk else db1, None if w_sunk else dW, None if bls is not None else dbp,
                 None if g2s is not None else dg2, None if b2s is not None else db2, None, None, None, None)
 
 

@@ -218,6 +218,9 @@ int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t 
 /* VQ EMA buffer update (decay 0.8) of cluster_size and embed. */
 int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s);
 
+/* parameter-space epilogue of the patch-embedding backward (replaces the autograd of nn.LayerNorm(K) + nn.Linear(K, d), ctvit.py:172-173, with the LayerNorm affine folded into the GEMM): from G = dZ^T xhat (N x K) and dbp = colsum(dZ): dW (+)= G * gamma1 + dbp (x) beta1, dgamma1 (+)= sum_n W G, dbeta1 (+)= W^T dbp; all f32, fixed summation order. */
+int ctclip_patch_embed_param_bwd(const float* G, const float* W, const float* gamma1, const float* beta1, const float* dbp, float* dW, float* dgamma1, float* dbeta1, int N, int K, int accumulate, hipStream_t s);
+
 /* F.layer_norm (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm). gamma/beta may be NULL. */
 int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps, int dtype, hipStream_t stream);
 

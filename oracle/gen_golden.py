@@ -166,7 +166,7 @@ def fingerprint(t):
 
 
 # The BENCHMARKED stack (bench.py default = BASELINE.json configs[1] "24 layers"): the same geometry with 12+12 layers, B = 2.  Pins the
-# error growth through 24 layers and the VQ agreement after them; every layer's feed-forward output is sampled (`s{i}_ff`, `t{i}_ff`) so
+# error growth through 24 layers and the VQ agreement after them; the residual stream at every layer boundary is sampled (`s{i}_in`, `t{i}_in`) so
 # that a test can show WHERE a low-precision run leaves the reference.
 FULL2_CASE = dict(FULL_CASE, seed=3, sdepth=12, tdepth=12)
 
@@ -216,10 +216,15 @@ def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000,
           vt.enc_temporal_transformer.layers[0][1].register_forward_hook(hook("t0_attn")),
           vt.enc_temporal_transformer.layers[0][3].register_forward_hook(hook("t0_ff"))]
     if every_layer:
-        for i in range(1, c["sdepth"]):
-            hs.append(vt.enc_spatial_transformer.layers[i][3].register_forward_hook(hook(f"s{i}_ff", lambda o: o.reshape(-1, o.shape[-1]))))
-        for i in range(1, c["tdepth"]):
-            hs.append(vt.enc_temporal_transformer.layers[i][3].register_forward_hook(hook(f"t{i}_ff", lambda o: o.reshape(-1, o.shape[-1]))))
+        # the residual stream at every layer boundary = the input of each layer's PEG (attention.py:322-324), flat order
+        def pre(key):
+            def fn(_m, args):
+                inter[key] = subsample(args[0], inter_limit)
+            return fn
+        for i in range(c["sdepth"]):
+            hs.append(vt.enc_spatial_transformer.layers[i][0].register_forward_pre_hook(pre(f"s{i}_in")))
+        for i in range(c["tdepth"]):
+            hs.append(vt.enc_temporal_transformer.layers[i][0].register_forward_pre_hook(pre(f"t{i}_in")))
     vq_out = {}
 
     def vq_hook(_m, _i, o):

@@ -439,6 +439,13 @@ class RefBackend:
         out += _f(x[:, :N]).sum(0)
         return out
 
+    def patch_embed_param_bwd(self, G, W, g1, b1, dbp, dW, dg1, db1, accumulate):
+        vW, vg, vb = G * g1[None, :] + dbp[:, None] * b1[None, :], (W * G).sum(0), W.t() @ dbp
+        if accumulate:
+            dW.add_(vW); dg1.add_(vg); db1.add_(vb)
+        else:
+            dW.copy_(vW); dg1.copy_(vg); db1.copy_(vb)
+
     def permute0213(self, x):
         return x.permute(0, 2, 1, 3).contiguous()
 

@@ -1,11 +1,15 @@
-"""BASELINE.json configs[1] geometry (480x480x240, patch 20x20x10, dim 512, 24^3 tokens, 8192 codes, BERT-base, T=128) against
-tests/golden/full1.pt -- outputs of the REAL reference at that size (oracle/gen_golden.py full1: 4+4 layers, B=2, forward +
-backward).  Weights and inputs are rebuilt from the seeds (the fixture proves with fingerprints that they are the tensors the
-reference ran on).  Protocol of SURVEY.md Appendix D:
+"""BASELINE.json configs[1] geometry (480x480x240, patch 20x20x10, dim 512, 24^3 tokens, 8192 codes, BERT-base, T=128) against outputs
+of the REAL reference at that size (oracle/gen_golden.py):
+  * tests/golden/full1.pt -- the reference scripts' own depth, 4+4 layers (run_train.py:17-27), B = 2, forward + backward;
+  * tests/golden/full2.pt -- the BENCHMARKED stack, 12+12 layers ("24 layers" of BASELINE.json configs[1], bench.py's default), B = 2,
+    with the residual stream sampled at every layer boundary.
+Weights and inputs are rebuilt from the seeds (the fixtures prove with fingerprints that they are the tensors the reference ran on).
+Protocol of SURVEY.md Appendix D:
   * f32 parity mode: tokens / latents / loss <= 1e-4, VQ code agreement >= 99.9 %, gradients by relative Frobenius error;
-  * bf16 performance mode with TEACHER-FORCED VQ indices (kernel error without code flips): loss <= 1e-2 rel, latents cosine;
-  * bf16 free-running: code agreement reported and bounded (>= 0.95), loss bounded.
+  * bf16 performance mode with TEACHER-FORCED VQ indices (kernel error without code flips): loss within the north_star bar 1e-3 rel;
+  * bf16 free-running: code agreement, loss and BOTH latent cosines bounded at <= 3x the measured values (profiles/r03_full_size_parity.log).
 """
+import functools
 import os
 
 import pytest
@@ -19,9 +23,9 @@ DEV = torch.device("cuda", 0)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def full():
-    g = torch.load(os.path.join(ROOT, "tests", "golden", "full1.pt"), weights_only=False)
+@functools.lru_cache(maxsize=None)
+def _load(name):
+    g = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
     c = g["config"]
     clip = build_model(c, None, torch.device("cpu"), torch.float32)
     perturb_1d(clip, c["seed"])
@@ -33,7 +37,19 @@ def full():
     assert fingerprint_ok(video, g["video_fingerprint"])
     assert torch.equal(ids, g["input_ids"]) and torch.equal(mask, g["attention_mask"])
     state = {k: v.clone() for k, v in sd.items()}
+    g["name"] = name
     return g, clip, state, video, ids, mask
+
+
+@pytest.fixture(scope="module", params=["full1", "full2"])
+def full(request):
+    yield _load(request.param)
+    _load(request.param)[1].to("cpu")          # one model on the device at a time
+
+
+@pytest.fixture(scope="module")
+def full1():
+    return _load("full1")
 
 
 def sub(rec, mine):
@@ -63,7 +79,7 @@ def test_f32_full_size_matches_reference(full):
     g, clip, text, video = prepare(full, torch.float32, True)
     loss = clip(text, video, return_loss=True, device=DEV)
     rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
-    print(f"[full1 f32] loss {float(loss):.6f} reference {float(g['loss']):.6f} rel {rel:.2e}")
+    print(f"[{g['name']} f32] loss {float(loss):.6f} reference {float(g['loss']):.6f} rel {rel:.2e}")
     assert rel < 1e-4
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
@@ -77,8 +93,8 @@ def test_f32_full_size_matches_reference(full):
         if e > worst[1]:
             worst = (k, e)
         n += 1
-    print(f"[full1 f32] {n} gradients, worst relative error {worst[1]:.2e} ({worst[0]})")
-    assert n > 150 and worst[1] < 2e-2
+    print(f"[{g['name']} f32] {n} gradients, worst relative error {worst[1]:.2e} ({worst[0]})")
+    assert n > 150 and worst[1] < 1e-3
     sd = clip.state_dict()
     cs, cs_ref = sd["visual_transformer.vq._codebook.cluster_size"].cpu(), g["vq_after"]["visual_transformer.vq._codebook.cluster_size"]
     ntok = g["vq_indices"].numel()
@@ -91,7 +107,7 @@ def test_f32_full_size_matches_reference(full):
         tl, il, toks = clip(text, video, return_latents=True, device=DEV)
         ids = clip.visual_transformer(video, return_only_codebook_ids=True)
     agree = (ids.reshape(-1).cpu() == g["eval_vq_indices"].reshape(-1).long()).float().mean().item()
-    print(f"[full1 f32] VQ code agreement {agree:.5f}")
+    print(f"[{g['name']} f32] VQ code agreement {agree:.5f}")
     assert agree >= 0.999
     torch.testing.assert_close(tl.cpu(), g["eval_text_latents"], rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(il.cpu(), g["eval_image_latents"], rtol=1e-3, atol=2e-4)
@@ -107,6 +123,15 @@ def _bf16_run(full, teacher):
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
     gn_rel = abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"])
+    grads = dict((n, p.grad) for n, p in clip.named_parameters() if p.grad is not None)
+    cos_min, cos_name = 1.0, ""
+    for k, rec in g["grads"].items():
+        if rec["value"].numel() < 64 or float(rec["norm"]) < 1e-6 * float(g["grad_norm"]):
+            continue
+        a, b_ = sub(rec, grads[k]).reshape(-1).double(), rec["value"].reshape(-1).double()
+        c = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-300))
+        if c < cos_min:
+            cos_min, cos_name = c, k
     clip.load_state_dict(full[2])
     clip.eval()
     with torch.no_grad():
@@ -116,42 +141,71 @@ def _bf16_run(full, teacher):
     agree = (ids.reshape(-1).cpu() == g["eval_vq_indices"].reshape(-1).long()).float().mean().item()
     cos_i = torch.nn.functional.cosine_similarity(il.cpu(), g["eval_image_latents"]).min().item()
     cos_t = torch.nn.functional.cosine_similarity(tl.cpu(), g["eval_text_latents"]).min().item()
-    return rel, gn_rel, agree, cos_i, cos_t
+    return dict(name=g["name"], rel=rel, gn_rel=gn_rel, agree=agree, cos_i=cos_i, cos_t=cos_t, grad_cos_min=cos_min, grad_cos_name=cos_name)
+
+
+# bounds = <= 3x the values measured on MI355X (profiles/r03_full_size_parity.log), never above the north_star bar where one exists
+TEACHER_BOUNDS = {"full1": dict(rel=1e-3, gn_rel=5e-2, cos_i=0.9999, cos_t=0.9999, grad_cos=0.99),
+                  "full2": dict(rel=1e-3, gn_rel=5e-2, cos_i=0.9999, cos_t=0.9999, grad_cos=0.99)}
+FREE_BOUNDS = {"full1": dict(rel=6e-3, gn_rel=0.3, agree=0.97, cos_i=0.97, cos_t=0.9999),
+               "full2": dict(rel=6e-3, gn_rel=0.3, agree=0.95, cos_i=0.95, cos_t=0.9999)}
 
 
 def test_bf16_full_size_teacher_forced(full):
-    rel, gn_rel, agree, cos_i, cos_t = _bf16_run(full, True)
-    print(f"[full1 bf16 teacher-forced] loss rel {rel:.2e}, grad-norm rel {gn_rel:.2e}, free-running code agreement {agree:.4f}, "
-          f"latent cosine image {cos_i:.5f} text {cos_t:.5f}")
-    assert rel < 1e-2 and gn_rel < 5e-2 and cos_i > 0.999 and cos_t > 0.999
+    """Kernel error alone (the reference's code ids forced): the bf16 loss meets the north_star bar (1e-3 rel) at full size."""
+    r = _bf16_run(full, True)
+    print(f"[{r['name']} bf16 teacher-forced] loss rel {r['rel']:.2e}, grad-norm rel {r['gn_rel']:.2e}, free-running code agreement {r['agree']:.4f}, "
+          f"latent cosine image {r['cos_i']:.6f} text {r['cos_t']:.6f}, worst gradient cosine {r['grad_cos_min']:.5f} ({r['grad_cos_name']})")
+    b = TEACHER_BOUNDS[r["name"]]
+    assert r["rel"] < b["rel"] and r["gn_rel"] < b["gn_rel"] and r["cos_i"] > b["cos_i"] and r["cos_t"] > b["cos_t"] and r["grad_cos_min"] > b["grad_cos"]
 
 
 def test_bf16_full_size_free_running(full):
-    rel, gn_rel, agree, cos_i, cos_t = _bf16_run(full, False)
-    print(f"[full1 bf16 free-running] loss rel {rel:.2e}, grad-norm rel {gn_rel:.2e}, code agreement {agree:.4f}, "
-          f"latent cosine image {cos_i:.5f} text {cos_t:.5f}")
-    assert agree >= 0.95 and rel < 3e-2 and cos_t > 0.999
+    r = _bf16_run(full, False)
+    print(f"[{r['name']} bf16 free-running] loss rel {r['rel']:.2e}, grad-norm rel {r['gn_rel']:.2e}, code agreement {r['agree']:.4f}, "
+          f"latent cosine image {r['cos_i']:.6f} text {r['cos_t']:.6f}")
+    b = FREE_BOUNDS[r["name"]]
+    assert r["agree"] >= b["agree"] and r["rel"] < b["rel"] and r["gn_rel"] < b["gn_rel"] and r["cos_i"] > b["cos_i"] and r["cos_t"] > b["cos_t"]
 
 
-def _agree(results_a, results_b):
-    """Bit-identity of two configurations in the presence of a RARE run-to-run difference of the bf16 step that round 2 observed on
-    some boxes (about 1 run in 70: loss +-1e-4, a handful of vector-quantiser codes; not an uninitialised read -- NaN-poisoned
-    allocations reproduce bit for bit -- and not located yet): the two configurations must share their most
-    frequent result, and at most one run of all may deviate from it."""
-    from collections import Counter
-    allr = list(results_a) + list(results_b)
-    top, n = Counter(allr).most_common(1)[0]
-    if n < len(allr):
-        print(f"[full1] {len(allr) - n} of {len(allr)} runs deviated from the common result: {Counter(allr)}")
-    return top in results_a and top in results_b and n >= len(allr) - 1
+def test_layer_error_trace(full):
+    """Where does a low-precision run leave the reference?  Relative error of the residual stream at every layer boundary against the
+    fixture's samples (full2 only: full1 holds two boundaries), f32 and bf16, printed as a table (committed under profiles/)."""
+    g = full[0]
+    if "s1_in" not in g["intermediates"]:
+        pytest.skip("fixture without per-layer samples")
+    rows = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        g, clip, text, video = prepare(full, dtype, False)
+        vt = clip.visual_transformer
+        errs = {}
+        for tr, pre in ((vt.enc_spatial_transformer, "s"), (vt.enc_temporal_transformer, "t")):
+            tr.__dict__["layer_tap"] = (lambda i, x, pre=pre: errs.__setitem__(f"{pre}{i}_in", rel_err(g["intermediates"][f"{pre}{i}_in"], x)))
+        try:
+            with torch.no_grad():
+                toks = vt(video, return_encoded_tokens=True)
+                ids = vt(video, return_only_codebook_ids=True)
+        finally:
+            for tr in (vt.enc_spatial_transformer, vt.enc_temporal_transformer):
+                tr.__dict__.pop("layer_tap", None)
+        errs["vq_agreement"] = (ids.reshape(-1).cpu() == g["eval_vq_indices"].reshape(-1).long()).float().mean().item()
+        rows[tag] = errs
+    keys = [k for k in rows["f32"] if k.endswith("_in")]
+    print(f"[{g['name']}] residual-stream relative error per layer boundary (vs the real reference, f32 CPU)")
+    print("   boundary        f32        bf16")
+    for k in keys:
+        print(f"   {k:10s} {rows['f32'][k]:10.2e} {rows['bf16'][k]:10.2e}")
+    print(f"   VQ code agreement: f32 {rows['f32']['vq_agreement']:.5f}, bf16 {rows['bf16']['vq_agreement']:.5f}")
+    assert max(rows["f32"][k] for k in keys) < 1e-4
+    assert max(rows["bf16"][k] for k in keys) < 3e-2
 
 
-def test_zz_side_stream_backward_is_bit_identical(full, tmp_path, monkeypatch):
+def test_zz_side_stream_backward_is_bit_identical(full1, tmp_path, monkeypatch):
     """Inside the trainer's backward the weight-gradient GEMMs, the PEG weight gradient and the position-bias table gradient run on a
     side stream under the grad-input chain (functional.wgrad_stream_begin).  Same kernels, same order of every sum: the flat gradient
     buffer must be bit-identical to the single-stream backward (CTCLIP_WGRAD_STREAM=0), and so must the loss."""
     import ct_clip_amd
-    g, clip, text, video = prepare(full, torch.bfloat16, True)
+    g, clip, text, video = prepare(full1, torch.bfloat16, True)
     vq = clip.visual_transformer.vq._codebook
     vq0 = (vq.embed.clone(), vq.cluster_size.clone())
     data0 = {id(p): p.data for p in clip.parameters()}
@@ -168,7 +222,7 @@ def test_zz_side_stream_backward_is_bit_identical(full, tmp_path, monkeypatch):
             fg = trainer.optim.flat_grad
             assert float(fg.abs().max()) > 0
             out[mode].append((float(loss.detach()), float(fg.double().sum()), float(fg.double().abs().sum()), int(fg.view(torch.int32).sum())))
-        assert _agree(out["0"], out["1"]), out
+        assert len(set(out["0"] + out["1"])) == 1, out      # 5 of 5 runs bit-identical (strict since the attn_short fix)
     finally:      # the module-scoped model goes back to ordinary parameters for whoever uses the fixture next
         for p in clip.parameters():
             p.__dict__.pop("_ctclip_grad_sink", None)
@@ -178,13 +232,13 @@ def test_zz_side_stream_backward_is_bit_identical(full, tmp_path, monkeypatch):
         vq.embed.copy_(vq0[0]); vq.cluster_size.copy_(vq0[1])
 
 
-def test_zz_batched_shadow_refresh_in_training(full, tmp_path, monkeypatch):
+def test_zz_batched_shadow_refresh_in_training(full1, tmp_path, monkeypatch):
     """Two optimisation steps at the full geometry with the one-launch weight-shadow refresh after the optimiser step against the lazy
     per-shadow makers: every bf16 GEMM operand of step 2 (plain, padded, GEGLU split / interleaved, stacked q|k|v, transposed) must be
     bit-identical, hence the loss of step 2 and the parameters after it."""
     import ct_clip_amd
     from ct_clip_amd import functional as Fn
-    g, clip, text, video = prepare(full, torch.bfloat16, True)
+    g, clip, text, video = prepare(full1, torch.bfloat16, True)
     vq = clip.visual_transformer.vq._codebook
     vq0 = (vq.embed.clone(), vq.cluster_size.clone())
     data0 = {id(p): p.data for p in clip.parameters()}
@@ -212,7 +266,7 @@ def test_zz_batched_shadow_refresh_in_training(full, tmp_path, monkeypatch):
                 p.__dict__.pop("_ctclip_grad_sink", None)
                 p.grad = None
                 p.data = p.data.clone()
-        assert _agree(outs[True], outs[False]), outs
+        assert len(set(outs[True] + outs[False])) == 1, outs      # 4 of 4 bit-identical
     finally:
         for p in clip.parameters():
             p.__dict__.pop("_ctclip_grad_sink", None)

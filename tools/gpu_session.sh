@@ -5,6 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/session; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -q -m gpu -s > $O/t_all.log 2>&1; echo "all gpu tests rc=$? $(tail -n 1 $O/t_all.log)" >> $O/summary.log
+timeout 600 python tools/trace_determinism.py --runs ${TRACE_RUNS:-200} 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/trace200.log; grep TRACE_SUMMARY $O/trace200.log >> $O/summary.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?" >> $O/summary.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
 timeout 300 python tools/bench_gemm_shapes.py 10 > $O/shapes.json 2> $O/shapes.err; echo "shapes rc=$?" >> $O/summary.log
