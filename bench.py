@@ -313,6 +313,184 @@ def attention_block_util(args, device, dtype, iters=10):
                                        "(once per forward for all layers) is outside")
 
 
+# ----------------------------------------------------------------------------------------------------------------- fine-tuning workloads
+def build_towers(args, device, dtype, dropout):
+    from transformers import BertConfig, BertModel
+    import ct_clip_amd
+    torch.manual_seed(0)
+    enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                            temporal_patch_size=FULL["tpatch"], spatial_depth=args.spatial_depth, temporal_depth=args.temporal_depth,
+                            dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=dtype)
+    bert = BertModel(BertConfig(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout))
+    hw = args.image // FULL["patch"]
+    clip = ct_clip_amd.CTCLIP(image_encoder=enc, text_encoder=bert, dim_text=768, dim_image=hw * hw * FULL["dim"], dim_latent=FULL["dim_latent"],
+                              compute_dtype=dtype)
+    return clip.to(device)
+
+
+def finetune_setup(args, device, dtype, rank):
+    """-> (step function, units per step, description).  lipro: scripts/ct_lipro_train.py:92-107 (frozen CT-CLIP in train mode -> image
+    latents -> ReLU -> Dropout(0.3) -> Linear(512, 18), BCEWithLogits(pos_weight), clip 1.0, AdamW + cosine schedule; the reference also
+    runs the unused text tower on " " -- skipped here, the logits do not depend on it).  vocabfine: scripts/ct_vocabfine_train.py:77-123
+    (18 pathologies x (true, false) prompt, similarity of both with the volume = one full CTCLIP forward each, softmax-MSE per group of six,
+    three backwards, one AdamW step per volume, every parameter trains)."""
+    from ct_clip_amd import finetune as FT
+    gd = torch.Generator(device=device).manual_seed(1234 + rank)
+    g = torch.Generator().manual_seed(1234 + rank)
+    video = torch.rand(args.batch, 1, args.frames, args.image, args.image, generator=gd, device=device) * 2 - 1
+    if args.workload == "lipro":
+        clip = build_towers(args, device, dtype, 0.0)
+        head = FT.ImageLatentsClassifier(clip, FULL["dim_latent"], 18).to(device)
+        trainer = FT.LiProTrainer(head, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10 ** 6)
+        labels = (torch.rand(args.batch, 18, generator=g) < 0.3).float().to(device)
+        blank = Text(*synth_text(1, args.text_len, g, device))
+
+        def step():
+            return trainer.train_step(blank, video, labels)[0]
+        what = (f"CT-LiPro / ClassFine step (ct_lipro_train.py:92-107): frozen CTViT {args.image}x{args.image}x{args.frames} "
+                f"{args.spatial_depth}+{args.temporal_depth} layers in train mode (VQ EMA on) -> image latents -> ReLU/Dropout(0.3)/Linear(512,18), "
+                f"BCEWithLogits(pos_weight), clip 1.0, AdamW on the 9 234 head parameters; batch {args.batch}/GPU; text tower skipped")
+        return step, args.batch, what
+    clip = build_towers(args, device, dtype, args.bert_dropout)
+    clip.train()
+    npath = len(FT.PATHOLOGIES)
+    pairs = [Text(*synth_text(2, args.text_len, g, device)) for _ in range(npath)]      # synthetic token ids stand in for the tokenizer
+    trainer = FT.VocabFineTrainer(clip, tokenize=None, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10 ** 6)
+    vol = video[:1]
+
+    def step():
+        trainer.scheduler(trainer.step)
+        losses, _ = trainer.forward_backward(vol, pairs)
+        trainer.optim.step(None)
+        trainer.step += 1
+        return losses[-1]
+    what = (f"VocabFine step (ct_vocabfine_train.py:77-123): one volume {args.image}x{args.image}x{args.frames}, {npath} pathologies x (true, false) prompt "
+            f"(T={args.text_len}) = {npath} full CTCLIP forwards ({args.spatial_depth}+{args.temporal_depth} layers + BERT-base), softmax-MSE per group of 6, "
+            "3 backwards, AdamW on every parameter (end-to-end)")
+    return step, 1, what
+
+
+def finetune_bench(args, device, dtype, world, rank):
+    from ct_clip_amd import backend
+    be = backend.get()
+    step, units, what = finetune_setup(args, device, dtype, rank)
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = None
+    if args.profile_steps > 0:
+        be.start_gemm_timing()
+        for _ in range(min(args.profile_steps, 3)):
+            step()
+        timing = be.stop_gemm_timing()
+        timing["timed_in"] = "extra steps after the timed region, event pair around every GEMM launch on its stream"
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    cfgi = 4 if args.workload == "lipro" else 3
+    out = {"metric": f"CT volumes/sec/node, BASELINE.json configs[{cfgi}] ({'ClassFine / CT-LiPro' if cfgi == 4 else 'VocabFine'} step)",
+           "value": round(world * units * args.steps / dt, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic (uniform [-1,1] volumes generated on device, random token ids, random labels; random-init weights)",
+           "config": {"workload": what, "global_batch": world * units, "text_len": args.text_len, "parallelism": f"dp{world}",
+                      "layers": f"{args.spatial_depth}+{args.temporal_depth}"},
+           "loss": round(float(loss), 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}
+    if world > 1:
+        out["config"]["note"] = ("every rank runs its own volumes; the head / model replicas are NOT gradient-synchronised in this workload line "
+                                 "(the reference uses nn.DataParallel here): throughput of independent replicas")
+    if timing:
+        out["roofline"] = timing
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = run_finetune_cpu_bounded(args)
+        print(json.dumps(out), flush=True)
+
+
+def finetune_cpu_worker(args):
+    """Child process: the CPU oracle (a restatement of the reference modules, kind "port") on a bounded sample of the fine-tuning step."""
+    from oracle import ctclip_oracle as O
+    from transformers import BertConfig, BertModel
+    import torch.nn.functional as F
+    import ct_clip_amd
+    cores = min(args.cpu_threads, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+    torch.set_num_threads(cores)
+    hw = args.image // FULL["patch"]
+    torch.manual_seed(0)
+    enc = ct_clip_amd.CTViT(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                            temporal_patch_size=FULL["tpatch"], spatial_depth=args.spatial_depth, temporal_depth=args.temporal_depth,
+                            dim_head=FULL["dim_head"], heads=FULL["heads"], compute_dtype=torch.float32)
+    bert = BertModel(BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    sd = {"temperature": torch.tensor(1.0)}
+    sd.update({"visual_transformer." + k: v for k, v in enc.state_dict().items()})
+    sd.update({"text_transformer." + k: v for k, v in bert.state_dict().items()})
+    sd["to_text_latent.weight"] = torch.randn(FULL["dim_latent"], 768) * 0.02
+    sd["to_visual_latent.weight"] = torch.randn(FULL["dim_latent"], hw * hw * FULL["dim"]) * 0.002
+    cfg = O.OracleConfig(dim=FULL["dim"], codebook_size=FULL["codebook"], image_size=args.image, patch_size=FULL["patch"],
+                         temporal_patch_size=FULL["tpatch"], spatial_depth=args.spatial_depth, temporal_depth=args.temporal_depth,
+                         dim_head=FULL["dim_head"], heads=FULL["heads"], bert_layers=12, bert_heads=12, dim_latent=FULL["dim_latent"])
+    g = torch.Generator().manual_seed(1234)
+    video = torch.rand(1, 1, args.frames, args.image, args.image, generator=g) * 2 - 1
+    t0 = time.time()
+    if args.finetune_cpu_worker == "lipro":
+        with torch.no_grad():
+            toks, _ = O.ctvit_forward(sd, cfg, video, training=True)
+            lat = O.l2norm(F.linear(toks.mean(dim=1).reshape(1, -1), sd["to_visual_latent.weight"]))
+        W = (torch.randn(18, FULL["dim_latent"]) * 0.05).requires_grad_(True)
+        b = torch.zeros(18, requires_grad=True)
+        loss = F.binary_cross_entropy_with_logits(F.linear(F.relu(lat), W, b), torch.zeros(1, 18), pos_weight=torch.ones(18))
+        loss.backward()
+        dt = time.time() - t0
+        rec = dict(value=round(1 / dt, 5), unit="volumes/s", cores=cores, kind="port", seconds=round(dt, 1),
+                   sample=f"oracle image tower forward (train mode) + head forward/backward on ONE volume, {args.spatial_depth}+{args.temporal_depth} layers, "
+                          f"f32, torch CPU kernels, {cores} threads: {dt:.1f} s (the step is linear in the batch)")
+    else:
+        ids, mask = synth_text(2, args.text_len, g, "cpu")
+        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "vq._codebook" not in k and not k.endswith(".beta")
+                                                       and "position_ids" not in k) for k, v in sd.items()}
+        enc_text = O.bert_forward(leaves, cfg, ids, mask)
+        toks, _ = O.ctvit_forward(leaves, cfg, video, training=True)
+        tl = O.l2norm(F.linear(enc_text[:, 0, :], leaves["to_text_latent.weight"]))
+        il = O.l2norm(F.linear(toks.mean(dim=1).reshape(1, -1), leaves["to_visual_latent.weight"]))
+        sim = O.similarity_no_loss(tl, il, leaves["temperature"])
+        loss = F.mse_loss(F.softmax(sim, dim=0), torch.tensor([1.0, 0.0]))
+        loss.backward()
+        dt = time.time() - t0
+        rec = dict(value=round(1 / (18 * dt), 5), unit="volumes/s", cores=cores, kind="port", seconds=round(dt, 1),
+                   sample=f"oracle forward + backward of ONE of the 18 prompt pairs of one volume ({args.spatial_depth}+{args.temporal_depth} layers + BERT-base, "
+                          f"T={args.text_len}, f32, {cores} threads): {dt:.1f} s; value = 1 / (18 x that) -- a step is 18 such forwards and their backwards")
+    print("CPU_BASELINE " + json.dumps(rec), flush=True)
+
+
+def run_finetune_cpu_bounded(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--finetune-cpu-worker", args.workload,
+           "--spatial-depth", str(args.spatial_depth), "--temporal-depth", str(args.temporal_depth), "--cpu-threads", str(args.cpu_threads),
+           "--text-len", str(args.text_len), "--image", str(args.image), "--frames", str(args.frames)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="volumes/s", kind="port", cores=args.cpu_threads, sample=f"CPU sample did not finish within {args.cpu_timeout:.0f} s")
+    for line in res.stdout.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    return dict(value=None, unit="volumes/s", kind="port", sample="CPU baseline failed: " + res.stderr[-300:])
+
+
 def self_launch(n):
     """`python bench.py --gpus N` (N > 1) with no launcher around it: run this same command line under
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and pass the ranks'
@@ -352,8 +530,25 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10, help="extra steps after the timed region in which every GEMM launch is event-timed (roofline)")
     ap.add_argument("--gemm-probe", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--also-reference-depth", action="store_true", help="additionally time the reference-true 4+4-layer model")
+    ap.add_argument("--also-reference-depth", action="store_true", help=argparse.SUPPRESS)      # (default on since round 3; kept for old command lines)
+    ap.add_argument("--no-reference-depth", action="store_true", help="skip the second timed configuration (reference scripts' 4+4 layers)")
+    ap.add_argument("--workload", default="train", choices=["train", "lipro", "vocabfine"],
+                    help="train = BASELINE.json configs[1]/[2] (default); lipro = configs[4] (ClassFine / CT-LiPro step, frozen tower, batch 16); "
+                         "vocabfine = configs[3] (VocabFine step: 18 prompt pairs per volume)")
+    ap.add_argument("--finetune-cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.workload != "train":      # the fine-tuning scripts build the towers with 4+4 layers (ct_lipro_train.py:47-51, ct_vocabfine_train.py:29-33)
+        if "--spatial-depth" not in sys.argv:
+            args.spatial_depth = 4
+        if "--temporal-depth" not in sys.argv:
+            args.temporal_depth = 4
+        if "--batch" not in sys.argv:
+            args.batch = 16 if args.workload == "lipro" else 1
+        if "--steps" not in sys.argv:
+            args.steps = 20 if args.workload == "lipro" else 5
+    if args.finetune_cpu_worker:
+        finetune_cpu_worker(args)
+        return
 
     if args.cpu_baseline_worker:      # child process: time the oracle and print its JSON lines
         cpu_baseline(args, args.text_len)
@@ -385,6 +580,12 @@ def main():
 
     from ct_clip_amd import backend
     be = backend.get()
+    if args.workload != "train":
+        finetune_bench(args, device, dtype, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     def run_config(sdepth, tdepth, steps, warmup, profile_gemm):
         args.spatial_depth, args.temporal_depth = sdepth, tdepth
@@ -487,10 +688,13 @@ def main():
             out["attn_block"] = attention_block_util(args, device, dtype)
         except Exception as e:      # never lose the headline number to the auxiliary measurement
             out["attn_block"] = {"error": repr(e)[:300]}
-    if args.also_reference_depth:
-        dt2, loss2, _, _ = run_config(4, 4, args.steps, max(1, args.warmup), False)
-        out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps / dt2, 3), "unit": "volumes/s",
-                                      "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5)}
+    if not args.no_reference_depth and (sdepth, tdepth) != (4, 4):
+        # the reference's own scripts build 4+4 layers (run_train.py:17-27): the same step at that depth, same batch, fewer timed steps
+        dt2, loss2, _, _ = run_config(4, 4, max(5, args.steps // 3), max(1, args.warmup), False)
+        args.steps_ref = max(5, args.steps // 3)
+        out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps_ref / dt2, 3), "unit": "volumes/s", "steps": args.steps_ref,
+                                      "ms_per_step": round(dt2 / args.steps_ref * 1e3, 3), "loss": round(loss2, 5),
+                                      "workload": "the same train step with the reference scripts' 4+4 transformer layers (run_train.py:17-27)"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline_bounded(args, sdepth, tdepth)

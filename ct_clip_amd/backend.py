@@ -68,7 +68,7 @@ class HipBackend:
         self.lib = _lib.load()
         self._ws = {}
         self._gemm_events = None
-        self._shadow_table = None
+        self._shadow_tables = {}
 
     # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
     def start_gemm_timing(self):
@@ -476,21 +476,24 @@ class HipBackend:
         return du
 
     def shadow_refresh(self, jobs, version):
-        """jobs: [dict(src f32 (rows, cols) parameter, dst bf16 2-D view, map, aux, transposed)] -> one launch (csrc/shadow.hip).  The
-        device-side job table is rebuilt only when `version` changes (the pointers are those of parameters / cached shadows)."""
-        tab = self._shadow_table
-        if tab is None or tab[0] != version:
+        """jobs: [dict(src_ptr / src_stride / src_shape of an f32 (rows, cols) parameter, dst bf16 2-D view, map, aux, transposed)] -> one
+        launch (csrc/shadow.hip).  The device-side job table is rebuilt only when `version` changes (functional.refresh_shadows validates
+        the raw pointers before every call)."""
+        tab = self._shadow_tables.get(version)
+        if tab is None:
             rows, tile0 = [], 0
             for j in jobs:
-                src, dst = j["src"], j["dst"]
-                assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and dst.dtype == torch.bfloat16 and dst.stride(1) == 1
-                rows.append([src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), src.shape[0], src.shape[1], dst.shape[0], dst.shape[1],
+                dst = j["dst"]
+                assert len(j["src_shape"]) == 2 and dst.dtype == torch.bfloat16 and dst.stride(1) == 1
+                rows.append([j["src_ptr"], dst.data_ptr(), j["src_stride"], dst.stride(0), j["src_shape"][0], j["src_shape"][1], dst.shape[0], dst.shape[1],
                              int(j["map"]), int(j["aux"]), int(j["transposed"]), tile0])
                 tile0 += ((dst.shape[0] + 63) // 64) * ((dst.shape[1] + 63) // 64)
             dev = jobs[0]["dst"].device
             table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            tab = self._shadow_table = (version, table, len(rows), tile0)
-        _, table, n, ntiles = tab
+            if len(self._shadow_tables) > 8:
+                self._shadow_tables.clear()
+            tab = self._shadow_tables[version] = (table, len(rows), tile0)
+        table, n, ntiles = tab
         _lib.check(self.lib.ctclip_shadow_refresh(_p(table), n, ntiles, _stream()), "ctclip_shadow_refresh")
 
     def gemm_geglu_bwd(self, x, w_il, dg, hp):

@@ -67,11 +67,26 @@ class CTCLIP(nn.Module):
         if hasattr(image_encoder, "compute_dtype"):
             image_encoder.compute_dtype = self.compute_dtype
         self.gather_negatives = gather_negatives
+        # dtype of the text tower's activations / GEMM operands: None = the compute dtype; CTCLIP_TEXT_DTYPE=f32 (or the attribute) keeps BERT in
+        # f32 while the image tower runs in bf16 (M = B*T rows on a side stream: 1 % of the step's FLOPs, most of the teacher-forced loss error)
+        import os
+        env = os.environ.get("CTCLIP_TEXT_DTYPE", "").lower()
+        self.text_compute_dtype = torch.float32 if env in ("f32", "fp32", "float32") else torch.bfloat16 if env in ("bf16", "bfloat16") else None
+
+    def _text_dtype(self):
+        return self.text_compute_dtype or self.compute_dtype
 
     def load(self, path):
+        """ct_clip.py:593-597.  Additive: the trainer's periodic checkpoints are written from the DDP-wrapped model with
+        `accelerator.get_state_dict(..., unwrap=False)` (CTCLIPTrainer.py:331-337), i.e. every key carries a `module.` prefix when the run
+        was multi-GPU; such a dict is accepted as well (the prefix is stripped when ALL keys have it)."""
         path = Path(path)
         assert path.exists()
-        self.load_state_dict(torch.load(str(path)))
+        pt = torch.load(str(path), map_location="cpu")
+        if len(pt) and all(k.startswith("module.") for k in pt):
+            pt = {k[len("module."):]: v for k, v in pt.items()}
+        self.load_state_dict(pt)
+        Fn.bump_weight_epoch()
 
     def _text_stream(self, device):
         import os
@@ -94,7 +109,7 @@ class CTCLIP(nn.Module):
     def encode_text(self, text):
         """HF BatchEncoding-like (.input_ids, .attention_mask) -> (Bt, dim_latent) l2-normalised f32 text latents (ct_clip.py:685-686,762,771)."""
         ids, mask = text.input_ids, text.attention_mask
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self.compute_dtype)
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self._text_dtype())
         cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
         return Fn.l2norm_f32(Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32))
 
@@ -111,7 +126,7 @@ class CTCLIP(nn.Module):
         # freeze_* are accepted and ignored exactly as in the reference (ct_clip.py:709-715)
         if aug_text is not None or aug_image is not None:
             raise NotImplementedError("multiview augmentation is never used by CT-CLIP's entry scripts")
-        dt = self.compute_dtype
+        dt = self._text_dtype()
         ids, mask = text.input_ids, text.attention_mask
         Bt, T = ids.shape
         # The text tower (M = B*T rows: far too small to fill 256 CUs) runs on a side stream underneath the image tower;

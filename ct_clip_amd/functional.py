@@ -31,80 +31,119 @@ def round_up(x, m):
 _WEIGHT_EPOCH = 0
 
 
-def bump_weight_epoch():
-    """Called by the fused optimiser (which updates parameters through raw kernels, invisible to torch's version
-    counters) so that every weight shadow is rebuilt on next use."""
+def bump_weight_epoch(params=None):
+    """The fused optimiser updates parameters through raw kernels, invisible to torch's version counters: it calls this so that
+    the weight shadows of ITS parameters are rebuilt (params = the tensors it updated).  Without arguments every shadow of the
+    process is invalidated (checkpoint load, tests)."""
     global _WEIGHT_EPOCH
-    _WEIGHT_EPOCH += 1
+    if params is None:
+        _WEIGHT_EPOCH += 1
+        return
+    for p in params:
+        p.__dict__["_ctclip_epoch"] = p.__dict__.get("_ctclip_epoch", 0) + 1
 
 
-def shadow(param, tag, dtype, maker, recipe=None):
-    """Cached derived tensor of a parameter (recomputed when the parameter is modified).
+def _stamp(tensors):
+    return (_WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr(), t.__dict__.get("_ctclip_epoch", 0)) for t in tensors)
+
+
+def shadow(param, tag, dtype, maker, recipe=None, deps=()):
+    """Cached derived tensor of a parameter (recomputed when the parameter -- or one of `deps`, the other parameters it is built
+    from -- is modified).
     recipe: how the batched refresh (refresh_shadows) rebuilds this tensor from f32 master weights -- a list of jobs
     (source parameter, first destination row, destination rows, destination columns, map, aux, transposed), see csrc/shadow.hip."""
     cache = param.__dict__.setdefault("_ctclip_shadow", {})
     key = (tag, dtype)
     ent = cache.get(key)
-    stamp = (param._version, param.data_ptr(), _WEIGHT_EPOCH)
+    stamp = _stamp((param,) + tuple(deps))
     if ent is not None and ent[0] == stamp:
         return ent[1]
     with torch.no_grad():
         val = maker()
     cache[key] = (stamp, val)
     if recipe is not None and dtype == torch.bfloat16 and val.dim() == 2 and val.stride(1) == 1 and _SHADOW_BATCH:
-        _register_shadow(param, key, recipe)
+        _register_shadow(param, key, recipe, deps)
     return val
 
 
 # ---- batched refresh: one launch after the optimiser step instead of one small launch per shadow in front of its first GEMM
 _SHADOW_BATCH = os.environ.get("CTCLIP_SHADOW_BATCH", "1") != "0"
-_SHADOW_PLAN = {}            # (id(owner parameter), key) -> (weakref(owner), key, [(weakref(source), row0, rows, cols, map, aux, transposed)])
-_SHADOW_JOBS = None          # cached job list for the backend (None = rebuild)
+_SHADOW_PLAN = {}            # (id(owner parameter), key) -> (weakref(owner), key, [(weakref(source), row0, rows, cols, map, aux, transposed)], [weakref(dep)])
+_SHADOW_PLAN_VERSION = 0     # bumped by every registration
+_SHADOW_JOBS = {}            # scope key -> cached job list for the backend
 _SHADOW_VERSION = 0
 MAP_PLAIN, MAP_GEGLU_SPLIT, MAP_GEGLU_INTERLEAVE = 0, 1, 2
 
 
-def _register_shadow(param, key, recipe):
-    global _SHADOW_JOBS
+def _register_shadow(param, key, recipe, deps=()):
+    global _SHADOW_PLAN_VERSION
     import weakref
-    _SHADOW_PLAN[(id(param), key)] = (weakref.ref(param), key, [(weakref.ref(src),) + tuple(rest) for src, *rest in recipe])
-    _SHADOW_JOBS = None
+    _SHADOW_PLAN[(id(param), key)] = (weakref.ref(param), key, [(weakref.ref(src),) + tuple(rest) for src, *rest in recipe],
+                                      [weakref.ref(d) for d in deps])
+    _SHADOW_PLAN_VERSION += 1
 
 
-def refresh_shadows():
-    """Rebuild every registered bf16 weight shadow in place from the current f32 parameters (ONE launch) and stamp it valid.
-    Called by the fused optimiser right after the parameter update; shadows without a recipe stay lazy."""
-    global _SHADOW_JOBS, _SHADOW_VERSION
+def _build_shadow_jobs(scope):
+    """-> (jobs, owners, checks).  Sources are held WEAKLY (a job keeps raw pointers; `checks` = (weakref(tensor), data_ptr) pairs that
+    refresh_shadows re-validates before every launch): a freed or re-based parameter rebuilds the list instead of being read stale."""
+    import weakref
+    jobs, owners, checks = [], [], []
+    for pk, (pref, key, recipe, deprefs) in list(_SHADOW_PLAN.items()):
+        param = pref()
+        ent = param.__dict__.get("_ctclip_shadow", {}).get(key) if param is not None else None
+        srcs = [r[0]() for r in recipe]
+        if ent is None or any(s_ is None for s_ in srcs):
+            del _SHADOW_PLAN[pk]           # the module is gone
+            continue
+        val = ent[1]
+        if scope is not None and not any(id(s_) in scope for s_ in srcs):
+            continue                       # none of this shadow's sources belongs to the calling optimiser: untouched by its step
+        if any(s_.device != val.device or s_.dtype != torch.float32 for s_ in srcs):
+            continue                       # (a model moved to another device keeps its lazy makers)
+        for src, (_, row0, rows, cols, mp, aux, tr) in zip(srcs, recipe):
+            dst = val[row0:row0 + rows, :cols]
+            jobs.append(dict(src_ref=weakref.ref(src), src_ptr=src.data_ptr(), src_stride=src.stride(0), src_shape=tuple(src.shape), dst=dst,
+                             map=mp, aux=aux, transposed=bool(tr)))
+            checks.append((weakref.ref(src), src.data_ptr()))
+        checks.append((weakref.ref(val), val.data_ptr()))
+        owners.append((pref, key, deprefs))
+    return jobs, owners, checks
+
+
+def refresh_shadows(params=None):
+    """Rebuild the registered bf16 weight shadows in place from the current f32 parameters (ONE launch) and stamp them valid.
+    Called by the fused optimiser right after its parameter update with params = the parameters it owns: only shadows built from
+    them are touched (a frozen tower keeps its operands; another optimiser's shadows are its own business).  params=None: every
+    registered shadow.  Shadows without a recipe stay lazy."""
+    global _SHADOW_VERSION
     if not _SHADOW_BATCH or not _SHADOW_PLAN:
         return
-    if _SHADOW_JOBS is None:
-        jobs, owners = [], []
-        for pk, (pref, key, recipe) in list(_SHADOW_PLAN.items()):
-            param = pref()
-            ent = param.__dict__.get("_ctclip_shadow", {}).get(key) if param is not None else None
-            srcs = [r[0]() for r in recipe]
-            if ent is None or any(s_ is None for s_ in srcs):
-                del _SHADOW_PLAN[pk]           # the module is gone
-                continue
-            val = ent[1]
-            for src, (_, row0, rows, cols, mp, aux, tr) in zip(srcs, recipe):
-                jobs.append(dict(src=src.detach(), dst=val[row0:row0 + rows, :cols], map=mp, aux=aux, transposed=bool(tr)))
-            owners.append((pref, key))
-        _SHADOW_JOBS = (jobs, owners)
+    scope = None if params is None else frozenset(id(p) for p in params)
+    ent = _SHADOW_JOBS.get(scope)
+    if ent is not None:
+        pv, jobs, owners, checks, version = ent
+        if pv != _SHADOW_PLAN_VERSION or any(r() is None or r().data_ptr() != ptr for r, ptr in checks):
+            ent = None
+    if ent is None:
+        jobs, owners, checks = _build_shadow_jobs(scope)
         _SHADOW_VERSION += 1
-    jobs, owners = _SHADOW_JOBS
+        version = _SHADOW_VERSION
+        if len(_SHADOW_JOBS) > 8:
+            _SHADOW_JOBS.clear()
+        _SHADOW_JOBS[scope] = (_SHADOW_PLAN_VERSION, jobs, owners, checks, version)
     if not jobs:
         return
     with torch.no_grad():
-        B().shadow_refresh(jobs, _SHADOW_VERSION)
-    for pref, key in owners:
+        B().shadow_refresh(jobs, version)
+    for pref, key, deprefs in owners:
         param = pref()
-        if param is None:
+        deps = [d() for d in deprefs]
+        if param is None or any(d is None for d in deps):
             continue
         cache = param.__dict__.get("_ctclip_shadow", {})
         ent = cache.get(key)
         if ent is not None:
-            cache[key] = ((param._version, param.data_ptr(), _WEIGHT_EPOCH), ent[1])
+            cache[key] = (_stamp((param,) + tuple(deps)), ent[1])
 
 
 def plain_shadow(weight, dtype, kpad=None, npad=None):
@@ -852,8 +891,10 @@ class QkvSdpaFn(Function):
                 be.convert_pad(w.detach(), N, K, x.dtype, out=out[i * N:(i + 1) * N])
             return out
         # (the stamp of the cache entry is wq's; the fused optimiser bumps the weight epoch, load_state_dict touches all three)
-        wsh = shadow(wq, ("qkv", id(wk), id(wv)), x.dtype, make_w, recipe=[(w, i * N, N, K, MAP_PLAIN, 0, False) for i, w in enumerate((wq, wk, wv))])
-        bias = shadow(bq, ("qkv_bias", id(bk), id(bv)), torch.float32, lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]).float())
+        wsh = shadow(wq, ("qkv", id(wk), id(wv)), x.dtype, make_w, recipe=[(w, i * N, N, K, MAP_PLAIN, 0, False) for i, w in enumerate((wq, wk, wv))],
+                     deps=(wk, wv))
+        bias = shadow(bq, ("qkv_bias", id(bk), id(bv)), torch.float32, lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]).float(),
+                      deps=(bk, bv))
         qkv = be.gemm(x, wsh, bias=bias)
         q, k, v = qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
         vt = be.head_transpose(v, nseq, H, L, D)

@@ -114,8 +114,8 @@ class FusedAdam:
         self.lr = self.param_groups[0]["lr"]          # learning-rate schedules write param_groups (finetune.cosine_lr)
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                      self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4)
-        Fn.bump_weight_epoch()
-        Fn.refresh_shadows()          # every bf16 GEMM operand rebuilt from the new f32 weights in one launch
+        Fn.bump_weight_epoch(self.params)
+        Fn.refresh_shadows(self.params)   # every bf16 GEMM operand of THIS optimiser's parameters rebuilt from the new f32 weights in one launch
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names,
@@ -208,15 +208,19 @@ class CTClipTrainer(nn.Module):
     def save(self, path):
         if not self.is_main:
             return
-        torch.save(dict(model=self.CTClip.state_dict(), optim=self.optim.state_dict()), path)
+        # CTCLIPTrainer.py:205-213 keeps {model, optim}; `steps` is additive so that a resumed run continues its counters
+        torch.save(dict(model=self.CTClip.state_dict(), optim=self.optim.state_dict(), steps=self.steps.detach().cpu()), path)
 
     def load(self, path):
         path = Path(path)
         assert path.exists()
         pkg = torch.load(path, weights_only=False)
-        self.CTClip.load_state_dict(pkg["model"])
+        self.CTClip.load_state_dict(pkg["model"])      # in place: the parameters stay views of the optimiser's flat buffer
         self.optim.load_state_dict(pkg["optim"])
+        if "steps" in pkg:
+            self.steps.copy_(pkg["steps"])
         Fn.bump_weight_epoch()
+        Fn.refresh_shadows()                            # every bf16 GEMM operand rebuilt from the restored f32 weights
 
     def print(self, msg):
         if self.is_main:

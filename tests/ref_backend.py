@@ -354,7 +354,7 @@ class RefBackend:
     def shadow_refresh(self, jobs, version):
         """csrc/shadow.hip restated: dst = gather (plain: dst[r][c] = src[map(r)][c]; transposed: dst[r][c] = src[map(c)][r]), 0 outside."""
         for j in jobs:
-            src, dst, mp, aux, tr = j["src"].float(), j["dst"], j["map"], j["aux"], j["transposed"]
+            src, dst, mp, aux, tr = j["src_ref"]().detach().float(), j["dst"], j["map"], j["aux"], j["transposed"]
             ext = dst.shape[1] if tr else dst.shape[0]          # the mapped extent
             other = dst.shape[0] if tr else dst.shape[1]        # extent along the source columns
             n = torch.arange(ext)

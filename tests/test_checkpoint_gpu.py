@@ -1,0 +1,98 @@
+"""SURVEY.md section 8(f) rank 4 on the device: latent export (scripts/forward_data.py:131-148), trainer checkpoint round trip
+(scripts/CTCLIPTrainer.py:205-223) and the `module.`-prefixed model checkpoints the reference trainer writes from a DDP-wrapped model
+(CTCLIPTrainer.py:331-337, `get_state_dict(..., unwrap=False)`) into CTCLIP.load (ct_clip.py:593-597)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import TextBatch, build_model  # noqa: E402
+from tests.test_zero_shot_cpu import StubTokenizer  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_latent_export_equals_return_latents_on_device(golden, tmp_path, dtype):
+    """text/<acc>.npz and image/<acc>.npz hold exactly CTCLIP.forward(return_latents=True)[0:2] of the HIP towers; f32 latents also
+    match the real reference's eval latents of the golden fixture."""
+    from ct_clip_amd.forward_data import CTClipInference as Export
+    g = golden("tiny")
+    c = g["config"]
+    clip = build_model(c, g["state_dict"], DEV, dtype).eval()
+    tok = StubTokenizer(c["vocab"], c["T"])
+    ds = [(g["video"][i], f"report number {i} no acute findings", torch.zeros(1, 2), f"case_{i}") for i in range(g["video"].shape[0])]
+    Export(clip, results_folder=str(tmp_path / "lat"), dataset=ds, tokenizer=tok, max_text_len=c["T"]).infer()
+    for i, (vol, text, _, name) in enumerate(ds):
+        with torch.no_grad():
+            tl, il, _ = clip(tok([text], max_length=c["T"]).to(DEV), vol[None].to(DEV), device=DEV, return_latents=True)
+        np.testing.assert_array_equal(np.load(tmp_path / "lat" / "text" / f"{name}.npz")["arr"], tl.float().cpu().numpy())
+        np.testing.assert_array_equal(np.load(tmp_path / "lat" / "image" / f"{name}.npz")["arr"], il.float().cpu().numpy())
+        if dtype == torch.float32:       # the image latent does not depend on the text: pinned by the real reference's eval latents
+            np.testing.assert_allclose(il.cpu().numpy(), g["eval_image_latents"][i:i + 1].numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainer_checkpoint_round_trip_is_bit_exact(golden, tmp_path, dtype):
+    """Step 1, save, step 2 -- against: fresh model + fresh trainer, load, step 2.  Loss of step 2, every parameter, both Adam moments,
+    the VQ buffers and the `steps` buffer must be bit-identical (the flat f32 state and the bf16 weight shadows are restored exactly)."""
+    import ct_clip_amd
+    g = golden("tiny")
+    c = g["config"]
+    text = TextBatch(g["input_ids"].to(DEV), g["attention_mask"].to(DEV))
+    video = g["video"].to(DEV)
+
+    def make(state):
+        clip = build_model(c, state, DEV, dtype)
+        clip.train()
+        return clip, ct_clip_amd.CTClipTrainer(clip, num_train_steps=3, batch_size=2, tokenizer=object(), lr=1e-3, train_dataset=[0], evaluate=False,
+                                               checkpoint=False, results_folder=str(tmp_path / "res"), num_workers=0)
+
+    def one_step(tr):
+        loss = tr.forward_backward(video, text)
+        tr.optim.step(tr.max_grad_norm)
+        tr.optim.zero_grad()
+        tr.steps += 1
+        return float(loss.detach())
+
+    clip_a, tr_a = make(g["state_dict"])
+    l1 = one_step(tr_a)
+    ck = str(tmp_path / "ck.pt")
+    tr_a.save(ck)
+    l2 = one_step(tr_a)
+    torch.cuda.synchronize()
+    ref = {k: v.detach().clone() for k, v in clip_a.state_dict().items()}
+    ref_m, ref_v = tr_a.optim.exp_avg.clone(), tr_a.optim.exp_avg_sq.clone()
+
+    perturbed = {k: (v + 0.01 if v.is_floating_point() else v) for k, v in g["state_dict"].items()}      # NOT the checkpoint's weights
+    clip_b, tr_b = make(perturbed)
+    tr_b.load(ck)
+    assert int(tr_b.steps.item()) == 1 and tr_b.optim.step_count == 1
+    l2b = one_step(tr_b)
+    torch.cuda.synchronize()
+    assert l2b == l2 and l2 != l1
+    sd_b = clip_b.state_dict()
+    for k, v in ref.items():
+        assert torch.equal(sd_b[k], v), k
+    assert torch.equal(tr_b.optim.exp_avg, ref_m) and torch.equal(tr_b.optim.exp_avg_sq, ref_v)
+    assert int(tr_b.steps.item()) == 2
+
+
+def test_ctclip_load_accepts_the_ddp_prefixed_checkpoint(golden, tmp_path):
+    g = golden("tiny")
+    c = g["config"]
+    clip = build_model(c, g["state_dict"], DEV, torch.float32).eval()
+    plain, wrapped = str(tmp_path / "plain.pt"), str(tmp_path / "module.pt")
+    sd = {k: v.cpu() for k, v in clip.state_dict().items()}
+    torch.save(sd, plain)
+    torch.save({"module." + k: v for k, v in sd.items()}, wrapped)            # CTCLIPTrainer.py:331-337 under DDP
+    text = TextBatch(g["input_ids"].to(DEV), g["attention_mask"].to(DEV))
+    with torch.no_grad():
+        want = clip(text, g["video"].to(DEV), device=DEV, return_latents=True)[1]
+    for path in (plain, wrapped):
+        other = build_model(c, None, DEV, torch.float32).eval()
+        other.load(path)
+        with torch.no_grad():
+            got = other(text, g["video"].to(DEV), device=DEV, return_latents=True)[1]
+        assert torch.equal(got, want), path

@@ -1,0 +1,86 @@
+"""The drop-in boundary against the reference's OWN entry scripts: every constructor call of CTViT / CTCLIP /
+CTClipTrainer / CTClipInference / ImageLatentsClassifier that the reference scripts make is parsed out of the script source and bound
+against the signature of the drop-in class (inspect.Signature.bind: unknown keyword -> TypeError), and every method the scripts call on
+those objects must exist.  Runs where /root/reference is present (the build container); the GPU box has no reference and skips."""
+import ast
+import inspect
+import os
+import sys
+
+import pytest
+
+REF = "/root/reference/scripts"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is not on this machine")
+
+
+def _dropin(name):
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        if name == "CTViT":
+            from transformer_maskgit import CTViT as cls
+        elif name == "CTCLIP":
+            from ct_clip import CTCLIP as cls
+        elif name == "CTClipTrainer":
+            from CTCLIPTrainer import CTClipTrainer as cls
+        elif name == "ImageLatentsClassifier":
+            from ct_clip_amd.finetune import ImageLatentsClassifier as cls
+        else:
+            raise KeyError(name)
+        return cls
+    finally:
+        sys.path.pop(0)
+
+
+def _calls(path, names):
+    tree = ast.parse(open(path).read())
+    out = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in names:
+            out.append((node.func.id, len(node.args), [k.arg for k in node.keywords]))
+    return out
+
+
+SCRIPTS = ["run_train.py", "run_zero_shot.py", "run_forward_data.py", "ct_lipro_train.py", "ct_vocabfine_train.py", "ct_lipro_inference.py"]
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_reference_script_constructs_against_the_dropin(script):
+    path = os.path.join(REF, script)
+    if not os.path.exists(path):
+        pytest.skip(f"{script} not in this reference checkout")
+    calls = _calls(path, {"CTViT", "CTCLIP", "CTClipTrainer", "ImageLatentsClassifier"})
+    assert calls, f"{script}: no constructor calls found"
+    for name, npos, kws in calls:
+        cls = _dropin(name)
+        sig = inspect.signature(cls.__init__)
+        sig.bind(None, *([object()] * npos), **{k: object() for k in kws})      # raises TypeError on an unknown / missing argument
+    seen = {c[0] for c in calls}
+    assert {"CTViT", "CTCLIP"} <= seen
+
+
+def test_run_train_calls_exist_and_inference_ctor_binds():
+    """run_train.py:17-58: the three constructions and trainer.train(); run_zero_shot.py / run_forward_data.py: CTClipInference(...).infer()."""
+    tr = _dropin("CTClipTrainer")
+    for m in ("train", "train_step", "save", "load", "print"):
+        assert callable(getattr(tr, m)), m
+    assert isinstance(getattr(tr, "is_main"), property)
+    ctclip = _dropin("CTCLIP")
+    assert callable(ctclip.load) and callable(ctclip.forward)
+    fwd = inspect.signature(ctclip.forward)
+    for kw in ("text", "image", "device", "return_loss", "return_encodings", "return_latents", "freeze_image_encoder", "freeze_text_encoder",
+               "text_to_image", "aug_text", "aug_image"):                            # ct_clip.py:614-627
+        assert kw in fwd.parameters, kw
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        import forward_data
+        import zero_shot
+    finally:
+        sys.path.pop(0)
+    for mod, script in ((zero_shot, "run_zero_shot.py"), (forward_data, "run_forward_data.py")):
+        path = os.path.join(REF, script)
+        if not os.path.exists(path):
+            continue
+        for name, npos, kws in _calls(path, {"CTClipInference"}):
+            inspect.signature(mod.CTClipInference.__init__).bind(None, *([object()] * npos), **{k: object() for k in kws})
+        assert callable(mod.CTClipInference.infer)

@@ -87,3 +87,15 @@ def test_latent_export_matches_return_latents(golden, ref_backend, tmp_path):
         tl, il, _ = clip(tok(["no acute findings"], max_length=32), vol[None], device=torch.device("cpu"), return_latents=True)
     np.testing.assert_allclose(np.load(tmp_path / "lat" / "text" / "case_7.npz")["arr"], tl.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(np.load(tmp_path / "lat" / "image" / "case_7.npz")["arr"], il.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_ctclip_load_strips_the_ddp_prefix(golden, ref_backend, tmp_path):
+    """CTCLIPTrainer.py:331-337 saves `get_state_dict(model, unwrap=False)`: under DDP every key starts with `module.`."""
+    g = golden("tiny")
+    clip = build_model(g["config"], g["state_dict"], torch.device("cpu"), torch.float32)
+    sd = clip.state_dict()
+    torch.save({"module." + k: v for k, v in sd.items()}, tmp_path / "m.pt")
+    other = build_model(g["config"], None, torch.device("cpu"), torch.float32)
+    other.load(tmp_path / "m.pt")
+    for k, v in sd.items():
+        assert torch.equal(other.state_dict()[k], v), k
