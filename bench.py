@@ -360,13 +360,15 @@ def finetune_setup(args, device, dtype, rank):
 
     def step():
         trainer.scheduler(trainer.step)
-        losses, _ = trainer.forward_backward(vol, pairs)
+        losses, _ = trainer.forward_backward(vol, pairs, fused=not args.vocabfine_literal)
         trainer.optim.step(None)
         trainer.step += 1
         return losses[-1]
     what = (f"VocabFine step (ct_vocabfine_train.py:77-123): one volume {args.image}x{args.image}x{args.frames}, {npath} pathologies x (true, false) prompt "
-            f"(T={args.text_len}) = {npath} full CTCLIP forwards ({args.spatial_depth}+{args.temporal_depth} layers + BERT-base), softmax-MSE per group of 6, "
-            "3 backwards, AdamW on every parameter (end-to-end)")
+            f"(T={args.text_len}), softmax-MSE per group of 6, AdamW on every parameter (end-to-end), {args.spatial_depth}+{args.temporal_depth} layers + BERT-base; "
+            + ("the reference's loop literally: 18 full CTCLIP forwards, 3 backwards" if args.vocabfine_literal else
+               "same numbers from ONE pass of each tower per volume (the 18 forwards share weights and volume: image transformer once, 36 prompts as one "
+               "BERT batch, the quantiser's EMA sequence + pooling + latents re-applied per pathology, one backward of the summed group losses)"))
     return step, 1, what
 
 
@@ -535,6 +537,8 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "lipro", "vocabfine"],
                     help="train = BASELINE.json configs[1]/[2] (default); lipro = configs[4] (ClassFine / CT-LiPro step, frozen tower, batch 16); "
                          "vocabfine = configs[3] (VocabFine step: 18 prompt pairs per volume)")
+    ap.add_argument("--vocabfine-literal", action="store_true", help="vocabfine: the reference's loop literally (18 image-tower passes per volume) "
+                                                                       "instead of one pass of each tower per volume")
     ap.add_argument("--finetune-cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.workload != "train":      # the fine-tuning scripts build the towers with 4+4 layers (ct_lipro_train.py:47-51, ct_vocabfine_train.py:29-33)

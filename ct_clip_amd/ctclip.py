@@ -113,6 +113,13 @@ class CTCLIP(nn.Module):
         cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
         return Fn.l2norm_f32(Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32))
 
+    def text_latents_raw(self, ids, mask):
+        """(Bt, T) ids / mask -> (Bt, dim_latent) f32 text latents BEFORE l2norm (ct_clip.py:685-686,762,765), differentiable."""
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self._text_dtype())
+        cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
+        cls = Fn.grad_ready(cls, self.to_text_latent)
+        return Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)
+
     def encode_image(self, image, return_tokens=False):
         """(Bi, 1, F, H, W) volume -> (Bi, dim_latent) l2-normalised f32 image latents (ct_clip.py:715-767,771) [, the token grid]."""
         enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)

@@ -258,11 +258,9 @@ class CTViT(nn.Module):
         x = Fn.Permute0213Fn.apply(x.view(b, h * w, t, d)).view(-1, d)              # back to b t h w
         return x
 
-    def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
-                apply_grad_penalty=True, return_only_codebook_ids=False, return_encoded_tokens=False):
+    def tokens_before_vq(self, video):
+        """Patch embedding + spatial / temporal transformers (ctvit.py:385-395): -> ((b*t*h*w, dim) tokens in the compute dtype, (b, t, h, w))."""
         assert video.ndim == 5, "expected (b, c, frames, H, W)"
-        if mask is not None:
-            raise NotImplementedError("frame masks are never passed on the CT-CLIP path (ct_clip.py:715)")
         b, c, f, *image_dims = video.shape
         assert tuple(image_dims) == self.image_size
         assert f % self.temporal_patch_size == 0
@@ -272,7 +270,13 @@ class CTViT(nn.Module):
         video = video.to(device=e[2].weight.device, dtype=torch.float32).contiguous()
         tokens = Fn.PatchEmbedFn.apply(video, e[1].weight, e[1].bias, e[2].weight, e[2].bias, e[3].weight, e[3].bias,
                                        pt, p1, p2, self.compute_dtype)
-        tokens = self.encode(tokens, b, t, h, w)
+        return self.encode(tokens, b, t, h, w), (b, t, h, w)
+
+    def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
+                apply_grad_penalty=True, return_only_codebook_ids=False, return_encoded_tokens=False):
+        if mask is not None:
+            raise NotImplementedError("frame masks are never passed on the CT-CLIP path (ct_clip.py:715)")
+        tokens, (b, t, h, w) = self.tokens_before_vq(video)
         q, idx = self.vq(tokens)
         if return_only_codebook_ids:
             return idx.view(b, t, h, w)

@@ -188,21 +188,51 @@ class VocabFineTrainer:
         self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
         self.step = 0
 
-    def forward_backward(self, volume, token_pairs):
-        """token_pairs: one (true prompt, false prompt) token batch per pathology.  One backward per group of `group_size`
-        pathologies, gradients accumulate (ct_vocabfine_train.py:88-121).  Returns (losses, similarities)."""
+    def forward_backward(self, volume, token_pairs, fused=True):
+        """token_pairs: one (true prompt, false prompt) token batch per pathology.  Returns (losses per group, similarities per group);
+        the gradients of all groups accumulate in the parameters' .grad as in ct_vocabfine_train.py:88-121.
+
+        fused=False is the reference's loop literally: one full CTCLIP forward per pathology (18 image-tower passes over the SAME volume
+        with the SAME weights), one backward per group of `group_size`.
+        fused=True (default) computes the same numbers from ONE pass of each tower: within a step the weights do not change, so the image
+        transformer's output is identical in all 18 forwards -- only the vector quantiser differs (train mode: its EMA update after every
+        forward moves the codebook the next forward reads).  Hence: patch embedding + transformers once; all prompts through BERT as one
+        batch; the quantiser + pooling + latent projection re-applied per pathology in the reference's order (same EMA sequence); the group
+        losses summed and ONE backward (backward is linear in the incoming gradient, so the sum of the reference's three backwards equals
+        the backward of the summed loss).  M = 13 824 token rows per launch either way -- but 1 image-tower pass instead of 18."""
         model = self.model
         model.train()
         dev = model.temperature.device
         self.optim.zero_grad()
         losses, sims_all = [], []
+        if not fused:
+            for k in range(0, len(token_pairs), self.group_size):
+                sims = [model(tokens, volume, device=dev) for tokens in token_pairs[k:k + self.group_size]]     # (2,) each: true prompt first
+                st = torch.stack(sims)
+                loss = PairSoftmaxMseFn.apply(st)
+                loss.backward()
+                losses.append(loss.detach())
+                sims_all.append(st.detach())
+            return losses, sims_all
+        vt = model.visual_transformer
+        pre, (b, t, h, w) = vt.tokens_before_vq(volume)                              # once per volume
+        ids = torch.cat([tp.input_ids for tp in token_pairs]).to(dev)
+        mask = torch.cat([tp.attention_mask for tp in token_pairs]).to(dev)
+        text_lat = model.text_latents_raw(ids, mask)                                 # (2 P, Dl) f32, every prompt in one BERT batch
+        total = None
         for k in range(0, len(token_pairs), self.group_size):
-            sims = [model(tokens, volume, device=dev) for tokens in token_pairs[k:k + self.group_size]]     # (2,) each: true prompt first
+            sims = []
+            for j in range(k, min(k + self.group_size, len(token_pairs))):
+                q, _ = vt.vq(pre)                                                    # EMA update j: the next pathology reads the moved codebook
+                enc_image = Fn.PoolFn.apply(q.view(b, t, -1))
+                image_lat = Fn.visual_latent(enc_image, model.to_visual_latent.weight)
+                sims.append(Fn.LatentSimilarityFn.apply(text_lat[2 * j:2 * j + 2], image_lat, model.temperature))
             st = torch.stack(sims)
             loss = PairSoftmaxMseFn.apply(st)
-            loss.backward()
+            total = loss if total is None else total + loss
             losses.append(loss.detach())
             sims_all.append(st.detach())
+        total.backward()
         return losses, sims_all
 
     def train_step(self, volume, labels):

@@ -36,3 +36,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(ImportError, match="no PyTorch/CPU fallback"):
         _lib.load()
+
+
+def test_docs_state_the_header_entry_point_count():
+    """DESIGN.md / INTEGRATION.md quote the number of extern "C" entry points: it must be the header's (the docs drifted once: 71 vs 78)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ctclip_hip.h")).read()
+    n = len(re.findall(r"^[A-Za-z_][\w \*]*\bctclip_\w+\(", hdr, flags=re.M))
+    assert n >= 79
+    for doc in ("DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(root, doc)).read()
+        counts = {int(m) for m in re.findall(r"(\d+) `extern \"C\"`", text)} | {int(m) for m in re.findall(r"\((\d+) entry points\)", text)}
+        assert counts == {n}, (doc, counts, n)

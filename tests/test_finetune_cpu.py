@@ -53,13 +53,13 @@ def check_lipro(g, f, device, dtype, skip_text, tol):
     torch.testing.assert_close(probs.cpu(), L["eval_probs"], rtol=tol, atol=tol)
 
 
-def check_vocabfine(g, f, device, dtype, tol, gtol):
+def check_vocabfine(g, f, device, dtype, tol, gtol, fused=True):
     V = f["vocabfine"]
     clip = build_model(g["config"], g["state_dict"], device, dtype)
     tr = FT.VocabFineTrainer(clip, tokenize=None, lr=1e-5, wd=0.1, warmup_length=2, total_steps=10, pathologies=["a", "b", "c", "d"],
                              group_size=V["group"])
     pairs = [TextBatch(V["prompt_ids"][i].to(device), V["prompt_mask"][i].to(device)) for i in range(V["prompt_ids"].shape[0])]
-    losses, sims = tr.forward_backward(g["video"][:1].to(device), pairs)
+    losses, sims = tr.forward_backward(g["video"][:1].to(device), pairs, fused=fused)
     for a, b in zip(sims, V["sims"]):
         torch.testing.assert_close(a.cpu(), b, rtol=tol, atol=tol)
     for a, b in zip(losses, V["losses"]):
@@ -88,9 +88,11 @@ def test_lipro_matches_reference(ref_backend, skip_text):
     check_lipro(g, f, torch.device("cpu"), torch.float32, skip_text, 2e-4)
 
 
-def test_vocabfine_matches_reference(ref_backend):
+@pytest.mark.parametrize("fused", [True, False])
+def test_vocabfine_matches_reference(ref_backend, fused):
+    """fused: one pass of each tower per volume; not fused: the reference's loop literally.  Both against the REAL reference's loop."""
     g, f = load()
-    check_vocabfine(g, f, torch.device("cpu"), torch.float32, 2e-4, 5e-3)
+    check_vocabfine(g, f, torch.device("cpu"), torch.float32, 2e-4, 5e-3, fused=fused)
 
 
 def test_cosine_lr_schedule():

@@ -16,9 +16,11 @@ def test_lipro_f32_matches_reference(skip_text):
     check_lipro(g, f, DEV, torch.float32, skip_text, 5e-4)
 
 
-def test_vocabfine_f32_matches_reference():
+@pytest.mark.parametrize("fused", [True, False])
+def test_vocabfine_f32_matches_reference(fused):
+    """fused = one pass of each tower per volume (default); not fused = the reference's 18-forward loop literally."""
     g, f = load()
-    check_vocabfine(g, f, DEV, torch.float32, 5e-4, 1e-2)
+    check_vocabfine(g, f, DEV, torch.float32, 5e-4, 1e-2, fused=fused)
 
 
 def test_lipro_bf16_stays_close():
