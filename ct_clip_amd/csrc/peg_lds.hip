@@ -158,7 +158,10 @@ __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
 template <int TB, int D3, int DIR>
 __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                                 const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                                                int D1, int D2, int C, int ntile) {
+                                                                                bf16_t* __restrict__ rres, int D1, int D2, int C, int ntile) {
+  // DIR: +1 forward, -1 grad-in, +2 forward that ALSO stores the rounding residue r = bf16(s - bf16(s)) of every output (s = the f32
+  // value of x + conv(x)): the residual stream's compensation term (ctclip_peg_fwd_comp, profiles/r03_bf16_error_budget.md)
+  constexpr bool COMP = DIR == 2;
   using G = Geo<TB, D3>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NT = (G::NCW + 1) * 64;
@@ -216,6 +219,7 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
   // stores: a buffer descriptor over the batch item, a scalar offset per plane and column, one 32-bit lane offset; rows past D2
   // (ragged last tile) get an offset beyond the descriptor and the hardware drops their stores -- no branches in the column loop
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(y + t.b * D1 * plane_elems, 0, (int)(D1 * plane_elems * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres_d = __builtin_amdgcn_make_buffer_rsrc((COMP ? rres : y) + t.b * D1 * plane_elems, 0, (int)(D1 * plane_elems * 2), 0x00020000);
   const uint32_t lane_off = t.beta0 + r < D2 ? (uint32_t)((((t.beta0 + r) * D3 + g0) * C + ch) * 2) : 0x80000000u;
 
   for (int m = 0; m < D1; ++m) {
@@ -245,7 +249,13 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
         if (jj >= 1 && jj <= G::L) { acc0[0] = fmaf(wk[k * 3 + 1][0], x0, acc0[0]); acc0[1] = fmaf(wk[k * 3 + 1][1], x1, acc0[1]); }
         if (jj >= 2) { accm[0] = fmaf(wk[k * 3 + 2][0], x0, accm[0]); accm[1] = fmaf(wk[k * 3 + 2][1], x1, accm[1]); }
       }
-      if (jj >= 2) __builtin_amdgcn_raw_buffer_store_b32(pack2bf(accm[0], accm[1]), yres, lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
+      if (jj >= 2) {
+        const uint32_t yv = pack2bf(accm[0], accm[1]);
+        __builtin_amdgcn_raw_buffer_store_b32(yv, yres, lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
+        if (COMP)
+          __builtin_amdgcn_raw_buffer_store_b32(pack2bf(accm[0] - __uint_as_float(yv << 16), accm[1] - __uint_as_float(yv & 0xffff0000u)), rres_d,
+                                                lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
+      }
       accm[0] = acc0[0]; accm[1] = acc0[1]; acc0[0] = accp[0]; acc0[1] = accp[1]; accp[0] = bv[0]; accp[1] = bv[1];
     }
   }
@@ -375,7 +385,7 @@ bool lds_path_enabled() {
 int pick_tb(int64_t B, int D2, int C) { return B * ((D2 + 11) / 12) * (C / PCC) >= 200 ? 12 : 4; }
 
 template <int TB, int D3, int DIR>
-int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int64_t B, int D1, int D2, int C, hipStream_t s) {
+int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* rres, int64_t B, int D1, int D2, int C, hipStream_t s) {
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
   constexpr int SHM = G::NSLOT * G::SLOT + G::ROWB;
@@ -383,7 +393,7 @@ int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, 
   const size_t shm = SHM;
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
   if (!once) { (void)hipGetLastError(); return 1; }
-  hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, D1, D2, C, ntile);
+  hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, rres, D1, D2, C, ntile);
   return 0;
 }
 
@@ -418,17 +428,22 @@ int64_t peg_lds_wgrad_groups(int64_t B, int D2, int C) { return B * ((D2 + 3) / 
     default: return 1;                      \
   }
 
-int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s) {
-  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s, void* rres) {
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* rp = (bf16_t*)rres;
   const int tb = pick_tb(B, D2, C);
-#define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, B, D1, D2, C, s)
-#define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, B, D1, D2, C, s)
-#define BWD12(D) launch_march<12, D, -1>(xp, w, nullptr, yp, B, D1, D2, C, s)
-#define BWD4(D) launch_march<4, D, -1>(xp, w, nullptr, yp, B, D1, D2, C, s)
-  if (dir > 0) { if (tb == 12) { PEG_D3_SWITCH(FWD12) } else { PEG_D3_SWITCH(FWD4) } }
+#define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, nullptr, B, D1, D2, C, s)
+#define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, nullptr, B, D1, D2, C, s)
+#define CMP12(D) launch_march<12, D, 2>(xp, w, bias, yp, rp, B, D1, D2, C, s)
+#define CMP4(D) launch_march<4, D, 2>(xp, w, bias, yp, rp, B, D1, D2, C, s)
+#define BWD12(D) launch_march<12, D, -1>(xp, w, nullptr, yp, nullptr, B, D1, D2, C, s)
+#define BWD4(D) launch_march<4, D, -1>(xp, w, nullptr, yp, nullptr, B, D1, D2, C, s)
+  if (dir > 0 && rp) { if (tb == 12) { PEG_D3_SWITCH(CMP12) } else { PEG_D3_SWITCH(CMP4) } }
+  else if (dir > 0) { if (tb == 12) { PEG_D3_SWITCH(FWD12) } else { PEG_D3_SWITCH(FWD4) } }
   else { if (tb == 12) { PEG_D3_SWITCH(BWD12) } else { PEG_D3_SWITCH(BWD4) } }
 #undef FWD12
 #undef FWD4
+#undef CMP12
+#undef CMP4
 #undef BWD12
 #undef BWD4
 }

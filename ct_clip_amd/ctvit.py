@@ -144,23 +144,37 @@ class Transformer(nn.Module):
         b, t, h, w = video_shape
         d = x.shape[1]
         tap = self.__dict__.get("layer_tap")      # test hook (never set by the product): tap(i, x) sees the residual stream at every layer boundary
+        # bf16 mode: the residual stream is the bf16 pair (x, e) -- x what the consumers read, e the rounding residue of the last add(s), added
+        # back in f32 by the next residual add (functional.residual_comp_enabled: the 72 roundings of a 24-layer stream stop accumulating)
+        comp = Fn.residual_comp_enabled(x)
+        e = None
         for i, layer in enumerate(self.layers):
             peg, attn, _, ff = layer
             if tap is not None:
-                tap(i, x)
+                tap(i, x if e is None else x.float() + e.float())
             x = Fn.grad_ready(x, layer)     # backward passing this point = the layer's parameter gradients are final
             # x = peg(x) + x  -- PEG sees the buffer flat-reinterpreted as (b, t, h, w, d) (attention.py:69-70)
-            x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
+            if comp:
+                x, r = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias, comp=True)
+                x, r = x.view(-1, d), r.view(-1, d)
+            else:
+                x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
             # x = attn(x) + x  -- q from LayerNorm(x), k/v from the RAW x (attention.py:139-143)
             xn, x_kv, x = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)   # the three consumers of x: LayerNorm, to_kv, residual
             q = Fn.linear(xn, attn.to_q.weight)
             kv = Fn.linear(x_kv, attn.to_kv.weight)
             o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
                                     float(attn.scale), bias_grid)
-            x = Fn.linear(o, attn.to_out.weight, residual=x)
+            if comp:
+                x, e = Fn.linear(o, attn.to_out.weight, residual=x, comp=(r, e))
+            else:
+                x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
             y, x = Fn.layer_norm_branch(x, ff[0].weight, ff[0].bias, 1)
-            x = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x)
+            if comp:
+                x, e = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x, comp=(e, None))
+            else:
+                x = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x)
         return Fn.layer_norm(x, self.norm_out.gamma, None)
 
 

@@ -322,17 +322,29 @@ class LinearFn(Function):
     """y = x @ Wshadow^T (+ bias) (+ residual).  ``segments``/``K`` describe how dW maps back onto the real weight."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype):
-        y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
-                     out_dtype=out_dtype or x.dtype)
+    def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype, comp=None):
+        """comp = (e1, e2 or None): the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled)."""
+        e_out = None
+        if comp is not None and bias is None and residual is not None:
+            pair = B().gemm_residual_comp(x, wsh, residual, comp[0], comp[1])
+            if pair is not None:
+                y, e_out = pair
+        if e_out is None:
+            y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
+                         out_dtype=out_dtype or x.dtype)
         ctx.save_for_backward(x, wsh)
         ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
         ctx.has_res = residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
-        return y
+        if comp is None:
+            return y
+        if e_out is None:      # shape not served: the residues are dropped at this add (plain bf16 rounding, as without compensation)
+            e_out = torch.zeros_like(y)
+        ctx.mark_non_differentiable(e_out)
+        return y, e_out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _de=None):
         x, wsh = ctx.saved_tensors
         dy = dy.contiguous()
         dres = None
@@ -361,14 +373,15 @@ class LinearFn(Function):
         db = None
         if ctx.bias is not None and ctx.bias.requires_grad:
             db = vec_grad(ctx.bias, lambda dst: B().colsum(dyc, dst, N=ctx.bias.numel()))
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None):
-    """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros)."""
+def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None):
+    """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros).  comp = (e1, e2 | None): the residual add on the
+    compensated residual stream -> (y, e_out)."""
     N, K = weight.shape
     wsh = plain_shadow(weight, x.dtype, kpad=kpad)
-    return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype)
+    return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype, comp)
 
 
 def geglu_hidden_pad(inner):
@@ -457,20 +470,30 @@ class FeedForwardFn(Function):
     CTCLIP_GEGLU_RECOMPUTE=1: u is not stored; the backward recomputes it (ctclip_gemm_geglu_bwd) from y after an ordinary dg GEMM."""
 
     @staticmethod
-    def forward(ctx, y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd=True):
+    def forward(ctx, y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd=True, comp=None):
         be = B()
         recompute = os.environ.get("CTCLIP_GEGLU_RECOMPUTE", "0") == "1"
         u, g = be.gemm_geglu(y, w_il, Hp, save_u=need_bwd and not recompute)      # inference / frozen towers: u is never read, not written
-        if not need_bwd:
-            return be.gemm(g, wsh_out, residual=residual)
-        out = be.gemm(g, wsh_out, residual=residual)
-        ctx.save_for_backward(y, g, wsh_in, wsh_out, w_il if recompute else u)
-        ctx.recompute, ctx.has_res = recompute, residual is not None
-        ctx.w_in, ctx.w_out, ctx.dims = w_in, w_out, (Hp, inner, K)
-        return out
+        e_out = None
+        if comp is not None and residual is not None:      # the residual add on the compensated stream (see residual_comp_enabled)
+            pair = be.gemm_residual_comp(g, wsh_out, residual, comp[0], comp[1])
+            if pair is not None:
+                out, e_out = pair
+        if e_out is None:
+            out = be.gemm(g, wsh_out, residual=residual)
+        if need_bwd:
+            ctx.save_for_backward(y, g, wsh_in, wsh_out, w_il if recompute else u)
+            ctx.recompute, ctx.has_res = recompute, residual is not None
+            ctx.w_in, ctx.w_out, ctx.dims = w_in, w_out, (Hp, inner, K)
+        if comp is None:
+            return out
+        if e_out is None:
+            e_out = torch.zeros_like(out)
+        ctx.mark_non_differentiable(e_out)
+        return out, e_out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _de=None):
         y, g, wsh_in, wsh_out, last = ctx.saved_tensors
         Hp, inner, K = ctx.dims
         be = B()
@@ -488,12 +511,13 @@ class FeedForwardFn(Function):
         dw_in = weight_grad(du, y, ctx.w_in, segs, K) if ctx.w_in.requires_grad else None      # (weight-gradient stream: under the next GEMM)
         dy = be.gemm(du, transposed_shadow(ctx.w_in, wsh_in, segs)) if ctx.needs_input_grad[0] else None
         dres = dout if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dy, dw_in, dw_out, dres, None, None, None, None, None, None, None
+        return dy, dw_in, dw_out, dres, None, None, None, None, None, None, None, None
 
 
-def feed_forward(y, w_in, w_out, residual=None):
+def feed_forward(y, w_in, w_out, residual=None, comp=None):
     """LayerNormed tokens -> FeedForward output (+ residual).  One autograd node with the fused launches when the large-tile kernel
-    serves the shape (bf16, whole 256-row tiles), otherwise the composition of the separate pieces."""
+    serves the shape (bf16, whole 256-row tiles), otherwise the composition of the separate pieces.  comp = (e1, e2 | None): the residual add
+    on the compensated residual stream -> (out, e_out)."""
     two_inner, K = w_in.shape
     inner = two_inner // 2
     Hp = geglu_hidden_pad(inner)
@@ -501,7 +525,7 @@ def feed_forward(y, w_in, w_out, residual=None):
     fused = (y.dtype == torch.bfloat16 and M % 256 == 0 and (2 * Hp) % 256 == 0 and (M // 256) * (2 * Hp // 256) >= 160 and K % 64 == 0 and K >= 128
              and (residual is None or residual.dtype == y.dtype) and os.environ.get("CTCLIP_FF_NODE", "1") != "0")
     if not fused:
-        return linear_geglu_out(feed_forward_in(y, w_in), w_out, residual)
+        return linear_geglu_out(feed_forward_in(y, w_in), w_out, residual, comp)
 
     def make():
         w = w_in.detach()
@@ -515,15 +539,16 @@ def feed_forward(y, w_in, w_out, residual=None):
     wsh_out = plain_shadow(w_out, y.dtype, kpad=Hp)
     need_bwd = torch.is_grad_enabled() and (y.requires_grad or w_in.requires_grad or w_out.requires_grad or
                                             (residual is not None and residual.requires_grad))
-    return FeedForwardFn.apply(y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd)
+    return FeedForwardFn.apply(y, w_in, w_out, residual, wsh_in, w_il, wsh_out, Hp, inner, K, need_bwd, comp)
 
 
-def linear_geglu_out(g, weight, residual):
-    """FeedForward[4]: Linear(inner, d, no bias) (attention.py:51) consuming the padded hidden (M, Hp), + residual."""
+def linear_geglu_out(g, weight, residual, comp=None):
+    """FeedForward[4]: Linear(inner, d, no bias) (attention.py:51) consuming the padded hidden (M, Hp), + residual (comp: on the
+    compensated residual stream -> (out, e_out))."""
     N, inner = weight.shape
     Hp = g.shape[1]
     wsh = plain_shadow(weight, g.dtype, kpad=Hp)
-    return LinearFn.apply(g, weight, None, residual, wsh, [(0, N, 0)], inner, None)
+    return LinearFn.apply(g, weight, None, residual, wsh, [(0, N, 0)], inner, None, comp)
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
@@ -656,15 +681,27 @@ class PatchEmbedFn(Function):
 
 class PegFn(Function):
     @staticmethod
-    def forward(ctx, x5, weight, bias):
+    def forward(ctx, x5, weight, bias, comp=False):
+        """comp: also return the rounding residue of the output (compensated residual stream, see residual_comp_enabled)."""
         w27 = weight.detach().reshape(weight.shape[0], 27)
-        y = B().peg_fwd(x5, w27, bias.detach())
+        r = None
+        if comp:
+            pair = B().peg_fwd_comp(x5, w27, bias.detach())
+            if pair is not None:
+                y, r = pair
+        if r is None:
+            y = B().peg_fwd(x5, w27, bias.detach())
         ctx.save_for_backward(x5)
         ctx.weight, ctx.bias = weight, bias
-        return y
+        if not comp:
+            return y
+        if r is None:
+            r = torch.zeros_like(y)      # (grids the marching kernels do not serve: this add carries no residue)
+        ctx.mark_non_differentiable(r)
+        return y, r
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dr=None):
         (x5,) = ctx.saved_tensors
         w, b = ctx.weight, ctx.bias
         ws, bs = sink_of(w), sink_of(b)
@@ -682,12 +719,22 @@ class PegFn(Function):
             dx = B().peg_bwd(dy, x5, w27, None, None)
         else:
             dx = B().peg_bwd(dy, x5, w27, dw, db)
-        return dx, (None if ws is not None else dw.view_as(w)), (None if bs is not None else db)
+        return dx, (None if ws is not None else dw.view_as(w)), (None if bs is not None else db), None
 
 
-def peg_residual(x5, weight, bias):
-    """x + PEG(x) on a contiguous (b, D1, D2, D3, C) view (attention.py:63-84,324)."""
-    return PegFn.apply(x5, weight, bias)
+def peg_residual(x5, weight, bias, comp=False):
+    """x + PEG(x) on a contiguous (b, D1, D2, D3, C) view (attention.py:63-84,324).  comp=True: -> (y, residue of y's rounding)."""
+    return PegFn.apply(x5, weight, bias, comp)
+
+
+# ---- compensated residual stream.  bf16 storage rounds the residual stream at each of its three adds per layer; over 24 layers those 72
+# roundings -- not the bf16 GEMM operands -- are the error of the bf16 mode (profiles/r03_bf16_error_budget.md: pre-VQ token error 1.5e-2 and
+# 96.8 % code agreement with them, 4.6e-3 and 99.1 % without).  The stream is therefore carried as a bf16 PAIR (x, e): x is what every
+# consumer reads (LayerNorm, the k/v projection, PEG's taps: one fresh rounding, not an accumulated one), e = the residue the roundings cut
+# off, added back in f32 inside the next residual add's epilogue, which emits the next pair.  e never enters autograd (backward is
+# unchanged) and is dead after the next add.  CTCLIP_RESIDUAL_COMP=0 switches it off (the round-2 behaviour).
+def residual_comp_enabled(x):
+    return x.dtype == torch.bfloat16 and os.environ.get("CTCLIP_RESIDUAL_COMP", "1") != "0"
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -279,3 +279,48 @@ def test_roofline_pricing_of_gemm_launch_groups():
     assert wgrad["bound"] == "mfma" and wgrad["side_stream"] and abs(wgrad["tflops"] - 1176.1) < 2
     f32 = price_gemm_group(("NT", "f32", 1024, 1024, 1024, False), [0.1])
     assert f32["peak_tflops"] == 157.3
+
+
+def test_compensated_residual_stream(ref_backend, monkeypatch):
+    """bf16 mode carries the residual stream as the pair (x, e) (functional.residual_comp_enabled): against the f32 run of the same
+    Transformer the output error must drop well below the plain bf16 stream's, the layer tap must see x + e, and backward must be
+    unaffected in structure (gradients for every parameter, close to the f32 ones)."""
+    import torch
+    from ct_clip_amd import functional as Fn
+    from ct_clip_amd.ctvit import Transformer
+    torch.manual_seed(0)
+    b, t, h, w, d = 1, 4, 8, 8, 128                      # 256 token rows: one whole tile of the large-tile epilogue
+    tr = Transformer(dim=d, depth=6, dim_head=32, heads=4, peg=True, peg_causal=True)
+    with torch.no_grad():
+        for p in tr.parameters():
+            if p.ndim <= 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    x0 = torch.randn(b * t * h * w, d)
+
+    def run(dtype, comp):
+        monkeypatch.setenv("CTCLIP_RESIDUAL_COMP", "1" if comp else "0")
+        Fn.bump_weight_epoch()
+        for p in tr.parameters():
+            p.grad = None
+        x = x0.to(dtype).detach().requires_grad_(True)
+        seen = []
+        tr.__dict__["layer_tap"] = lambda i, v: seen.append(v.detach().float())
+        try:
+            y = tr(x, (b, t, h, w), nseq=b * t, L=h * w)
+        finally:
+            tr.__dict__.pop("layer_tap")
+        y.float().square().mean().backward()
+        return y.detach().float(), seen, {n: p.grad.detach().clone() for n, p in tr.named_parameters() if p.grad is not None}, x.grad.float()
+
+    y32, taps32, g32, dx32 = run(torch.float32, False)
+    yb, tapsb, gb, dxb = run(torch.bfloat16, False)
+    yc, tapsc, gc, dxc = run(torch.bfloat16, True)
+    rel = lambda a, r: float((a - r).norm() / r.norm())
+    e_plain, e_comp = rel(tapsb[-1], taps32[-1]), rel(tapsc[-1], taps32[-1])
+    assert e_comp < 0.6 * e_plain, (e_plain, e_comp)          # the stream itself (last layer boundary): roundings no longer accumulate
+    assert rel(yc, y32) <= rel(yb, y32) * 1.05
+    assert set(gc) == set(g32) and len(gc) > 20
+    for n in g32:
+        if g32[n].norm() > 1e-6:
+            assert rel(gc[n].float(), g32[n]) < max(0.1, 2 * rel(gb[n].float(), g32[n])), n
+    assert rel(dxc, dx32) < 0.1
