@@ -44,8 +44,8 @@ SIGNATURES = {
     "ctclip_geglu_weight_interleave": (_I, [_P, _P, _I, _I, _I, _L, _P]),
     "ctclip_gemm_geglu": (_I, [_P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_gemm_dgeglu": (_I, [_P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _I, _P]),
-    "ctclip_gemm_residual_comp": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _P]),
-    "ctclip_peg_fwd_comp": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "ctclip_gemm_residual_comp": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _P]),
+    "ctclip_peg_fwd_comp": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ctclip_shadow_refresh": (_I, [_P, _I, _L, _P]),
     "ctclip_gemm_geglu_bwd": (_I, [_P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_preprocess_volume": (_I, [_P, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, _P, _I, _I, _I, _D, _D, _D, _F, _P]),

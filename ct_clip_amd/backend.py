@@ -228,32 +228,33 @@ class HipBackend:
         _lib.check(rc, "ctclip_peg_fwd")
         return y
 
-    def peg_fwd_comp(self, x, w, bias):
-        """-> (y, r): y = bf16(x + conv(x) + bias), r = the rounding residue bf16(s - y) of every output; None when the marching kernels do
-        not serve the grid (the caller then runs peg_fwd and carries no residue for this add)."""
+    def peg_fwd_comp(self, x, w, bias, e_in=None):
+        """The PEG residual add on the compensated residual stream: s = x + e_in + conv(x) + bias (f32) -> (y, e) = (bf16(s), bf16(s - y));
+        None when the marching kernels do not serve the grid (the caller then runs peg_fwd and this add carries no residue)."""
         B, D1, D2, D3, C = x.shape
         assert x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
         if x.dtype != torch.bfloat16:
             return None
-        y, r = torch.empty_like(x), torch.empty_like(x)
-        rc = self.lib.ctclip_peg_fwd_comp(_p(x), _p(w), _p(bias), _p(y), _p(r), B, D1, D2, D3, C, dcode(x.dtype), _stream())
+        assert e_in is None or (e_in.dtype == x.dtype and e_in.is_contiguous() and e_in.numel() == x.numel())
+        y, e = torch.empty_like(x), torch.empty_like(x)
+        rc = self.lib.ctclip_peg_fwd_comp(_p(x), _p(w), _p(bias), _p(e_in), _p(y), _p(e), B, D1, D2, D3, C, dcode(x.dtype), _stream())
         if rc == -2:      # CTCLIP_EUNSUPPORTED
             return None
         _lib.check(rc, "ctclip_peg_fwd_comp")
-        return y, r
+        return y, e
 
-    def gemm_residual_comp(self, a, b, residual, comp1, comp2=None):
-        """-> (y, e) = the bf16 pair of s = a @ b^T + residual + comp1 (+ comp2) (f32): y = bf16(s), e = bf16(s - y); None when the
-        large-tile kernel does not serve the shape."""
+    def gemm_residual_comp(self, a, b, residual, comp):
+        """-> (y, e) = the bf16 pair of s = a @ b^T + residual + comp (f32): y = bf16(s), e = bf16(s - y); None when the large-tile kernel
+        does not serve the shape."""
         M, K = a.shape
         N = b.shape[0]
         if a.dtype != torch.bfloat16 or M % 256 or N % 128 or K % 64:
             return None
-        for t in (residual, comp1) + ((comp2,) if comp2 is not None else ()):
+        for t in (residual, comp):
             assert t.dtype == torch.bfloat16 and tuple(t.shape) == (M, N) and t.stride(1) == 1 and t.stride(0) == residual.stride(0)
         y = torch.empty((M, N), dtype=a.dtype, device=a.device)
         e = torch.empty_like(y)
-        rc = self.lib.ctclip_gemm_residual_comp(_p(a), _p(b), _p(y), _p(e), _p(residual), _p(comp1), _p(comp2), M, N, K, _rowmajor(a, "a"),
+        rc = self.lib.ctclip_gemm_residual_comp(_p(a), _p(b), _p(y), _p(e), _p(residual), _p(comp), M, N, K, _rowmajor(a, "a"),
                                                 _rowmajor(b, "b"), N, _rowmajor(residual, "residual"), dcode(a.dtype), _stream())
         if rc == -2:      # CTCLIP_EUNSUPPORTED
             return None

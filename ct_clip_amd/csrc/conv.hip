@@ -280,14 +280,14 @@ extern "C" int ctclip_peg_fwd(const void* x, const float* w, const float* bias, 
   return ctclip_check_launch("peg_fwd");
 }
 
-// ctclip_peg_fwd that ALSO stores r = bf16(s - y), the rounding residue of every output (s = x + conv(x) + bias in f32, y = bf16(s)): the
-// PEG residual add (attention.py:323-324) on a compensated residual stream (see ctclip_gemm_residual_comp).  bf16 grids the LDS-marching
-// kernels serve only (C % 32 == 0, D3 in {8, 16, 24, 32}); CTCLIP_EUNSUPPORTED otherwise.
-extern "C" int ctclip_peg_fwd_comp(const void* x, const float* w, const float* bias, void* y, void* r, int64_t B, int D1, int D2, int D3, int C,
-                                   int dtype, hipStream_t stream) {
-  if (!x || !w || !y || !r || C % 8) { ctclip_set_error("peg_fwd_comp: bad args"); return CTCLIP_EBADARG; }
+// ctclip_peg_fwd on the COMPENSATED residual stream (see ctclip_gemm_residual_comp): s = x + e_in + conv(x) + bias in f32 (e_in may be NULL:
+// zeros), y = bf16(s), e_out = bf16(s - y) the rounding residue -- the PEG residual add (attention.py:323-324) without an accumulating
+// rounding.  bf16 grids the LDS-marching kernels serve only (C % 32 == 0, D3 in {8, 16, 24, 32}); CTCLIP_EUNSUPPORTED otherwise.
+extern "C" int ctclip_peg_fwd_comp(const void* x, const float* w, const float* bias, const void* e_in, void* y, void* e_out, int64_t B, int D1,
+                                   int D2, int D3, int C, int dtype, hipStream_t stream) {
+  if (!x || !w || !y || !e_out || C % 8) { ctclip_set_error("peg_fwd_comp: bad args"); return CTCLIP_EBADARG; }
   if (!peg_lds_supported(B, D1, D2, D3, C, dtype)) return CTCLIP_EUNSUPPORTED;
-  if (peg_lds_march(x, w, bias, y, B, D1, D2, D3, C, +1, stream, r) != 0) return CTCLIP_EUNSUPPORTED;
+  if (peg_lds_march(x, w, bias, y, B, D1, D2, D3, C, +1, stream, e_in, e_out) != 0) return CTCLIP_EUNSUPPORTED;
   return ctclip_check_launch("peg_fwd_comp");
 }
 

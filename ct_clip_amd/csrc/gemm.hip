@@ -454,7 +454,7 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
 // ---------------------------------------------------------------------------------------------------- fused GEGLU in-projection
 int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream);
-int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp1, const void* comp2,
+int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp,
                                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, hipStream_t stream);
 int ctclip_gemm_nt_dgeglu_try(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
                               int64_t ldu, int64_t lddu, hipStream_t stream);
@@ -520,16 +520,16 @@ extern "C" int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, v
 }
 
 // A residual add of the transformer (attention.py:325,331: x + attn(x), x + ff(x)) on a COMPENSATED residual stream: the stream is the bf16
-// pair (x, e), x what every consumer reads, e the rounding residue of the last add(s).  C (M, ldc) = bf16(s), E (M, ldc) = bf16(s - C) with
-// s = A B^T + residual + comp1 (+ comp2, may be NULL) in f32; A (M, K), B (N, K) bf16 k-contiguous, residual / comp rows with stride ldr.
+// pair (x, e), x what every consumer reads, e the rounding residue of the last add.  C (M, ldc) = bf16(s), E (M, ldc) = bf16(s - C) with
+// s = A B^T + residual + comp in f32; A (M, K), B (N, K) bf16 k-contiguous, residual / comp rows with stride ldr.
 // Replaces `x = out_proj(...) + x` where bf16 storage rounds x at every add: 72 roundings over 24 layers are the bf16 mode's error
 // (profiles/r03_bf16_error_budget.md); with the residue carried along they no longer accumulate.  CTCLIP_EUNSUPPORTED unless bf16, whole
 // 256-row tiles, N % 128 == 0, K % 64 == 0, 16-byte aligned rows.
-extern "C" int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp1, const void* comp2,
+extern "C" int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp,
                                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int dtype,
                                          hipStream_t stream) {
-  if (!A || !B || !C || !E || !residual || !comp1 || M < 1 || N < 1 || K < 1) { ctclip_set_error("gemm_residual_comp: bad args"); return CTCLIP_EBADARG; }
+  if (!A || !B || !C || !E || !residual || !comp || M < 1 || N < 1 || K < 1) { ctclip_set_error("gemm_residual_comp: bad args"); return CTCLIP_EBADARG; }
   if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
-  const int rc = ctclip_gemm_nt_rescomp_try(A, B, C, E, residual, comp1, comp2, M, N, K, lda, ldb, ldc, ldr, stream);
+  const int rc = ctclip_gemm_nt_rescomp_try(A, B, C, E, residual, comp, M, N, K, lda, ldb, ldc, ldr, stream);
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }

@@ -89,9 +89,9 @@ struct NtParams {
   const bf16_t* dgeglu_u; int64_t dgeglu_ldu; int dgeglu_hp;
   // Compensated residual stream (ctclip_gemm_residual_comp, epilogue family 3): the residual stream of the transformer is carried as a
   // bf16 pair (x, e): x = the rounded value every consumer reads, e = the rounding residue of the last add(s).  The epilogue forms
-  // s = A B^T + residual + comp1 (+ comp2) in f32 and stores C = bf16(s) AND comp_out = bf16(s - C): the 72 bf16 roundings of a 24-layer
+  // s = A B^T + residual + comp1 in f32 and stores C = bf16(s) AND comp_out = bf16(s - C): the 72 bf16 roundings of a 24-layer
   // residual stream no longer accumulate (profiles/r03_bf16_error_budget.md).  comp rows use ldr, comp_out rows use ldc.
-  const bf16_t* comp1; const bf16_t* comp2; bf16_t* comp_out;
+  const bf16_t* comp1; bf16_t* comp_out;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -537,21 +537,18 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
           }
           pn = 48;          // 32 loads + 32 stores: more than vmcnt can count, an under-count is safe
         }
-      } else if (EPI == 3) {      // residual + compensation terms in, rounded value + rounding residue out (full row tiles only: checked by the launcher)
+      } else if (EPI == 3) {      // residual + its compensation term in, rounded value + rounding residue out (full row tiles only: checked by the launcher)
        if (cols_in) {
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + rbase * p.ldr + col;
-        const bf16_t* e1p = p.comp1 + rbase * p.ldr + col;
-        const bf16_t* e2p = (p.comp2 ? p.comp2 : p.comp1) + rbase * p.ldr + col;      // (kernel-uniform; without a second term the first is re-read and not added)
-        const float w2 = p.comp2 ? 1.f : 0.f;
+        const bf16_t* ep = p.comp1 + rbase * p.ldr + col;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {             // four rows of three tensors in flight per lane (48 registers)
-          u32x4 rr[4], ea[4], eb[4];
+        for (int a = 0; a < 4; ++a) {             // four rows of both tensors in flight per lane (32 registers; eight rows spill)
+          u32x4 rr[4], ee[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int64_t o = (int64_t)(a * 16 + r) * p.ldr;
             rr[r] = *reinterpret_cast<const u32x4*>(rp + o);
-            ea[r] = *reinterpret_cast<const u32x4*>(e1p + o);
-            eb[r] = *reinterpret_cast<const u32x4*>(e2p + o);
+            ee[r] = *reinterpret_cast<const u32x4*>(ep + o);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -559,12 +556,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
             u32x4 d, e;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-              const uint32_t w = rr[r][b], u1 = ea[r][b], u2 = eb[r][b];
-              // the small terms first: e1 + e2 is exact to 2^-9 of a residue, then the residual, then the accumulator
-              const float c0 = fmaf(w2, __uint_as_float(u2 << 16), __uint_as_float(u1 << 16));
-              const float c1 = fmaf(w2, __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u));
-              const float s0 = fmaf(acc[a][2 * b][r], p.alpha, __uint_as_float(w << 16)) + c0;
-              const float s1 = fmaf(acc[a][2 * b + 1][r], p.alpha, __uint_as_float(w & 0xffff0000u)) + c1;
+              const uint32_t w = rr[r][b], u = ee[r][b];
+              const float s0 = fmaf(acc[a][2 * b][r], p.alpha, __uint_as_float(w << 16)) + __uint_as_float(u << 16);
+              const float s1 = fmaf(acc[a][2 * b + 1][r], p.alpha, __uint_as_float(w & 0xffff0000u)) + __uint_as_float(u & 0xffff0000u);
               const uint32_t y = pack2bf(s0, s1);
               d[b] = y;
               e[b] = pack2bf(s0 - __uint_as_float(y << 16), s1 - __uint_as_float(y & 0xffff0000u));
@@ -749,13 +743,13 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
   return nt_launch(p, nontemporal, stream);
 }
 
-// out = A B^T + residual + comp1 (+ comp2), stored as the bf16 pair (C, comp_out = the rounding residue): the residual adds of
-// attention.py:325,331 on a compensated residual stream.  Whole 256-row tiles, N a multiple of 128.  Returns 1 when the shape is not eligible.
-int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp1, const void* comp2,
+// out = A B^T + residual + comp, stored as the bf16 pair (C, E = the rounding residue): the residual adds of attention.py:325,331 on a
+// compensated residual stream.  Whole 256-row tiles, N a multiple of 128.  Returns 1 when the shape is not eligible.
+int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp,
                                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, hipStream_t stream) {
   if (K % TK || K / TK < 2 || M % TM || N % 128 || ldc % 8 || ldr % 8) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
-  for (const void* q : {(const void*)C, (const void*)E, residual, comp1, comp2})
+  for (const void* q : {(const void*)C, (const void*)E, residual, comp})
     if (reinterpret_cast<uintptr_t>(q) % 16) return 1;
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
   const int64_t ntm = M / TM, ntn = cdiv(N, TN);
@@ -763,7 +757,7 @@ int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, c
   NtParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.residual = residual; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.out_dtype = DT_BF16; p.res_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
-  p.comp1 = (const bf16_t*)comp1; p.comp2 = (const bf16_t*)comp2; p.comp_out = (bf16_t*)E;
+  p.comp1 = (const bf16_t*)comp; p.comp_out = (bf16_t*)E;
   return nt_launch(p, 2 * M * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
 }
 

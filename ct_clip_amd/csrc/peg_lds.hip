@@ -158,9 +158,10 @@ __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
 template <int TB, int D3, int DIR>
 __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                                 const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                                                bf16_t* __restrict__ rres, int D1, int D2, int C, int ntile) {
-  // DIR: +1 forward, -1 grad-in, +2 forward that ALSO stores the rounding residue r = bf16(s - bf16(s)) of every output (s = the f32
-  // value of x + conv(x)): the residual stream's compensation term (ctclip_peg_fwd_comp, profiles/r03_bf16_error_budget.md)
+                                                                                const bf16_t* __restrict__ ein, bf16_t* __restrict__ rres, int D1, int D2,
+                                                                                int C, int ntile) {
+  // DIR: +1 forward, -1 grad-in, +2 forward on the COMPENSATED residual stream (ctclip_peg_fwd_comp, profiles/r03_bf16_error_budget.md):
+  // s = x + e_in + conv(x) in f32, y = bf16(s) and the rounding residue e_out = bf16(s - y) are stored (e_in may be null: zeros)
   constexpr bool COMP = DIR == 2;
   using G = Geo<TB, D3>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -220,6 +221,9 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
   // (ragged last tile) get an offset beyond the descriptor and the hardware drops their stores -- no branches in the column loop
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(y + t.b * D1 * plane_elems, 0, (int)(D1 * plane_elems * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rres_d = __builtin_amdgcn_make_buffer_rsrc((COMP ? rres : y) + t.b * D1 * plane_elems, 0, (int)(D1 * plane_elems * 2), 0x00020000);
+  // (a null e_in becomes a descriptor of zero records: every load is out of range and returns 0 without touching memory)
+  const __amdgpu_buffer_rsrc_t ein_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(COMP && ein ? ein : x) + t.b * D1 * plane_elems, 0,
+                                                                         (COMP && ein) ? (int)(D1 * plane_elems * 2) : 0, 0x00020000);
   const uint32_t lane_off = t.beta0 + r < D2 ? (uint32_t)((((t.beta0 + r) * D3 + g0) * C + ch) * 2) : 0x80000000u;
 
   for (int m = 0; m < D1; ++m) {
@@ -229,6 +233,11 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
     for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 - 2 + G::NSLOT) % G::NSLOT) * G::SLOT + tb;
     const uint32_t plane_off = (uint32_t)(plane_of(m) * plane_elems * 2);
     float accm[2] = {0.f, 0.f}, acc0[2] = {bv[0], bv[1]}, accp[2] = {bv[0], bv[1]};
+    uint32_t ev[G::L];      // COMP: the compensation terms of this plane's outputs, requested a whole plane body ahead of their use
+    if (COMP) {
+#pragma unroll
+      for (int j = 0; j < G::L; ++j) ev[j] = __builtin_amdgcn_raw_buffer_load_b32(ein_d, lane_off, plane_off + (uint32_t)(j * C * 2), 0);
+    }
     uint32_t raw[2][9];
     auto fetch = [&](uint32_t (&dst)[9], int jj) {
 #pragma unroll
@@ -250,6 +259,7 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
         if (jj >= 2) { accm[0] = fmaf(wk[k * 3 + 2][0], x0, accm[0]); accm[1] = fmaf(wk[k * 3 + 2][1], x1, accm[1]); }
       }
       if (jj >= 2) {
+        if (COMP) { accm[0] += __uint_as_float(ev[jj - 2] << 16); accm[1] += __uint_as_float(ev[jj - 2] & 0xffff0000u); }
         const uint32_t yv = pack2bf(accm[0], accm[1]);
         __builtin_amdgcn_raw_buffer_store_b32(yv, yres, lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
         if (COMP)
@@ -385,7 +395,7 @@ bool lds_path_enabled() {
 int pick_tb(int64_t B, int D2, int C) { return B * ((D2 + 11) / 12) * (C / PCC) >= 200 ? 12 : 4; }
 
 template <int TB, int D3, int DIR>
-int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* rres, int64_t B, int D1, int D2, int C, hipStream_t s) {
+int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, const bf16_t* ein, bf16_t* rres, int64_t B, int D1, int D2, int C, hipStream_t s) {
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
   constexpr int SHM = G::NSLOT * G::SLOT + G::ROWB;
@@ -393,7 +403,7 @@ int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, 
   const size_t shm = SHM;
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
   if (!once) { (void)hipGetLastError(); return 1; }
-  hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, rres, D1, D2, C, ntile);
+  hipLaunchKernelGGL((peg_march_kernel<TB, D3, DIR>), dim3((unsigned)(B * ntile * (C / PCC))), dim3((G::NCW + 1) * 64), shm, s, x, w, bias, y, ein, rres, D1, D2, C, ntile);
   return 0;
 }
 
@@ -428,15 +438,15 @@ int64_t peg_lds_wgrad_groups(int64_t B, int D2, int C) { return B * ((D2 + 3) / 
     default: return 1;                      \
   }
 
-int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s, void* rres) {
-  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* rp = (bf16_t*)rres;
+int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s, const void* ein, void* rres) {
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* rp = (bf16_t*)rres; const bf16_t* ep = (const bf16_t*)ein;
   const int tb = pick_tb(B, D2, C);
-#define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, nullptr, B, D1, D2, C, s)
-#define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, nullptr, B, D1, D2, C, s)
-#define CMP12(D) launch_march<12, D, 2>(xp, w, bias, yp, rp, B, D1, D2, C, s)
-#define CMP4(D) launch_march<4, D, 2>(xp, w, bias, yp, rp, B, D1, D2, C, s)
-#define BWD12(D) launch_march<12, D, -1>(xp, w, nullptr, yp, nullptr, B, D1, D2, C, s)
-#define BWD4(D) launch_march<4, D, -1>(xp, w, nullptr, yp, nullptr, B, D1, D2, C, s)
+#define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, nullptr, nullptr, B, D1, D2, C, s)
+#define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, nullptr, nullptr, B, D1, D2, C, s)
+#define CMP12(D) launch_march<12, D, 2>(xp, w, bias, yp, ep, rp, B, D1, D2, C, s)
+#define CMP4(D) launch_march<4, D, 2>(xp, w, bias, yp, ep, rp, B, D1, D2, C, s)
+#define BWD12(D) launch_march<12, D, -1>(xp, w, nullptr, yp, nullptr, nullptr, B, D1, D2, C, s)
+#define BWD4(D) launch_march<4, D, -1>(xp, w, nullptr, yp, nullptr, nullptr, B, D1, D2, C, s)
   if (dir > 0 && rp) { if (tb == 12) { PEG_D3_SWITCH(CMP12) } else { PEG_D3_SWITCH(CMP4) } }
   else if (dir > 0) { if (tb == 12) { PEG_D3_SWITCH(FWD12) } else { PEG_D3_SWITCH(FWD4) } }
   else { if (tb == 12) { PEG_D3_SWITCH(BWD12) } else { PEG_D3_SWITCH(BWD4) } }

@@ -155,8 +155,8 @@ class Transformer(nn.Module):
             x = Fn.grad_ready(x, layer)     # backward passing this point = the layer's parameter gradients are final
             # x = peg(x) + x  -- PEG sees the buffer flat-reinterpreted as (b, t, h, w, d) (attention.py:69-70)
             if comp:
-                x, r = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias, comp=True)
-                x, r = x.view(-1, d), r.view(-1, d)
+                x, e = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias, comp=False if e is None else e.view(b, t, h, w, d))
+                x, e = x.view(-1, d), e.view(-1, d)
             else:
                 x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
             # x = attn(x) + x  -- q from LayerNorm(x), k/v from the RAW x (attention.py:139-143)
@@ -166,13 +166,13 @@ class Transformer(nn.Module):
             o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
                                     float(attn.scale), bias_grid)
             if comp:
-                x, e = Fn.linear(o, attn.to_out.weight, residual=x, comp=(r, e))
+                x, e = Fn.linear(o, attn.to_out.weight, residual=x, comp=e)
             else:
                 x = Fn.linear(o, attn.to_out.weight, residual=x)
             # x = ff(x) + x
             y, x = Fn.layer_norm_branch(x, ff[0].weight, ff[0].bias, 1)
             if comp:
-                x, e = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x, comp=(e, None))
+                x, e = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x, comp=e)
             else:
                 x = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x)
         return Fn.layer_norm(x, self.norm_out.gamma, None)

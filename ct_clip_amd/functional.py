@@ -323,10 +323,10 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype, comp=None):
-        """comp = (e1, e2 or None): the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled)."""
+        """comp = the residue e of `residual`: the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled)."""
         e_out = None
         if comp is not None and bias is None and residual is not None:
-            pair = B().gemm_residual_comp(x, wsh, residual, comp[0], comp[1])
+            pair = B().gemm_residual_comp(x, wsh, residual, comp)
             if pair is not None:
                 y, e_out = pair
         if e_out is None:
@@ -338,8 +338,8 @@ class LinearFn(Function):
         ctx.res_dtype = residual.dtype if residual is not None else None
         if comp is None:
             return y
-        if e_out is None:      # shape not served: the residues are dropped at this add (plain bf16 rounding, as without compensation)
-            e_out = torch.zeros_like(y)
+        if e_out is None:      # shape not served: plain bf16 rounding at this add, the incoming residue travels on
+            e_out = comp.clone()
         ctx.mark_non_differentiable(e_out)
         return y, e_out
 
@@ -377,7 +377,7 @@ class LinearFn(Function):
 
 
 def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None):
-    """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros).  comp = (e1, e2 | None): the residual add on the
+    """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros).  comp = the residue e of `residual`: the residual add on the
     compensated residual stream -> (y, e_out)."""
     N, K = weight.shape
     wsh = plain_shadow(weight, x.dtype, kpad=kpad)
@@ -476,7 +476,7 @@ class FeedForwardFn(Function):
         u, g = be.gemm_geglu(y, w_il, Hp, save_u=need_bwd and not recompute)      # inference / frozen towers: u is never read, not written
         e_out = None
         if comp is not None and residual is not None:      # the residual add on the compensated stream (see residual_comp_enabled)
-            pair = be.gemm_residual_comp(g, wsh_out, residual, comp[0], comp[1])
+            pair = be.gemm_residual_comp(g, wsh_out, residual, comp)
             if pair is not None:
                 out, e_out = pair
         if e_out is None:
@@ -488,7 +488,7 @@ class FeedForwardFn(Function):
         if comp is None:
             return out
         if e_out is None:
-            e_out = torch.zeros_like(out)
+            e_out = comp.clone()
         ctx.mark_non_differentiable(e_out)
         return out, e_out
 
@@ -516,7 +516,7 @@ class FeedForwardFn(Function):
 
 def feed_forward(y, w_in, w_out, residual=None, comp=None):
     """LayerNormed tokens -> FeedForward output (+ residual).  One autograd node with the fused launches when the large-tile kernel
-    serves the shape (bf16, whole 256-row tiles), otherwise the composition of the separate pieces.  comp = (e1, e2 | None): the residual add
+    serves the shape (bf16, whole 256-row tiles), otherwise the composition of the separate pieces.  comp = the residue e of `residual`: the residual add
     on the compensated residual stream -> (out, e_out)."""
     two_inner, K = w_in.shape
     inner = two_inner // 2
@@ -681,24 +681,25 @@ class PatchEmbedFn(Function):
 
 class PegFn(Function):
     @staticmethod
-    def forward(ctx, x5, weight, bias, comp=False):
-        """comp: also return the rounding residue of the output (compensated residual stream, see residual_comp_enabled)."""
+    def forward(ctx, x5, weight, bias, comp=None):
+        """comp: None = plain add; otherwise the compensated residual stream (see residual_comp_enabled): comp = the incoming residue e (a
+        tensor shaped like x5, or False for "none yet") and the result is (y, e_out)."""
         w27 = weight.detach().reshape(weight.shape[0], 27)
-        r = None
-        if comp:
-            pair = B().peg_fwd_comp(x5, w27, bias.detach())
+        e_out = None
+        if comp is not None:
+            pair = B().peg_fwd_comp(x5, w27, bias.detach(), comp if torch.is_tensor(comp) else None)
             if pair is not None:
-                y, r = pair
-        if r is None:
+                y, e_out = pair
+        if e_out is None:
             y = B().peg_fwd(x5, w27, bias.detach())
         ctx.save_for_backward(x5)
         ctx.weight, ctx.bias = weight, bias
-        if not comp:
+        if comp is None:
             return y
-        if r is None:
-            r = torch.zeros_like(y)      # (grids the marching kernels do not serve: this add carries no residue)
-        ctx.mark_non_differentiable(r)
-        return y, r
+        if e_out is None:      # grids the marching kernels do not serve: plain rounding at this add, the incoming residue travels on
+            e_out = comp.reshape(y.shape) if torch.is_tensor(comp) else torch.zeros_like(y)
+        ctx.mark_non_differentiable(e_out)
+        return y, e_out
 
     @staticmethod
     def backward(ctx, dy, _dr=None):
@@ -722,8 +723,9 @@ class PegFn(Function):
         return dx, (None if ws is not None else dw.view_as(w)), (None if bs is not None else db), None
 
 
-def peg_residual(x5, weight, bias, comp=False):
-    """x + PEG(x) on a contiguous (b, D1, D2, D3, C) view (attention.py:63-84,324).  comp=True: -> (y, residue of y's rounding)."""
+def peg_residual(x5, weight, bias, comp=None):
+    """x + PEG(x) on a contiguous (b, D1, D2, D3, C) view (attention.py:63-84,324).  comp (the incoming residue tensor, or False for none
+    yet): the add on the compensated residual stream -> (y, e_out)."""
     return PegFn.apply(x5, weight, bias, comp)
 
 

@@ -92,8 +92,8 @@ const char* ctclip_target_arch(void);
 /* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
 int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
-/* ctclip_peg_fwd (attention.py:63-84 + the residual of :324) that also stores r = bf16(s - y), the rounding residue of every output (s = x + conv(x) + bias in f32): the PEG add on the compensated residual stream.  bf16 grids the LDS-marching kernels serve; CTCLIP_EUNSUPPORTED otherwise. */
-int ctclip_peg_fwd_comp(const void* x, const float* w, const float* bias, void* y, void* r, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
+/* ctclip_peg_fwd (attention.py:63-84 + the residual of :324) on the compensated residual stream: s = x + e_in (may be NULL) + conv(x) + bias in f32, y = bf16(s), e_out = bf16(s - y).  bf16 grids the LDS-marching kernels serve; CTCLIP_EUNSUPPORTED otherwise. */
+int ctclip_peg_fwd_comp(const void* x, const float* w, const float* bias, const void* e_in, void* y, void* e_out, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
 /* bytes of workspace ctclip_peg_bwd needs when dw is requested (per-workgroup partial weight gradients of the deterministic two-stage sum). */
 int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C);
@@ -137,8 +137,8 @@ int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* dG, void* dU
 /* Backward of the feed-forward block between FeedForward[4] and the GEGLU in ONE launch (replaces torch autograd through `Linear(inner, dim)` and `x * F.gelu(gate)`, attention.py:39-51): dU (M, lddu >= 2 hp) = [dg * gelu(gate) | dg * x * gelu'(gate)] where dg = dY W_out exists only in the accumulators (A = dY (M, K = model width) bf16, B = W_out^T (hp, ldb >= K), hidden feature j in row j) and U = [x | gate] (M, ldu >= 2 hp) is what ctclip_gemm_geglu stored.  No dg tensor, no ctclip_geglu_bwd pass.  CTCLIP_EUNSUPPORTED when the shape does not fill whole 256-row tiles / 128-column halves (caller: ctclip_gemm + ctclip_geglu_bwd). */
 int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu, int64_t lddu, int dtype, hipStream_t stream);
 
-/* a residual add of the transformer (attention.py:325,331: `x = attn(x) + x`, `x = ff(x) + x`) on a COMPENSATED bf16 residual stream: s = A B^T + residual + comp1 (+ comp2, may be NULL) in f32, C = bf16(s), E = bf16(s - C) (the rounding residue the next add takes back in): replaces nn.Linear + the torch add, whose bf16 storage rounds the stream at every add.  bf16, M % 256 == 0, N % 128 == 0, K % 64 == 0; CTCLIP_EUNSUPPORTED otherwise. */
-int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp1, const void* comp2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int dtype, hipStream_t stream);
+/* a residual add of the transformer (attention.py:325,331: `x = attn(x) + x`, `x = ff(x) + x`) on a COMPENSATED bf16 residual stream: s = A B^T + residual + comp in f32 (comp = the residue of `residual`), C = bf16(s), E = bf16(s - C) (the rounding residue the next add takes back in): replaces nn.Linear + the torch add, whose bf16 storage rounds the stream at every add.  bf16, M % 256 == 0, N % 128 == 0, K % 64 == 0; CTCLIP_EUNSUPPORTED otherwise. */
+int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int dtype, hipStream_t stream);
 
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);

@@ -110,21 +110,23 @@ class RefBackend:
         y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C)
         return (y.permute(0, 2, 3, 4, 1) + _f(x)).to(x.dtype).contiguous()
 
-    def peg_fwd_comp(self, x, w, bias):
+    def peg_fwd_comp(self, x, w, bias, e_in=None):
         if x.dtype != torch.bfloat16:
             return None
         C = x.shape[-1]
         xc = _f(x).permute(0, 4, 1, 2, 3)
         s = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C).permute(0, 2, 3, 4, 1) + _f(x)
+        if e_in is not None:
+            s = s + _f(e_in).view_as(s)
         y = s.to(x.dtype).contiguous()
         return y, (s - _f(y)).to(x.dtype).contiguous()
 
-    def gemm_residual_comp(self, a, b, residual, comp1, comp2=None):
+    def gemm_residual_comp(self, a, b, residual, comp):
         M, K = a.shape
         N = b.shape[0]
         if a.dtype != torch.bfloat16 or M % 256 or N % 128 or K % 64:
             return None
-        s = _f(a) @ _f(b).t() + _f(residual) + (_f(comp1) + (_f(comp2) if comp2 is not None else 0.0))
+        s = _f(a) @ _f(b).t() + _f(residual) + _f(comp)
         y = s.to(a.dtype)
         return y, (s - _f(y)).to(a.dtype)
 

@@ -230,45 +230,50 @@ def test_gemm_dgeglu_fused(hip, ref, M, inner, K):
 
 
 # ---------------------------------------------------------------- compensated residual stream (gemm_nt epilogue family 3, peg_march<.., 2>)
-@pytest.mark.parametrize("M,N,K,two", [(20480, 512, 256, True), (20480, 512, 1408, False), (110592, 512, 256, True), (512, 512, 256, True)])
-def test_gemm_residual_comp(hip, ref, M, N, K, two):
-    """s = a b^T + residual + e1 (+ e2) in f32 -> (y, e) = (bf16(s), bf16(s - y)): y must be THE bf16 rounding of s (up to f32 summation
-    order at rounding ties), y + e must carry s to ~2^-16, and the launch must be bit-reproducible; the last shape cannot fill the chip and
-    is declined."""
+@pytest.mark.parametrize("M,N,K", [(20480, 512, 256), (20480, 512, 1408), (110592, 512, 256), (512, 512, 256)])
+def test_gemm_residual_comp(hip, ref, M, N, K):
+    """s = a b^T + residual + e in f32 -> (y, e') = (bf16(s), bf16(s - y)): y must be THE bf16 rounding of s (up to f32 summation order
+    at rounding ties), y + e' must carry s to ~2^-16, and the launch must be bit-reproducible; the last shape cannot fill the chip and is
+    declined."""
     bf = torch.bfloat16
     a, b = rnd(M, K, dtype=bf, seed=1, scale=0.5), rnd(N, K, dtype=bf, seed=2, scale=K ** -0.5)
     res = rnd(M, N, dtype=bf, seed=3, scale=4.0)
     e1 = rnd(M, N, dtype=bf, seed=4, scale=4.0 * 2 ** -9)
-    e2 = rnd(M, N, dtype=bf, seed=5, scale=4.0 * 2 ** -9) if two else None
-    out = hip.gemm_residual_comp(a, b, res, e1, e2)
+    out = hip.gemm_residual_comp(a, b, res, e1)
     if (M // 256) * ((N + 255) // 256) < 160:
         assert out is None
         return
     y, e = out
-    s = a.float() @ b.float().t() + res.float() + e1.float() + (e2.float() if two else 0.0)
-    yr, er = ref.gemm_residual_comp(a, b, res, e1, e2)
+    s = a.float() @ b.float().t() + res.float() + e1.float()
+    yr, er = ref.gemm_residual_comp(a, b, res, e1)
     ulp = s.abs() * 2 ** -8 + 1e-30
     assert float((((y.float() - s).abs() / ulp) > 1.001).float().mean()) < 1e-3      # y is the nearest bf16 of s (|s| 2^-8 >= half a bf16 spacing; ties aside)
     close((y.float() + e.float()), s, rtol=0, atol=float(s.abs().max()) * 2 ** -15)
     assert float((y.float() + e.float() - s).norm() / s.norm()) < 3e-5                # against 2e-3 for the rounded value alone
     assert float((y.float() != yr.float()).float().mean()) < 2e-3                     # ties / summation order only
-    y2, e2_ = hip.gemm_residual_comp(a, b, res, e1, e2)
+    y2, e2_ = hip.gemm_residual_comp(a, b, res, e1)
     assert torch.equal(y, y2) and torch.equal(e, e2_)
 
 
 @pytest.mark.parametrize("shape", [(8, 6, 24, 24, 512), (2, 4, 30, 16, 512), (1, 3, 13, 24, 96), (2, 5, 7, 8, 64)])
-def test_peg_fwd_comp(hip, ref, shape):
-    """The marching PEG forward that also stores the rounding residue: y bit-identical to ctclip_peg_fwd, y + r = the f32 value."""
+@pytest.mark.parametrize("with_e", [False, True])
+def test_peg_fwd_comp(hip, ref, shape, with_e):
+    """The marching PEG forward on the compensated residual stream: s = x + e_in + conv(x): y + e_out = s to ~2^-16; without e_in, y is
+    bit-identical to ctclip_peg_fwd."""
     C, bf = shape[-1], torch.bfloat16
     x = rnd(*shape, dtype=bf, seed=1)
     w, b = rnd(C, 27, seed=3, scale=0.2), rnd(C, seed=4, scale=0.2)
-    y, r = hip.peg_fwd_comp(x, w, b)
-    assert torch.equal(y, hip.peg_fwd(x, w, b))
+    e_in = rnd(*shape, dtype=bf, seed=5, scale=2 ** -9) if with_e else None
+    y, r = hip.peg_fwd_comp(x, w, b, e_in)
+    if not with_e:
+        assert torch.equal(y, hip.peg_fwd(x, w, b))
     xc = x.float().permute(0, 4, 1, 2, 3)
     s = (torch.nn.functional.conv3d(torch.nn.functional.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), b, groups=C).permute(0, 2, 3, 4, 1) + x.float())
+    if with_e:
+        s = s + e_in.float()
     assert float((y.float() + r.float() - s).norm() / s.norm()) < 5e-5               # (f32 summation order of 27 taps)
     assert float((y.float() - s).norm() / s.norm()) > 5e-4                            # ... against the rounded value alone
-    y2, r2 = hip.peg_fwd_comp(x, w, b)
+    y2, r2 = hip.peg_fwd_comp(x, w, b, e_in)
     assert torch.equal(y, y2) and torch.equal(r, r2)
 
 
