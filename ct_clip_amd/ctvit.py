@@ -144,8 +144,9 @@ class Transformer(nn.Module):
         b, t, h, w = video_shape
         d = x.shape[1]
         tap = self.__dict__.get("layer_tap")      # test hook (never set by the product): tap(i, x) sees the residual stream at every layer boundary
-        # bf16 mode: the residual stream is the bf16 pair (x, e) -- x what the consumers read, e the rounding residue of the last add(s), added
-        # back in f32 by the next residual add (functional.residual_comp_enabled: the 72 roundings of a 24-layer stream stop accumulating)
+        # bf16 inference (or CTCLIP_RESIDUAL_COMP=1): the residual stream is the bf16 pair (x, e) -- x what the consumers read, e the rounding
+        # residue of the last add, added back in f32 by the next one (functional.residual_comp_enabled: the 72 roundings of a 24-layer stream
+        # stop accumulating)
         comp = Fn.residual_comp_enabled(x)
         e = None
         for i, layer in enumerate(self.layers):

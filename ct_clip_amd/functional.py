@@ -730,13 +730,23 @@ def peg_residual(x5, weight, bias, comp=None):
 
 
 # ---- compensated residual stream.  bf16 storage rounds the residual stream at each of its three adds per layer; over 24 layers those 72
-# roundings -- not the bf16 GEMM operands -- are the error of the bf16 mode (profiles/r03_bf16_error_budget.md: pre-VQ token error 1.5e-2 and
-# 96.8 % code agreement with them, 4.6e-3 and 99.1 % without).  The stream is therefore carried as a bf16 PAIR (x, e): x is what every
-# consumer reads (LayerNorm, the k/v projection, PEG's taps: one fresh rounding, not an accumulated one), e = the residue the roundings cut
-# off, added back in f32 inside the next residual add's epilogue, which emits the next pair.  e never enters autograd (backward is
-# unchanged) and is dead after the next add.  CTCLIP_RESIDUAL_COMP=0 switches it off (the round-2 behaviour).
+# roundings -- not the bf16 GEMM operands -- are the error of the bf16 mode (profiles/r03_bf16_error_budget.md: pre-VQ token error 1.6e-2 and
+# 96.4 % code agreement with them, 7.3e-3 and 98.4 % without, measured at 12+12 layers).  The stream can therefore be carried as a bf16 PAIR
+# (x, e): x is what every consumer reads (LayerNorm, the k/v projection, PEG's taps: one fresh rounding, not an accumulated one), e = the
+# residue the last rounding cut off, added back in f32 inside the next residual add (PEG kernel / GEMM epilogue), which emits the next pair.
+# e never enters autograd (backward is unchanged) and is dead after the next add.  It costs 680 MB of extra traffic per layer (+4.5 % of the
+# training step, measured), so the default policy is CTCLIP_RESIDUAL_COMP=auto: ON whenever no gradient is being recorded (zero-shot scoring,
+# latent export, frozen towers: fidelity of the latents to the f32 reference is what matters there), OFF inside a training forward.
+# =1 forces it everywhere (the mixed-precision semantics of torch.autocast, whose residual stream stays f32), =0 disables it.
 def residual_comp_enabled(x):
-    return x.dtype == torch.bfloat16 and os.environ.get("CTCLIP_RESIDUAL_COMP", "1") != "0"
+    if x.dtype != torch.bfloat16:
+        return False
+    mode = os.environ.get("CTCLIP_RESIDUAL_COMP", "auto").lower()
+    if mode in ("0", "off"):
+        return False
+    if mode in ("1", "on"):
+        return True
+    return not torch.is_grad_enabled()
 
 
 # ------------------------------------------------------------------------------------------ attention

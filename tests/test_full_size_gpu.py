@@ -153,8 +153,10 @@ TEACHER_BOUNDS = {"full1": dict(rel=1e-3, gn_rel=5e-2, cos_i=0.99998, cos_t=0.99
 # Free-running: the loss / gradient deviations are dominated by WHICH codes flip (2.1 % at 4+4 layers, 3.6 % at 12+12: a discrete, chaotic
 # event -- two builds of round 2 measured 1.15e-4 and 2.03e-3 for the same loss); bounds from the largest values seen.  The agreement itself is
 # what the bf16 residual stream allows (profiles/r03_bf16_error_budget.md: 0.968 emulated on the CPU oracle, 0.991 with an f32 residual stream).
-FREE_BOUNDS = {"full1": dict(rel=3e-3, gn_rel=0.3, agree=0.97, cos_i=0.96, cos_t=0.99985),
-               "full2": dict(rel=3e-3, gn_rel=0.3, agree=0.95, cos_i=0.95, cos_t=0.99985)}
+# (agreement / latent cosines come from the EVAL forward: compensated residual stream by default -- measured 0.9872 / 0.9878 at 4+4 and
+# 0.9841 / 0.9882 at 12+12; with the plain stream 0.9793 / 0.9804 and 0.9640 / 0.9737.)
+FREE_BOUNDS = {"full1": dict(rel=3e-3, gn_rel=0.3, agree=0.98, cos_i=0.965, cos_t=0.99985),
+               "full2": dict(rel=3e-3, gn_rel=0.3, agree=0.975, cos_i=0.965, cos_t=0.99985)}
 
 
 def test_bf16_full_size_teacher_forced(full):
@@ -196,14 +198,16 @@ def test_bf16_image_tower_with_f32_text_tower_teacher_forced(full):
     assert rel < 1e-3 and cos_t > 0.999999
 
 
-def test_layer_error_trace(full):
+def test_layer_error_trace(full, monkeypatch):
     """Where does a low-precision run leave the reference?  Relative error of the residual stream at every layer boundary against the
-    fixture's samples (full2 only: full1 holds two boundaries), f32 and bf16, printed as a table (committed under profiles/)."""
+    fixture's samples (full2 only: full1 holds two boundaries): f32, bf16 with the plain bf16 residual stream (training forward) and bf16
+    with the compensated stream (inference default), printed as a table (committed under profiles/)."""
     g = full[0]
     if "s1_in" not in g["intermediates"]:
         pytest.skip("fixture without per-layer samples")
     rows = {}
-    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+    for dtype, tag, comp in ((torch.float32, "f32", "0"), (torch.bfloat16, "bf16", "0"), (torch.bfloat16, "bf16 comp", "1")):
+        monkeypatch.setenv("CTCLIP_RESIDUAL_COMP", comp)
         g, clip, text, video = prepare(full, dtype, False)
         vt = clip.visual_transformer
         errs = {}
@@ -211,7 +215,6 @@ def test_layer_error_trace(full):
             tr.__dict__["layer_tap"] = (lambda i, x, pre=pre: errs.__setitem__(f"{pre}{i}_in", rel_err(g["intermediates"][f"{pre}{i}_in"], x)))
         try:
             with torch.no_grad():
-                toks = vt(video, return_encoded_tokens=True)
                 ids = vt(video, return_only_codebook_ids=True)
         finally:
             for tr in (vt.enc_spatial_transformer, vt.enc_temporal_transformer):
@@ -220,12 +223,15 @@ def test_layer_error_trace(full):
         rows[tag] = errs
     keys = [k for k in rows["f32"] if k.endswith("_in")]
     print(f"[{g['name']}] residual-stream relative error per layer boundary (vs the real reference, f32 CPU)")
-    print("   boundary        f32        bf16")
+    print("   boundary        f32        bf16   bf16 + compensated stream")
     for k in keys:
-        print(f"   {k:10s} {rows['f32'][k]:10.2e} {rows['bf16'][k]:10.2e}")
-    print(f"   VQ code agreement: f32 {rows['f32']['vq_agreement']:.5f}, bf16 {rows['bf16']['vq_agreement']:.5f}")
+        print(f"   {k:10s} {rows['f32'][k]:10.2e} {rows['bf16'][k]:10.2e} {rows['bf16 comp'][k]:10.2e}")
+    print(f"   VQ code agreement: f32 {rows['f32']['vq_agreement']:.5f}, bf16 {rows['bf16']['vq_agreement']:.5f}, "
+          f"bf16 + compensated stream {rows['bf16 comp']['vq_agreement']:.5f}")
     assert max(rows["f32"][k] for k in keys) < 1e-4
-    assert max(rows["bf16"][k] for k in keys) < 3e-2
+    assert max(rows["bf16"][k] for k in keys) < 3e-2                       # measured 1.64e-2 at the last boundary
+    assert max(rows["bf16 comp"][k] for k in keys) < 1.5e-2                # measured 7.3e-3
+    assert rows["bf16 comp"]["vq_agreement"] >= 0.975 > 0.0                # measured 0.9841 (plain stream: 0.9640)
 
 
 def test_zz_side_stream_backward_is_bit_identical(full1, tmp_path, monkeypatch):
