@@ -42,19 +42,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const float cs = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
-    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    const bool decay = weight_decay != 0.f && (!decay_mask4 || decay_mask4[i]);
+  // Two float4 groups per thread and trip, all eight 16-byte loads issued before the first use, non-temporal both ways: 28 bytes per
+  // parameter stream through once (7.95 GB for CT-CLIP's 284 M parameters) and nothing of it is read again before the next step.
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const int64_t idx[2] = {i0, i0 + stride};
+    const bool on1 = idx[1] < n4;
+    f32x4 pv[2], mv[2], vv[2], gv[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gg = gv[e] * cs;
-      if (decay) pv[e] *= 1.f - lr * weight_decay;
-      mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
-      vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
-      pv[e] -= step * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+    for (int u = 0; u < 2; ++u) {
+      const int64_t i = (u == 0 || on1) ? idx[u] : idx[0];       // (clamped: never branch around a load)
+      pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+      mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+      gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
     }
-    reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !on1) break;
+      const int64_t i = idx[u];
+      const bool decay = weight_decay != 0.f && (!decay_mask4 || decay_mask4[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = gv[u][e] * cs;
+        if (decay) pv[u][e] *= 1.f - lr * weight_decay;
+        mv[u][e] = beta1 * mv[u][e] + (1.f - beta1) * gg;
+        vv[u][e] = beta2 * vv[u][e] + (1.f - beta2) * gg * gg;
+        pv[u][e] -= step * mv[u][e] / (sqrtf(vv[u][e]) / bc2_sqrt + eps);
+      }
+      __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p) + i);
+      __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m) + i);
+      __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v) + i);
+    }
   }
   if (blockIdx.x == 0)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
