@@ -226,6 +226,11 @@ class CTClipTrainer(nn.Module):
         if self.is_main:
             print(msg)
 
+    def close(self):
+        """Detach this trainer from the process-global hooks it installed (the gradient reducer's grad-ready hook): a later model or
+        trainer in the same process must not call into this one's reducer."""
+        self.reducer.uninstall()
+
     @property
     def is_main(self):
         return _dist.rank() == 0
