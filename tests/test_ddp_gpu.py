@@ -118,3 +118,18 @@ def test_bench_self_launches_without_a_launcher(tmp_path):
                        "--no-attn-block", "--profile-steps", "0"], env, str(tmp_path))
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert abs(rec["loss"] - 1.386) < 0.2          # ln 4 for random towers: the loss saw the gathered batch
+
+
+@pytest.mark.parametrize("workload,cfgi", [("lipro", 4), ("vocabfine", 3)])
+def test_bench_finetune_workloads_emit_the_contract_line(tmp_path, workload, cfgi):
+    """bench.py --workload lipro / vocabfine (BASELINE.json configs[4] / configs[3]) at a reduced geometry: one JSON line with the contract's
+    keys, a roofline object and a finite loss."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    rec = _bench_line(["--workload", workload, "--image", "120", "--frames", "60", "--spatial-depth", "1", "--temporal-depth", "1", "--batch", "2",
+                       "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "1", "--text-len", "32"], env, str(tmp_path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in rec, key
+    assert f"configs[{cfgi}]" in rec["metric"] and rec["unit"] == "volumes/s" and rec["value"] > 0 and rec["n_gpus"] == 1
+    assert "workload" in rec["config"] and rec["roofline"]["frac"] > 0 and rec["loss"] == rec["loss"]

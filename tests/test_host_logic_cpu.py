@@ -324,3 +324,25 @@ def test_compensated_residual_stream(ref_backend, monkeypatch):
         if g32[n].norm() > 1e-6:
             assert rel(gc[n].float(), g32[n]) < max(0.1, 2 * rel(gb[n].float(), g32[n])), n
     assert rel(dxc, dx32) < 0.1
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` with no launcher: bench.py re-executes its own command line under torch.distributed.run with one rank per
+    GPU on 127.0.0.1 and a free port (the driver's N > 1 invocation must start without edits)."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
