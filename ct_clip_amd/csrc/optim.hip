@@ -42,24 +42,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const float cs = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   const int64_t n4 = n / 4;
-  // Two float4 groups per thread and trip, all eight 16-byte loads issued before the first use, non-temporal both ways: 28 bytes per
+  // ADAM_U float4 groups per thread and trip, all 4 * ADAM_U 16-byte loads issued before the first use, non-temporal both ways: 28 bytes per
   // parameter stream through once (7.95 GB for CT-CLIP's 284 M parameters) and nothing of it is read again before the next step.
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
-    const int64_t idx[2] = {i0, i0 + stride};
-    const bool on1 = idx[1] < n4;
-    f32x4 pv[2], mv[2], vv[2], gv[2];
+  constexpr int ADAM_U = 4;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += ADAM_U * stride) {
+    int64_t idx[ADAM_U];
+    f32x4 pv[ADAM_U], mv[ADAM_U], vv[ADAM_U], gv[ADAM_U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t i = (u == 0 || on1) ? idx[u] : idx[0];       // (clamped: never branch around a load)
+    for (int u = 0; u < ADAM_U; ++u) {
+      idx[u] = i0 + u * stride;
+      const int64_t i = idx[u] < n4 ? idx[u] : i0;       // (clamped: never branch around a load)
       pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
       mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
       vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
       gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !on1) break;
+    for (int u = 0; u < ADAM_U; ++u) {
+      if (idx[u] >= n4) break;
       const int64_t i = idx[u];
       const bool decay = weight_decay != 0.f && (!decay_mask4 || decay_mask4[i]);
 #pragma unroll
