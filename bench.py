@@ -1,7 +1,8 @@
 """bench.py -- CT-CLIP training-step throughput on MI355X (BASELINE.json metric: CT volumes/s/node at 480x480x240, bs=8/GPU).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`)
+    python bench.py --gpus N --steps K --warmup W [--workload train|lipro|vocabfine]
+    (N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or run as plain
+     `python bench.py --gpus N`: bench.py then re-executes itself under that launcher, one rank per GPU, rank 0 prints the line)
 
 A "step" is one full optimisation step of the hot path (scripts/CTCLIPTrainer.py:233-264): text tower + image tower forward,
 gathered-negatives CLIP loss, backward, gradient all-reduce (N > 1), global grad-norm clip, Adam -- on synthetic inputs that are
@@ -24,6 +25,10 @@ Extra objects on the line:
   cpu_baseline -- the CPU oracle (a restatement of the reference, kind "port") timed on the host cores on a bounded sample: one
                   training step on ONE volume at the bench's own depth (same configuration as `value`), and B=2 at the reference scripts'
                   4+4 layers when the time bound allows.
+  reference_depth_4+4 -- the same train step with the reference scripts' own 4+4 transformer layers (run_train.py:17-27), timed after the
+                  main configuration (--no-reference-depth skips it).
+--workload lipro / vocabfine: BASELINE.json configs[4] / configs[3] (one CT-LiPro step at batch 16 with the frozen tower; one VocabFine step =
+one volume x 18 prompt pairs), same contract line with `roofline` and a bounded `cpu_baseline`.
 """
 import argparse
 import json
