@@ -170,6 +170,8 @@ def run_cpu_baseline_bounded(args, sdepth, tdepth):
             samples[rec.pop("tag")] = rec
     if "bench_depth" in samples:
         res = samples["bench_depth"]
+        res["note"] = ("kind 'port': oracle/ctclip_oracle.py, a CPU restatement of the reference modules (pinned against the real reference by "
+                       "tests/golden/*, oracle/gen_golden.py); the reference itself is Python under /root/reference and cannot travel to the GPU box")
         if "reference_depth_b2" in samples:
             res["reference_depth_b2"] = samples["reference_depth_b2"]
         elif timed_out:
