@@ -197,8 +197,8 @@ class VocabFineTrainer:
         fused=True (default) computes the same numbers from ONE pass of each tower: within a step the weights do not change, so the image
         transformer's output is identical in all 18 forwards -- only the vector quantiser differs (train mode: its EMA update after every
         forward moves the codebook the next forward reads).  Hence: patch embedding + transformers once; all prompts through BERT as one
-        batch; the quantiser + pooling + latent projection re-applied per pathology in the reference's order (same EMA sequence); the group
-        losses summed and ONE backward (backward is linear in the incoming gradient, so the sum of the reference's three backwards equals
+        batch; the quantiser + pooling re-applied per pathology in the reference's order (same EMA sequence), the latent projection of all 18
+        pooled vectors as one batch; the group losses summed and ONE backward (backward is linear in the incoming gradient, so the sum of the reference's three backwards equals
         the backward of the summed loss).  M = 13 824 token rows per launch either way -- but 1 image-tower pass instead of 18."""
         model = self.model
         model.train()
@@ -219,14 +219,18 @@ class VocabFineTrainer:
         ids = torch.cat([tp.input_ids for tp in token_pairs]).to(dev)
         mask = torch.cat([tp.attention_mask for tp in token_pairs]).to(dev)
         text_lat = model.text_latents_raw(ids, mask)                                 # (2 P, Dl) f32, every prompt in one BERT batch
+        # the quantiser per pathology, in the reference's order (its EMA update after every forward moves the codebook the next one reads);
+        # the pooled vectors of all pathologies then go through the 151-M-parameter latent projection as ONE batch (one pass over the
+        # 302-MB weight forward, one 604-MB weight-gradient write backward instead of one per pathology)
+        pooled = []
+        for j in range(len(token_pairs)):
+            q, _ = vt.vq(pre)
+            pooled.append(Fn.PoolFn.apply(q.view(b, t, -1)))                          # (1, h*w*d)
+        image_lat = Fn.visual_latent(torch.cat(pooled, dim=0), model.to_visual_latent.weight)      # (P, Dl) f32, pre-l2norm
         total = None
         for k in range(0, len(token_pairs), self.group_size):
-            sims = []
-            for j in range(k, min(k + self.group_size, len(token_pairs))):
-                q, _ = vt.vq(pre)                                                    # EMA update j: the next pathology reads the moved codebook
-                enc_image = Fn.PoolFn.apply(q.view(b, t, -1))
-                image_lat = Fn.visual_latent(enc_image, model.to_visual_latent.weight)
-                sims.append(Fn.LatentSimilarityFn.apply(text_lat[2 * j:2 * j + 2], image_lat, model.temperature))
+            sims = [Fn.LatentSimilarityFn.apply(text_lat[2 * j:2 * j + 2], image_lat[j:j + 1], model.temperature)
+                    for j in range(k, min(k + self.group_size, len(token_pairs)))]
             st = torch.stack(sims)
             loss = PairSoftmaxMseFn.apply(st)
             total = loss if total is None else total + loss
