@@ -541,6 +541,8 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help=argparse.SUPPRESS)      # (default on since round 3; kept for old command lines)
     ap.add_argument("--no-reference-depth", action="store_true", help="skip the second timed configuration (reference scripts' 4+4 layers)")
+    ap.add_argument("--input-dist", default="uniform", choices=["uniform", "normal"],
+                    help="synthetic voxels: uniform [-1, 1] (default) or N(0, 0.3) clamped to [-1, 1] (SURVEY.md 8d: a second distribution, for DVFS honesty)")
     ap.add_argument("--workload", default="train", choices=["train", "lipro", "vocabfine"],
                     help="train = BASELINE.json configs[1]/[2] (default); lipro = configs[4] (ClassFine / CT-LiPro step, frozen tower, batch 16); "
                          "vocabfine = configs[3] (VocabFine step: 18 prompt pairs per volume)")
@@ -604,7 +606,10 @@ def main():
         clip.train()
         g = torch.Generator().manual_seed(1234 + rank)
         gd = torch.Generator(device=device).manual_seed(1234 + rank)
-        video = torch.rand(args.batch, 1, args.frames, args.image, args.image, generator=gd, device=device) * 2 - 1
+        if args.input_dist == "normal":
+            video = (torch.randn(args.batch, 1, args.frames, args.image, args.image, generator=gd, device=device) * 0.3).clamp_(-1, 1)
+        else:
+            video = torch.rand(args.batch, 1, args.frames, args.image, args.image, generator=gd, device=device) * 2 - 1
         ids, mask = synth_text(args.batch, args.text_len, g, device)
         text = Text(ids, mask)
 
@@ -669,7 +674,8 @@ def main():
         "metric": "CT volumes/sec/node (480x480x240, bs=8/GPU), full training step + CTViT MFMA util % (attn_block)",
         "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic (uniform [-1,1] volumes generated on device, random token ids; random-init weights)",
+        "dtype": args.dtype, "data": ("synthetic (uniform [-1,1] volumes generated on device, random token ids; random-init weights)" if args.input_dist == "uniform"
+                                      else "synthetic (N(0, 0.3) voxels clamped to [-1,1], generated on device, random token ids; random-init weights)"),
         "config": {"workload": f"CT-CLIP train step: CTViT {args.image}x{args.image}x{args.frames} patch 20x20x10 dim 512 "
                                f"{sdepth}+{tdepth} layers + BERT-base T={args.text_len}, batch {args.batch}/GPU, global batch {world * args.batch}, "
                                "gathered-negatives InfoNCE, grad clip 0.5, Adam",
