@@ -387,6 +387,33 @@ class HipBackend:
         _lib.check(rc, "ctclip_attn2_prep")
         return qh, kh, vh, qinv, kinv
 
+    def gemm_headnorm(self, a, b, sections):
+        """The attention-operand epilogue: a (M, K) @ b (nsec * 256, K)^T written per 256-column section as head-planar (8, M, 32) bf16.
+        sections: [(scale (32,) f32 | None, mult)]: with a scale vector the section is l2-normalised per head and scaled (q~ / k^ of
+        ctclip_attn2_prep) and its inverse norms (M, 8) f32 are returned, None = plain copy (v).  -> [(planar, inv | None)] or None when the
+        large-tile kernel does not serve the shape."""
+        M, K = a.shape
+        nsec = len(sections)
+        if a.dtype != torch.bfloat16 or M % 256 or K % 64 or b.shape[0] != nsec * 256 or not 1 <= nsec <= 3:
+            return None
+        outs, args = [], []
+        for i in range(3):
+            if i < nsec:
+                sc, mult = sections[i]
+                o = torch.empty((8, M, 32), dtype=a.dtype, device=a.device)
+                inv = torch.empty((M, 8), dtype=torch.float32, device=a.device) if sc is not None else None
+                if sc is not None:
+                    assert sc.dtype == torch.float32 and sc.numel() == 32 and sc.is_contiguous()
+                outs.append((o, inv))
+                args += [_p(o), _p(inv), _p(sc), float(mult)]
+            else:
+                args += [None, None, None, 0.0]
+        rc = self.lib.ctclip_gemm_headnorm(_p(a), _p(b), M, nsec, K, _rowmajor(a, "a"), _rowmajor(b, "b"), *args, dcode(a.dtype), _stream())
+        if rc == -2:      # CTCLIP_EUNSUPPORTED
+            return None
+        _lib.check(rc, "ctclip_gemm_headnorm")
+        return outs
+
     def attn2_fwd(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, nseq, L):
         H, M, _ = qh.shape
         gh, gw = bias_grid if tab is not None else (0, 0)

@@ -454,6 +454,8 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
 // ---------------------------------------------------------------------------------------------------- fused GEGLU in-projection
 int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, const void* dG, int64_t M, int hp, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldu, int64_t ldg, int64_t lddg, hipStream_t stream);
+int ctclip_gemm_nt_headnorm_try(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb, void* const* out,
+                                float* const* inv, const float* const* scale, const float* mult, hipStream_t stream);
 int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp,
                                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, hipStream_t stream);
 int ctclip_gemm_nt_dgeglu_try(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
@@ -531,5 +533,24 @@ extern "C" int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, 
   if (!A || !B || !C || !E || !residual || !comp || M < 1 || N < 1 || K < 1) { ctclip_set_error("gemm_residual_comp: bad args"); return CTCLIP_EBADARG; }
   if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
   const int rc = ctclip_gemm_nt_rescomp_try(A, B, C, E, residual, comp, M, N, K, lda, ldb, ldc, ldr, stream);
+  return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
+}
+
+// The q and k|v projections of the spatial attention (attention.py:141-154: to_q / to_kv, split heads, l2norm, * q_scale / k_scale) with the
+// attention kernels' operand layout written by the GEMM itself: replaces nn.Linear + ctclip_attn2_prep.  A (M, K) bf16, B (nsec * 256, K) bf16
+// (k-contiguous); per 256-column section s (8 heads x 32): inv_s != NULL -> out_s[h][m][d] = bf16(a_m . b_n) / max(|head row|, 1e-12) *
+// scale_s[d] * mult_s (head-planar [8][M][32] bf16), inv_s[m * 8 + h] = the inverse norm (f32); inv_s == NULL -> out_s = the head-planar copy
+// (v).  The arithmetic is ctclip_attn2_prep's on the bf16-rounded projection.  CTCLIP_EUNSUPPORTED unless bf16, M % 256 == 0, K % 64 == 0,
+// 1 <= nsec <= 3 and enough tiles to fill the chip.
+extern "C" int ctclip_gemm_headnorm(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb,
+                                    void* out0, float* inv0, const float* scale0, float mult0, void* out1, float* inv1, const float* scale1,
+                                    float mult1, void* out2, float* inv2, const float* scale2, float mult2, int dtype, hipStream_t stream) {
+  if (!A || !B || !out0 || M < 1 || K < 1) { ctclip_set_error("gemm_headnorm: bad args"); return CTCLIP_EBADARG; }
+  if (dtype != DT_BF16) return CTCLIP_EUNSUPPORTED;
+  void* const out[3] = {out0, out1, out2};
+  float* const inv[3] = {inv0, inv1, inv2};
+  const float* const scale[3] = {scale0, scale1, scale2};
+  const float mult[3] = {mult0, mult1, mult2};
+  const int rc = ctclip_gemm_nt_headnorm_try(A, B, M, nsec, K, lda, ldb, out, inv, scale, mult, stream);
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }

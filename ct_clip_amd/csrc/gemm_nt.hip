@@ -50,6 +50,9 @@
 #ifndef NT_DG_ROWS
 #define NT_DG_ROWS 2         // rows of u in flight per lane in the out-projection grad-input + GEGLU backward epilogue (1, 2 or 4)
 #endif
+#ifndef NT_PLANAR_TEST
+#define NT_PLANAR_TEST 0
+#endif
 #ifndef NT_COUNTED_EPI
 // 1 = the first step of a tile waits with vmcnt(GL + n) for its panels only, not for the previous tile's epilogue stores (n = the VMEM
 // instructions of that epilogue).  Measured +1..3 % on the GEMMs (profiles/r02_gemm_epilogue_experiments.md) and bit-identical results in
@@ -92,6 +95,11 @@ struct NtParams {
   // s = A B^T + residual + comp1 in f32 and stores C = bf16(s) AND comp_out = bf16(s - C): the 72 bf16 roundings of a 24-layer
   // residual stream no longer accumulate (profiles/r03_bf16_error_budget.md).  comp rows use ldr, comp_out rows use ldc.
   const bf16_t* comp1; bf16_t* comp_out;
+  // Attention-operand epilogue (ctclip_gemm_headnorm, epilogue family 4): the q / k|v projections of the spatial attention write the
+  // operands the attention kernels read -- head-planar [H][M][32] bf16 -- straight from the accumulators: per 256-column section s = n0 / 256
+  // (8 heads of 32): hn_inv[s] != null: x~ = bf16(acc) / max(|row of the head|, 1e-12) * hn_scale[s][d] * hn_mult[s] and the inverse norm
+  // to hn_inv[s][row * 8 + head] (exactly ctclip_attn2_prep's arithmetic on the bf16-rounded projection); null: plain copy (v).
+  bf16_t* hn_out[3]; float* hn_inv[3]; const float* hn_scale[3]; float hn_mult[3];
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -569,6 +577,45 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
         }
        }
         pn = 0;
+      } else if (EPI == 4) {      // head-planar attention operands (full row tiles, N a multiple of 256: checked by the launcher)
+        const int sec = (int)(n0 / TN);                          // tile-uniform: 0 = first 256 columns, ...
+        bf16_t* outp = sec == 0 ? p.hn_out[0] : (sec == 1 ? p.hn_out[1] : p.hn_out[2]);
+        float* invp = sec == 0 ? p.hn_inv[0] : (sec == 1 ? p.hn_inv[1] : p.hn_inv[2]);
+        const float* scp = sec == 0 ? p.hn_scale[0] : (sec == 1 ? p.hn_scale[1] : p.hn_scale[2]);
+        const float mult = sec == 0 ? p.hn_mult[0] : (sec == 1 ? p.hn_mult[1] : p.hn_mult[2]);
+        const int head = wn * 4 + (li_e >> 2), d0 = (li_e & 3) * 8;      // a head = 32 consecutive columns = 4 lanes x 8
+        float sc[8];
+        if (invp) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b) sc[b] = scp[d0 + b];
+        }
+        bf16_t* obase = outp + ((int64_t)head * p.M + rbase) * 32 + d0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t roff = (int64_t)(a * 16 + r);
+            u32x4 d;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[b] = pack2bf(acc[a][2 * b][r] * p.alpha, acc[a][2 * b + 1][r] * p.alpha);
+            if (invp) {      // (tile-uniform)
+              float v[8];
+#pragma unroll
+              for (int b = 0; b < 4; ++b) { v[2 * b] = __uint_as_float(d[b] << 16); v[2 * b + 1] = __uint_as_float(d[b] & 0xffff0000u); }
+              float ss = 0.f;
+#pragma unroll
+              for (int b = 0; b < 8; ++b) ss += v[b] * v[b];
+              ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+              const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+              for (int b = 0; b < 8; ++b) v[b] *= inv * sc[b] * mult;
+#pragma unroll
+              for (int b = 0; b < 4; ++b) d[b] = pack2bf(v[2 * b], v[2 * b + 1]);
+              if ((li_e & 3) == 0) invp[(rbase + roff) * 8 + head] = inv;
+            }
+            store16<NONTEMPORAL>(obase + roff * 32, d);
+          }
+        pn = 0;
       } else if (EPI != 0) {
         // (the launchers set the parameters of the instantiation's own family)
       } else if (fast_res) {
@@ -618,7 +665,12 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
               u32x4 d;
 #pragma unroll
               for (int b = 0; b < 4; ++b) d[b] = pack2bf(v[2 * b], v[2 * b + 1]);
+#if NT_PLANAR_TEST      // TIMING EXPERIMENT ONLY (tools/build_variant.py ... gemm_nt.hip:NT_PLANAR_TEST=1): the head-planar layout [N / 32][M][32] instead
+              // of token-major rows -- what would an attention-prep epilogue's 64-byte stores cost?  (profiles/r03_ab_experiments.md)
+              store16<NONTEMPORAL>(reinterpret_cast<bf16_t*>(p.C) + ((col >> 5) * p.M + row) * 32 + (col & 31), d);
+#else
               store16<NONTEMPORAL>(reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col, d);
+#endif
             }
           }
       } else if (!cols_out) {
@@ -685,12 +737,13 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 }  // namespace
 
 static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
-  const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : (p.comp_out ? 3 : 0));
+  const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : (p.comp_out ? 3 : (p.hn_out[0] ? 4 : 0)));
   static bool raised = false;
   if (!raised) {
-    const void* fns[8] = {(const void*)gemm_nt_kernel<false, 0>, (const void*)gemm_nt_kernel<true, 0>, (const void*)gemm_nt_kernel<false, 1>,
-                          (const void*)gemm_nt_kernel<true, 1>, (const void*)gemm_nt_kernel<false, 2>, (const void*)gemm_nt_kernel<true, 2>,
-                          (const void*)gemm_nt_kernel<false, 3>, (const void*)gemm_nt_kernel<true, 3>};
+    const void* fns[10] = {(const void*)gemm_nt_kernel<false, 0>, (const void*)gemm_nt_kernel<true, 0>, (const void*)gemm_nt_kernel<false, 1>,
+                           (const void*)gemm_nt_kernel<true, 1>, (const void*)gemm_nt_kernel<false, 2>, (const void*)gemm_nt_kernel<true, 2>,
+                           (const void*)gemm_nt_kernel<false, 3>, (const void*)gemm_nt_kernel<true, 3>, (const void*)gemm_nt_kernel<false, 4>,
+                           (const void*)gemm_nt_kernel<true, 4>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
     raised = true;
@@ -700,7 +753,7 @@ static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
   const dim3 grid((unsigned)ncu), block(NTH);
 #define NT_GO(E) do { if (nontemporal) hipLaunchKernelGGL((gemm_nt_kernel<true, E>), grid, block, NPANEL * PANEL, stream, p); \
                       else hipLaunchKernelGGL((gemm_nt_kernel<false, E>), grid, block, NPANEL * PANEL, stream, p); } while (0)
-  if (epi == 1) NT_GO(1); else if (epi == 2) NT_GO(2); else if (epi == 3) NT_GO(3); else NT_GO(0);
+  if (epi == 1) NT_GO(1); else if (epi == 2) NT_GO(2); else if (epi == 3) NT_GO(3); else if (epi == 4) NT_GO(4); else NT_GO(0);
 #undef NT_GO
   return ctclip_check_launch("gemm_nt");
 }
@@ -759,6 +812,28 @@ int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, c
   p.out_dtype = DT_BF16; p.res_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
   p.comp1 = (const bf16_t*)comp; p.comp_out = (bf16_t*)E;
   return nt_launch(p, 2 * M * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
+}
+
+// The q / k|v projections of the spatial attention with ctclip_attn2_prep folded into the epilogue: the N = nsec * 256 output columns go, per
+// 256-column section, to out[s] as head-planar [8][M][32] bf16 (normalised + scaled when inv[s] is given, copied otherwise).  Returns 1 when
+// the shape is not eligible.
+int ctclip_gemm_nt_headnorm_try(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb, void* const* out,
+                                float* const* inv, const float* const* scale, const float* mult, hipStream_t stream) {
+  const int64_t N = (int64_t)nsec * TN;
+  if (nsec < 1 || nsec > 3 || K % TK || K / TK < 2 || M % TM) return 1;
+  if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
+  const int64_t ntm = M / TM, ntn = nsec;
+  if (ntm * ntn < 160) return 1;
+  NtParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+  p.out_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
+  for (int s = 0; s < 3; ++s) {
+    const int t = s < nsec ? s : 0;
+    if (!out[t] || (reinterpret_cast<uintptr_t>(out[t]) % 16) || (inv[t] && !scale[t])) return 1;
+    p.hn_out[s] = (bf16_t*)out[t]; p.hn_inv[s] = inv[t]; p.hn_scale[s] = scale[t]; p.hn_mult[s] = mult[t];
+  }
+  return nt_launch(p, M * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
 }
 
 // Feed-forward in-projection with the GEGLU fused into the epilogue (attention.py:39-48).  B = the in-projection weight with its

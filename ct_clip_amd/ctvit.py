@@ -162,10 +162,8 @@ class Transformer(nn.Module):
                 x = Fn.peg_residual(x.view(b, t, h, w, d), peg.dsconv.weight, peg.dsconv.bias).view(-1, d)
             # x = attn(x) + x  -- q from LayerNorm(x), k/v from the RAW x (attention.py:139-143)
             xn, x_kv, x = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)   # the three consumers of x: LayerNorm, to_kv, residual
-            q = Fn.linear(xn, attn.to_q.weight)
-            kv = Fn.linear(x_kv, attn.to_kv.weight)
-            o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads, attn.dim_head,
-                                    float(attn.scale), bias_grid)
+            o = Fn.qkv_attention(xn, x_kv, attn.to_q.weight, attn.to_kv.weight, attn.q_scale, attn.k_scale, attn_bias, nseq, L, attn.heads,
+                                 attn.dim_head, float(attn.scale), bias_grid)
             if comp:
                 x, e = Fn.linear(o, attn.to_out.weight, residual=x, comp=e)
             else:

@@ -12,6 +12,7 @@ Weight handling
 """
 import os
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -815,60 +816,128 @@ class CosineAttn2Fn(Function):
         ctx.save_for_backward(qh, kh, vh, qinv, kinv, o, lse2, tabc if tabc is not None else q.new_empty(0))
         ctx.scales = (q_scale, k_scale)
         ctx.dims = (nseq, L, H, D, scale, tab is not None, bias_grid, q.dtype)
-        # the layers that share one table (ctvit.py:293): the table gradient of all of them is handed to autograd by the FIRST layer (the
-        # last one in backward) when the weight-gradient stream is on -- see backward
-        ctx.tab_users = None
-        if tab is not None and tab.requires_grad:
-            st = tab.__dict__.setdefault("_ctclip_tab_users", {"n": 0, "acc": None})
-            ctx.tab_users, ctx.tab_index = st, st["n"]
-            st["n"] += 1
+        _attn2_register_table(ctx, tab)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qh, kh, vh, qinv, kinv, o, lse2, tab = ctx.saved_tensors
+        dq, dkv, dqs, dks, dtab = _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, ctx.needs_input_grad[4])
+        return (dq, dkv, dqs, dks, dtab, None, None, None, None, None, None)
+
+
+def _attn2_register_table(ctx, tab):
+    """The layers that share one position-bias table (ctvit.py:293): the table gradient of all of them is handed to autograd by the FIRST
+    layer (the last one in backward) when the weight-gradient stream is on -- see _attn2_backward."""
+    ctx.tab_users = None
+    if tab is not None and tab.requires_grad:
+        st = tab.__dict__.setdefault("_ctclip_tab_users", {"n": 0, "acc": None})
+        ctx.tab_users, ctx.tab_index = st, st["n"]
+        st["n"] += 1
+
+
+def _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, need_dtab):
+    """Backward of the slab attention on prepared operands + the l2norm / scale backward (un-prep): -> token-major dq (M, HD), dkv (M, 2 HD),
+    the scale gradients (None when they went to the flat gradient buffer) and the table gradient.  ctx carries dims / scales / tab_users."""
+    be = B()
+    nseq, L, H, D, scale, has_tab, bias_grid, dtype = ctx.dims
+    q_scale, k_scale = ctx.scales
+    qs, ks = q_scale.detach(), k_scale.detach()
+    HD = H * D
+    do = do.contiguous()
+    want_dtab = has_tab and need_dtab
+    side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
+    if side is not None:
+        # The table gradient is a leaf until the position-bias MLP's backward, which runs after the FIRST layer's attention backward.
+        # Its pass (a third recomputation of S and dP) goes to the weight-gradient stream, under the rest of this layer's backward;
+        # the layers' tables are summed there, in backward order, and the first layer joins the stream and returns the sum.
+        dqh, dkh, dvh, ws = be.attn2_bwd(qh, kh, vh, tab, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, True, defer_dtab=True)
+        st = ctx.tab_users
+        side.wait_stream(torch.cuda.current_stream(do.device))
+        for t in (qh, kh, vh, lse2, tab, ws):
+            t.record_stream(side)
+        _WG["used"].add(do.device.index)
+        with torch.cuda.stream(side):
+            d = be.attn2_bwd_dbias(qh, kh, vh, tab, bias_grid, qs, ks, scale, lse2, nseq, L, ws)
+            if st["acc"] is None:
+                st["acc"] = d
+            else:
+                be.accumulate(st["acc"], d)
+        dtab = None
+        if ctx.tab_index == 0:
+            torch.cuda.current_stream(do.device).wait_stream(side)
+            dtab, st["acc"], st["n"] = st["acc"], None, 0
+            dtab.record_stream(torch.cuda.current_stream(do.device))
+    else:
+        dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, want_dtab)
+        if ctx.tab_users is not None and ctx.tab_index == 0:
+            ctx.tab_users["n"], ctx.tab_users["acc"] = 0, None
+    M = o.shape[0]
+    dq = torch.empty((M, HD), dtype=dtype, device=o.device)
+    dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)
+    qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
+    dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
+    dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
+    be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, scale, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
+    return dq, dkv, (None if qs_sink is not None else dqs), (None if ks_sink is not None else dks), dtab
+
+
+class QkvAttn2Fn(Function):
+    """to_q / to_kv + the slab attention as ONE node (attention.py:139-178 for the spatial transformer, bf16): the two projection GEMMs write
+    the attention kernels' operands themselves -- head-planar q~ = l2norm(q) q_scale (scale log2 e), k^ = l2norm(k) k_scale, v, and the
+    inverse norms -- from their epilogues (ctclip_gemm_headnorm: ctclip_attn2_prep's arithmetic on the bf16-rounded projection), so the
+    token-major q / kv tensors and the prep pass (340 MB of traffic per layer) do not exist.  Backward = CosineAttn2Fn's (slab kernels +
+    un-prep, which needs only the planar operands and the inverse norms) followed by the two Linear backwards."""
+
+    @staticmethod
+    def forward(ctx, xn, x_kv, wq, wkv, wsh_q, wsh_kv, q_scale, k_scale, tab, nseq, L, H, D, scale, bias_grid):
+        be = B()
+        qs, ks = q_scale.detach(), k_scale.detach()
+        c = float(np.float32(scale) * np.float32(LOG2E))      # (f32 product, as ctclip_attn2_prep forms it)
+        (qh, qinv), = be.gemm_headnorm(xn, wsh_q, [(qs, c)])
+        (kh, kinv), (vh, _) = be.gemm_headnorm(x_kv, wsh_kv, [(ks, 1.0), (None, 1.0)])
+        tabc = tab.detach().contiguous() if tab is not None else None
+        o, lse2 = be.attn2_fwd(qh, kh, vh, tabc, bias_grid, qs, ks, scale, nseq, L)
+        ctx.save_for_backward(xn, x_kv, wsh_q, wsh_kv, qh, kh, vh, qinv, kinv, o, lse2, tabc if tabc is not None else xn.new_empty(0))
+        ctx.scales, ctx.weights = (q_scale, k_scale), (wq, wkv)
+        ctx.dims = (nseq, L, H, D, scale, tab is not None, bias_grid, xn.dtype)
+        _attn2_register_table(ctx, tab)
         return o
 
     @staticmethod
     def backward(ctx, do):
         be = B()
-        qh, kh, vh, qinv, kinv, o, lse2, tab = ctx.saved_tensors
-        nseq, L, H, D, scale, has_tab, bias_grid, dtype = ctx.dims
-        q_scale, k_scale = ctx.scales
-        qs, ks = q_scale.detach(), k_scale.detach()
-        HD = H * D
-        do = do.contiguous()
-        want_dtab = has_tab and ctx.needs_input_grad[4]
-        side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
-        if side is not None:
-            # The table gradient is a leaf until the position-bias MLP's backward, which runs after the FIRST layer's attention backward.
-            # Its pass (a third recomputation of S and dP) goes to the weight-gradient stream, under the rest of this layer's backward;
-            # the layers' tables are summed there, in backward order, and the first layer joins the stream and returns the sum.
-            dqh, dkh, dvh, ws = be.attn2_bwd(qh, kh, vh, tab, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, True, defer_dtab=True)
-            st = ctx.tab_users
-            side.wait_stream(torch.cuda.current_stream(do.device))
-            for t in (qh, kh, vh, lse2, tab, ws):
-                t.record_stream(side)
-            _WG["used"].add(do.device.index)
-            with torch.cuda.stream(side):
-                d = be.attn2_bwd_dbias(qh, kh, vh, tab, bias_grid, qs, ks, scale, lse2, nseq, L, ws)
-                if st["acc"] is None:
-                    st["acc"] = d
-                else:
-                    be.accumulate(st["acc"], d)
-            dtab = None
-            if ctx.tab_index == 0:
-                torch.cuda.current_stream(do.device).wait_stream(side)
-                dtab, st["acc"], st["n"] = st["acc"], None, 0
-                dtab.record_stream(torch.cuda.current_stream(do.device))
-        else:
-            dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, want_dtab)
-            if ctx.tab_users is not None and ctx.tab_index == 0:
-                ctx.tab_users["n"], ctx.tab_users["acc"] = 0, None
-        M = o.shape[0]
-        dq = torch.empty((M, HD), dtype=dtype, device=o.device)
-        dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)
-        qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
-        dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
-        dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
-        be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, scale, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
-        return (dq, dkv, None if qs_sink is not None else dqs, None if ks_sink is not None else dks, dtab,
-                None, None, None, None, None, None)
+        xn, x_kv, wsh_q, wsh_kv, qh, kh, vh, qinv, kinv, o, lse2, tab = ctx.saved_tensors
+        wq, wkv = ctx.weights
+        dq, dkv, dqs, dks, dtab = _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, ctx.needs_input_grad[8])
+        outs = []
+        for dy, x, w, wsh, need in ((dq, xn, wq, wsh_q, ctx.needs_input_grad[0]), (dkv, x_kv, wkv, wsh_kv, ctx.needs_input_grad[1])):
+            N, K = w.shape
+            segs = [(0, N, 0)]
+            dw = weight_grad(dy, x, w, segs, K) if w.requires_grad else None      # (weight-gradient stream: under the grad-input GEMM below)
+            dx = be.gemm(dy, transposed_shadow(w, wsh, segs)) if need else None
+            outs.append((dx, dw))
+        (dxn, dwq), (dxkv, dwkv) = outs
+        return (dxn, dxkv, dwq, dwkv, None, None, dqs, dks, dtab, None, None, None, None, None, None)
+
+
+LOG2E = 1.4426950408889634
+
+
+def qkv_attention(xn, x_kv, wq, wkv, q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid=None):
+    """q = to_q(xn), k | v = to_kv(x_kv), cosine attention (attention.py:139-178).  Spatial transformer in bf16 (table bias, slab kernels,
+    whole 256-row tiles, inner width 256): one node with the operand layout written by the projection GEMMs (QkvAttn2Fn); anything else:
+    two Linear nodes + cosine_attention.  CTCLIP_ATTN_FUSED_PREP=0 forces the composition."""
+    M, HD = xn.shape[0], H * D
+    table = bias is not None and bias_grid is not None
+    fused = (xn.dtype == torch.bfloat16 and HD == 256 and D == 32 and M % 256 == 0 and (M // 256) >= 160 and xn.shape[1] % 64 == 0
+             and (bias is None or table) and not (bias is None and B().attn_short_supported(xn.dtype, L, D))
+             and B().attn2_supported(xn.dtype, H, L, D, bias_grid if table else None, table)
+             and os.environ.get("CTCLIP_ATTN_FUSED_PREP", "1") != "0")
+    if fused:
+        return QkvAttn2Fn.apply(xn, x_kv, wq, wkv, plain_shadow(wq, xn.dtype), plain_shadow(wkv, xn.dtype), q_scale, k_scale,
+                                bias if table else None, nseq, L, H, D, scale, bias_grid if table else None)
+    return cosine_attention(linear(xn, wq), linear(x_kv, wkv), q_scale, k_scale, bias, nseq, L, H, D, scale, bias_grid)
 
 
 class CosineAttnShortFn(Function):

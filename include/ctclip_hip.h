@@ -140,6 +140,9 @@ int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, void* dU, in
 /* a residual add of the transformer (attention.py:325,331: `x = attn(x) + x`, `x = ff(x) + x`) on a COMPENSATED bf16 residual stream: s = A B^T + residual + comp in f32 (comp = the residue of `residual`), C = bf16(s), E = bf16(s - C) (the rounding residue the next add takes back in): replaces nn.Linear + the torch add, whose bf16 storage rounds the stream at every add.  bf16, M % 256 == 0, N % 128 == 0, K % 64 == 0; CTCLIP_EUNSUPPORTED otherwise. */
 int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int dtype, hipStream_t stream);
 
+/* the q and k|v projections of the spatial attention with the operand layout of the attention kernels written by the GEMM (replaces nn.Linear at attention.py:141-143 + the head split / l2norm / learned scale of :145-154, i.e. nn.Linear + ctclip_attn2_prep): A (M, K) bf16, B (nsec * 256, K) bf16; per 256-column section s (8 heads x 32): inv_s != NULL -> out_s[h][m][d] = bf16(a_m . b_n) / max(|head row|, 1e-12) * scale_s[d] * mult_s, inv_s[m * 8 + h] = the inverse norm; inv_s == NULL -> head-planar copy (v).  CTCLIP_EUNSUPPORTED unless bf16, M % 256 == 0, K % 64 == 0, 1 <= nsec <= 3. */
+int ctclip_gemm_headnorm(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb, void* out0, float* inv0, const float* scale0, float mult0, void* out1, float* inv1, const float* scale1, float mult1, void* out2, float* inv2, const float* scale2, float mult2, int dtype, hipStream_t stream);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

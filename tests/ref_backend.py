@@ -110,6 +110,22 @@ class RefBackend:
         y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C)
         return (y.permute(0, 2, 3, 4, 1) + _f(x)).to(x.dtype).contiguous()
 
+    def gemm_headnorm(self, a, b, sections):
+        M, K = a.shape
+        nsec = len(sections)
+        if a.dtype != torch.bfloat16 or M % 256 or K % 64 or b.shape[0] != nsec * 256:
+            return None
+        y = (_f(a) @ _f(b).t()).to(a.dtype)                       # the bf16-rounded projection (what ctclip_attn2_prep reads)
+        outs = []
+        for i, (sc, mult) in enumerate(sections):
+            t = _f(y[:, i * 256:(i + 1) * 256]).view(M, 8, 32)
+            if sc is None:
+                outs.append((t.permute(1, 0, 2).contiguous().to(a.dtype), None))
+                continue
+            inv = 1.0 / t.norm(dim=-1).clamp_min(1e-12)
+            outs.append(((t * (inv[..., None] * sc * mult)).permute(1, 0, 2).contiguous().to(a.dtype), inv.contiguous()))
+        return outs
+
     def peg_fwd_comp(self, x, w, bias, e_in=None):
         if x.dtype != torch.bfloat16:
             return None

@@ -346,3 +346,34 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_fused_qkv_attention_node_equals_the_composition(ref_backend, monkeypatch):
+    """functional.qkv_attention: the one-node path (projection GEMMs write the attention operands: QkvAttn2Fn) against two Linear nodes +
+    cosine_attention, forward and every gradient, on the checker backend (bf16, 8 heads x 32, table bias on a 16 x 16 grid)."""
+    import torch
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(0)
+    H, D, gh, gw, nseq, dim = 8, 32, 16, 16, 160, 64
+    L, M = gh * gw, 160 * gh * gw
+    bf = torch.bfloat16
+    wq = torch.nn.Parameter(torch.randn(H * D, dim) * dim ** -0.5)
+    wkv = torch.nn.Parameter(torch.randn(2 * H * D, dim) * dim ** -0.5)
+    qs, ks = torch.nn.Parameter(torch.rand(D) + 0.5), torch.nn.Parameter(torch.rand(D) + 0.5)
+    tab = torch.nn.Parameter(torch.randn((2 * gh - 1) * (2 * gw - 1), H) * 0.3)
+    x0, xk0 = torch.randn(M, dim).to(bf), torch.randn(M, dim).to(bf)
+    do = (torch.randn(M, H * D) * 0.1).to(bf)
+
+    def run(fused):
+        monkeypatch.setenv("CTCLIP_ATTN_FUSED_PREP", "1" if fused else "0")
+        Fn.bump_weight_epoch()
+        for p in (wq, wkv, qs, ks, tab):
+            p.grad = None
+        xn, xk = x0.clone().requires_grad_(True), xk0.clone().requires_grad_(True)
+        o = Fn.qkv_attention(xn, xk, wq, wkv, qs, ks, tab, nseq, L, H, D, 8.0, (gh, gw))
+        o.backward(do)
+        return [o.detach().float(), xn.grad.float(), xk.grad.float()] + [p.grad.detach().float().clone() for p in (wq, wkv, qs, ks, tab)]
+
+    a, b = run(True), run(False)
+    for u, v, name in zip(a, b, ("o", "dxn", "dxkv", "dwq", "dwkv", "dq_scale", "dk_scale", "dtab")):
+        torch.testing.assert_close(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max()), msg=lambda m, name=name: f"{name}: {m}")

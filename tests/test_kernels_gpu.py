@@ -1,6 +1,7 @@
 """Per-kernel parity on a real MI355X: every primitive of the HIP backend (C-ABI) against the pure-torch checker on the same
 seeded inputs.  f32 mode is the parity mode (tight tolerances; MFMA f32 is an exact fmaf chain); bf16 is the performance mode
 (tolerances scaled to bf16 rounding of the inputs/outputs)."""
+import numpy as np
 import pytest
 import torch
 
@@ -275,6 +276,39 @@ def test_peg_fwd_comp(hip, ref, shape, with_e):
     assert float((y.float() - s).norm() / s.norm()) > 5e-4                            # ... against the rounded value alone
     y2, r2 = hip.peg_fwd_comp(x, w, b, e_in)
     assert torch.equal(y, y2) and torch.equal(r, r2)
+
+
+# ---------------------------------------------------------------- attention operands from the projection GEMM (gemm_nt epilogue family 4)
+@pytest.mark.parametrize("M,K", [(110592, 512), (40960, 128), (512, 512)])
+def test_gemm_headnorm_equals_gemm_plus_prep(hip, ref, M, K):
+    """ctclip_gemm_headnorm (to_q / to_kv with the attention-operand layout written by the epilogue) against the two launches it replaces,
+    ctclip_gemm + ctclip_attn2_prep: same arithmetic on the bf16-rounded projection -> equal up to one bf16 ulp where the compilers contract
+    the sum of squares differently; v bit for bit.  The last shape cannot fill the chip and is declined."""
+    bf = torch.bfloat16
+    x, xk = rnd(M, K, dtype=bf, seed=1), rnd(M, K, dtype=bf, seed=2)
+    wq, wkv = rnd(256, K, dtype=bf, seed=3, scale=K ** -0.5), rnd(512, K, dtype=bf, seed=4, scale=K ** -0.5)
+    qs, ks = torch.rand(32, device=DEV) + 0.5, torch.rand(32, device=DEV) + 0.5
+    c = float(np.float32(8.0) * np.float32(1.4426950408889634))
+    got_q = hip.gemm_headnorm(x, wq, [(qs, c)])
+    got_kv = hip.gemm_headnorm(xk, wkv, [(ks, 1.0), (None, 1.0)])
+    if M // 256 < 160:
+        assert got_q is None
+        return
+    (qh, qinv), = got_q
+    (kh, kinv), (vh, none) = got_kv
+    assert none is None
+    q, kv = hip.gemm(x, wq), hip.gemm(xk, wkv)
+    qh0, kh0, vh0, qinv0, kinv0 = hip.attn2_prep(q, kv[:, :256], kv[:, 256:], qs, ks, 8.0, 8)
+    assert torch.equal(vh, vh0)
+    for a, b in ((qinv, qinv0), (kinv, kinv0)):
+        close(a, b, rtol=1e-6, atol=0)
+    for a, b in ((qh, qh0), (kh, kh0)):
+        close(a, b, rtol=2 ** -7, atol=1e-6)                                      # one bf16 ulp
+        assert float((a != b).float().mean()) < 1e-3
+    r_q, = ref.gemm_headnorm(x, wq, [(qs, c)])
+    close(qh, r_q[0], rtol=2e-2, atol=2e-2)
+    (qh2, qinv2), = hip.gemm_headnorm(x, wq, [(qs, c)])
+    assert torch.equal(qh, qh2) and torch.equal(qinv, qinv2)
 
 
 # ---------------------------------------------------------------- short-sequence cosine attention (csrc/attn_short.hip)
