@@ -287,9 +287,9 @@ def attention_block_util(args, device, dtype, iters=10):
 
     def block():
         xn, x_kv, xr = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)
-        q = Fn.linear(xn, attn.to_q.weight)
-        kv = Fn.linear(x_kv, attn.to_kv.weight)
-        o = Fn.cosine_attention(q, kv, attn.q_scale, attn.k_scale, tab, nseq, L, attn.heads, attn.dim_head, float(attn.scale), (hw, hw))
+        # (the product's own composition, ctvit.Transformer.forward: the projections write the attention operands from their epilogues)
+        o = Fn.qkv_attention(xn, x_kv, attn.to_q.weight, attn.to_kv.weight, attn.q_scale, attn.k_scale, tab, nseq, L, attn.heads, attn.dim_head,
+                             float(attn.scale), (hw, hw))
         return Fn.linear(o, attn.to_out.weight, residual=xr)
     for _ in range(2):
         block().backward(dy)
