@@ -445,6 +445,31 @@ class HipBackend:
         _lib.check(rc, "ctclip_attn2_bwd")
         return dqh, dkh, dvh, dtab
 
+    def attn2_bwd_tok(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, qinv, kinv, dq, dk, dv, dq_scale, dk_scale, nseq, L,
+                      want_dtab, defer_dtab=False):
+        """Backward of attn2_fwd straight to ROW-MAJOR dq (M, HD), dk / dv (column views of one (M, 2 HD) buffer) with the l2norm backward
+        applied and dq_scale / dk_scale accumulated: the slab key pass writes dk / dv itself (no planar dk^ / dv round trip), the q half goes
+        through the q-only un-prep.  -> (dtab | None, ws | None) -- ws when defer_dtab (attn2_bwd_dbias finishes the table gradient from it) --
+        or None when the slab kernels do not serve the shape (caller: attn2_bwd + attn2_unprep)."""
+        H, M, _ = qh.shape
+        gh, gw = bias_grid if tab is not None else (0, 0)
+        dqh = torch.empty_like(qh)
+        nbytes = self.lib.ctclip_attn2_bwd_tok_workspace(nseq, H, L, gh, gw)
+        dtab = torch.empty_like(tab) if (want_dtab and tab is not None and not defer_dtab) else None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qh.device) if defer_dtab else self.workspace(qh.device, nbytes)
+        rc = self.lib.ctclip_attn2_bwd_tok(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o), _rowmajor(o, "o"),
+                                           _p(dout), _rowmajor(dout, "dout"), _p(lse2), _p(kinv), _p(dqh), _p(dk), _rowmajor(dk, "dk"), _p(dv),
+                                           _rowmajor(dv, "dv"), _p(dk_scale), _p(dtab), nseq, H, L, _p(ws), ws.numel(), _stream())
+        if rc == -2:      # CTCLIP_EUNSUPPORTED
+            return None
+        _lib.check(rc, "ctclip_attn2_bwd_tok")
+        ws2 = self.workspace(qh.device, self.lib.ctclip_attn2_unprep_workspace()) if defer_dtab else None
+        wsu = ws2 if ws2 is not None else self.workspace(qh.device, max(nbytes, self.lib.ctclip_attn2_unprep_workspace()))
+        # (not deferred: the shared per-stream workspace is reused -- stream order makes that safe: the reduce launches of bwd_tok are done)
+        _lib.check(self.lib.ctclip_attn2_unprep_q(_p(dqh), _p(qh), _p(qinv), _p(q_scale), float(scale), _p(dq), _rowmajor(dq, "dq"), _p(dq_scale), M, H,
+                                                  _p(wsu), wsu.numel(), _stream()), "ctclip_attn2_unprep_q")
+        return dtab, (ws if defer_dtab else None)
+
     def attn2_bwd_dbias(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, lse2, nseq, L, ws):
         """The table gradient (ncls, H) from the workspace a deferred attn2_bwd left behind."""
         H = qh.shape[0]

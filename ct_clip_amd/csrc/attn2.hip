@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const bf16_t* __restrict
 // head-planar dq^, dk^, dv + saved q~, k^, inverse norms  ->  row-major dq (M, lddq), dk | dv (M, lddk) through the l2norm backward
 //   u = x inv = x^ / scale_vec ; g = dx^ * scale_vec ; dx = inv (g - u (u . g)) ; dscale[d] = sum dx^ u
 // and per-workgroup partial sums of the two scale gradients (part: [blocks][2][32]; summed by scale_grad_sum_kernel).
+template <bool QONLY>
 __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restrict__ dqh, const bf16_t* __restrict__ dkh, const bf16_t* __restrict__ dvh,
                                                           const bf16_t* __restrict__ qh, const bf16_t* __restrict__ kh, const float* __restrict__ qinv,
                                                           const float* __restrict__ kinv, const float* __restrict__ q_scale, const float* __restrict__ k_scale,
@@ -562,9 +563,17 @@ __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restri
     const int64_t src = ((int64_t)h * M + mm) * D + 8 * j;
     float gq[8], xq[8], gk[8], xk[8];
     load8(dqh + src, gq); load8(qh + src, xq);
-    load8(dkh + src, gk); load8(kh + src, xk);
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(dvh + src);
-    const float iq = qinv[mm * H + h], ik = kinv[mm * H + h];
+    u32x4 vv = u32x4{0u, 0u, 0u, 0u};
+    float ik = 0.f;
+    if (!QONLY) {      // (QONLY: the slab key pass applied the k / v half itself, ctclip_attn2_bwd_tok)
+      load8(dkh + src, gk); load8(kh + src, xk);
+      vv = *reinterpret_cast<const u32x4*>(dvh + src);
+      ik = kinv[mm * H + h];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gk[e] = 0.f; xk[e] = 0.f; }
+    }
+    const float iq = qinv[mm * H + h];
     float dotq = 0.f, dotk = 0.f, uq[8], uk[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -580,8 +589,10 @@ __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) { oq[e] = iq * (gq[e] - uq[e] * dotq); ok8[e] = ik * (gk[e] - uk[e] * dotk); }
       store8(dq + m * lddq + h * D + 8 * j, oq);
-      store8(dk + m * lddk + h * D + 8 * j, ok8);
-      *reinterpret_cast<u32x4*>(dv + m * lddv + h * D + 8 * j) = vv;
+      if (!QONLY) {
+        store8(dk + m * lddk + h * D + 8 * j, ok8);
+        *reinterpret_cast<u32x4*>(dv + m * lddv + h * D + 8 * j) = vv;
+      }
     }
   }
   // deterministic in-block reduction: lanes with equal j (stride 4) by a fixed xor tree, then the four waves in order
@@ -615,6 +626,23 @@ __global__ __launch_bounds__(1024) void scale_grad_sum_kernel(const float* __res
     for (int i = 0; i < 16; ++i) a += red[i][o];
     float* dst = (o >> 5) ? dks : dqs;
     if (dst) dst[o & 31] += a;
+  }
+}
+
+// part[nblk][32] (the slab key pass's per-workgroup k_scale partials) -> dks (+=): 32 interleaved slices of the workgroups summed in parallel,
+// then the slices in a fixed order
+__global__ __launch_bounds__(1024) void kscale_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dks) {
+  __shared__ float red[32][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  float t = 0.f;
+  for (int b = sl; b < nblk; b += 32) t += part[(int64_t)b * 32 + o];
+  red[sl][o] = t;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a += red[i][o];
+    dks[o] += a;
   }
 }
 
@@ -786,6 +814,74 @@ extern "C" int ctclip_attn2_bwd_dbias(const void* qh, const void* kh, const void
 
 extern "C" int64_t ctclip_attn2_unprep_workspace(void) { return (int64_t)UNPREP_BLOCKS * 2 * 32 * 4; }
 
+// ctclip_attn2_bwd with the k / v half of ctclip_attn2_unprep folded into the slab key pass: dqh head-planar (as ctclip_attn2_bwd), but
+// dk (M, lddk) / dv (M, lddv) ROW-MAJOR with the l2norm backward of k applied (kinv = the inverse norms (M, H) of the forward) and dk_scale (32)
+// ACCUMULATED; dtab as in ctclip_attn2_bwd (NULL: ctclip_attn2_bwd_dbias later, same workspace).  Follow with ctclip_attn2_unprep_q for dq.
+// Saves the planar dk^ / dv round trip (283 MB per layer at CT-CLIP's spatial shape).  CTCLIP_EUNSUPPORTED when the slab kernels do not serve
+// the shape (then: ctclip_attn2_bwd + ctclip_attn2_unprep).  workspace >= ctclip_attn2_bwd_tok_workspace(...).
+extern "C" int64_t ctclip_attn2_bwd_tok_workspace(int nseq, int H, int L, int bias_gh, int bias_gw) {
+  return ctclip_attn2_bwd_workspace(nseq, H, L, bias_gh, bias_gw) + a256(1024 * 32 * 4);
+}
+extern "C" int ctclip_attn2_bwd_tok(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale,
+                                    const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2,
+                                    const float* kinv, void* dqh, void* dk, int64_t lddk, void* dv, int64_t lddv, float* dk_scale, float* dtab,
+                                    int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (!qh || !kh || !vh || !o || !dout || !lse2 || !kinv || !dqh || !dk || !dv || !dk_scale || !q_scale || !k_scale || ldo % 8 || lddo % 8 || lddk % 8 ||
+      lddv % 8) { ctclip_set_error("attn2_bwd_tok: bad args"); return CTCLIP_EBADARG; }
+  if (!shape_ok(H, L, bias_gh, bias_gw, tab)) return CTCLIP_EUNSUPPORTED;
+  if (dtab && !tab) { ctclip_set_error("attn2_bwd_tok: dtab without a table"); return CTCLIP_EBADARG; }
+  if (!workspace || workspace_bytes < ctclip_attn2_bwd_tok_workspace(nseq, H, L, tab ? bias_gh : 0, bias_gw)) { ctclip_set_error("attn2_bwd_tok: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int64_t M = (int64_t)nseq * L;
+  Params p{};
+  p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
+  p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = M; p.c = scale * LOG2E;
+  p.o = (const bf16_t*)o; p.ldo = ldo; p.dout = (const bf16_t*)dout; p.lddo = lddo; p.lse2 = const_cast<float*>(lse2);
+  char* w = (char*)workspace;
+  p.dop = (bf16_t*)w; w += a256(H * M * D * 2);
+  p.deltap = (float*)w; w += a256(H * M * 4);
+  p.dqh = (bf16_t*)dqh;
+  p.dk_tok = (bf16_t*)dk; p.dv_tok = (bf16_t*)dv; p.ldk_tok = lddk; p.ldv_tok = lddv; p.kinv = kinv;
+  p.kpart = (float*)((char*)workspace + ctclip_attn2_bwd_workspace(nseq, H, L, tab ? bias_gh : 0, bias_gw));
+  int rc = attn2_slab_bwd_dq(p, stream);
+  if (rc == 1) return CTCLIP_EUNSUPPORTED;       // (nothing launched: make_geo declined the shape)
+  if (rc) return rc;
+  int nwg = 0;
+  rc = attn2_slab_bwd_dkv(p, stream, &nwg);
+  if (rc == 1) { ctclip_set_error("attn2_bwd_tok: the key pass declined a shape the query pass served"); return CTCLIP_EBADARG; }
+  if (rc) return rc;
+  hipLaunchKernelGGL(kscale_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)p.kpart, nwg, dk_scale);
+  rc = ctclip_check_launch("attn2_kscale_sum");
+  if (rc || !dtab) return rc;
+  p.nsplit = dbias_splits(nseq, H, L);
+  p.dbias_part = (float*)w; w += a256((int64_t)p.nsplit * H * L * L * 4);
+  float* bins = (float*)w;
+  const int nkb = L / 32;
+  rc = attn2_slab_bwd_dbias(p, stream);
+  if (rc == 1) {
+    hipLaunchKernelGGL(attn2_bwd_dbias_kernel, dim3((unsigned)(((nkb + 1) / 2) * ((nkb + 3) / 4)), H, p.nsplit), dim3(512), 0, stream, p);
+    rc = ctclip_check_launch("attn2_bwd_dbias");
+  }
+  if (rc) return rc;
+  return ctclip_dbias_fold(p.dbias_part, p.nsplit, bins, dtab, H, bias_gh, bias_gw, stream);
+}
+
+// The q half of ctclip_attn2_unprep (after ctclip_attn2_bwd_tok): head-planar dq^ -> row-major dq (M, lddq) through the l2norm backward;
+// dq_scale (32) ACCUMULATED.  workspace >= ctclip_attn2_unprep_workspace().
+extern "C" int ctclip_attn2_unprep_q(const void* dqh, const void* qh, const float* qinv, const float* q_scale, float scale, void* dq, int64_t lddq,
+                                     float* dq_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (!dqh || !qh || !qinv || !q_scale || !dq || !dq_scale || lddq % 8) { ctclip_set_error("attn2_unprep_q: bad args"); return CTCLIP_EBADARG; }
+  if (!workspace || workspace_bytes < ctclip_attn2_unprep_workspace()) { ctclip_set_error("attn2_unprep_q: workspace too small"); return CTCLIP_EWORKSPACE; }
+  int64_t nb = cdiv(M, 64) * H;
+  if (nb > UNPREP_BLOCKS) nb = UNPREP_BLOCKS;
+  hipLaunchKernelGGL(attn_unprep_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dqh, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     (const bf16_t*)qh, (const bf16_t*)nullptr, qinv, (const float*)nullptr, q_scale, q_scale, scale * LOG2E, (bf16_t*)dq, (bf16_t*)nullptr,
+                     (bf16_t*)nullptr, lddq, (int64_t)0, (int64_t)0, (float*)workspace, M, H);
+  int rc = ctclip_check_launch("attn2_unprep_q");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scale_grad_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, (int)nb, dq_scale, (float*)nullptr);
+  return ctclip_check_launch("attn2_scale_grad");
+}
+
 // l2norm backward (attention.py:152-154) + layout: head-planar dq^, dk^, dv -> row-major dq (M, lddq), dk (M, lddk), dv (M, lddv);
 // dq_scale, dk_scale (32) ACCUMULATED (either may be null).
 extern "C" int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv,
@@ -796,7 +892,7 @@ extern "C" int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void*
   if (!workspace || workspace_bytes < ctclip_attn2_unprep_workspace()) { ctclip_set_error("attn2_unprep: workspace too small"); return CTCLIP_EWORKSPACE; }
   int64_t nb = cdiv(M, 64) * H;
   if (nb > UNPREP_BLOCKS) nb = UNPREP_BLOCKS;
-  hipLaunchKernelGGL(attn_unprep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dqh, (const bf16_t*)dkh, (const bf16_t*)dvh,
+  hipLaunchKernelGGL(attn_unprep_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dqh, (const bf16_t*)dkh, (const bf16_t*)dvh,
                      (const bf16_t*)qh, (const bf16_t*)kh, qinv, kinv, q_scale, k_scale, scale * LOG2E, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq,
                      lddk, lddv, (float*)workspace, M, H);
   int rc = ctclip_check_launch("attn2_unprep");

@@ -21,6 +21,10 @@ struct Params {
   float* deltap;                           // [H][M]: delta' = w delta
   bf16_t *dqh, *dkh, *dvh;                 // head-planar gradients
   float* dbias_part; int nsplit;           // dBias slabs [nsplit][H][L][L]
+  // fused k / v un-prep of the slab key pass (ctclip_attn2_bwd_tok): when dk_tok is set, the pass applies the l2norm backward of k itself and
+  // writes ROW-MAJOR dk (M, ldk_tok) / dv (M, ldv_tok) instead of the head-planar dkh / dvh; kinv = the inverse norms (M, H) of the forward,
+  // kpart = per-workgroup partial sums [gridDim][32] of the k_scale gradient (summed in workgroup order by the host's reduce launch)
+  bf16_t* dk_tok; bf16_t* dv_tok; int64_t ldk_tok, ldv_tok; const float* kinv; float* kpart;
 };
 }  // namespace ctclip_attn2
 
@@ -207,5 +211,5 @@ __device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70
 // launchers of the slab-resident kernels (attn2_slab.hip); each returns 1 when the shape is not eligible, else a C-ABI status
 int attn2_slab_fwd(const ctclip_attn2::Params& p, hipStream_t stream);
 int attn2_slab_bwd_dq(const ctclip_attn2::Params& p, hipStream_t stream);
-int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream);
+int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream, int* nwg_out = nullptr);
 int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream);

@@ -442,9 +442,12 @@ __global__ __launch_bounds__(NTH) void dq_slab_kernel(Params p, Geo g, int items
 
 // ================================================================================================================== dK, dV pass
 // slabs: Q~ and dO' (head-planar, written by the dQ pass); -delta' of the item's queries in LDS.  lane = key.
-template <bool SAFE, bool TAB>
+// TOK: the un-prep of k / v folded into the epilogue (Params::dk_tok): row-major dk = l2norm backward of dk^ (ctclip_attn2_unprep's arithmetic on
+// the bf16-rounded dk^), row-major dv, and the lane's share of the k_scale gradient accumulated in ksacc over the whole kernel.
+template <bool SAFE, bool TAB, bool TOK>
 __device__ __forceinline__ void dkv_block(const Params& p, const SRel& rel, const Geo& g, const char* qslab, const char* doslab, const float* ndelta,
-                                          const float* lse_it, Copier& cp, bool do_copy, const Item& it, int jb, int lane, const Frag& kf, const Frag& vf) {
+                                          const float* lse_it, Copier& cp, bool do_copy, const Item& it, int jb, int lane, const Frag& kf, const Frag& vf,
+                                          float (&ksacc)[16]) {
   const int L = p.L, nqb = L / 32;
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const TrOff tr = tr_offsets(lane);
@@ -489,7 +492,40 @@ __device__ __forceinline__ void dkv_block(const Params& p, const SRel& rel, cons
     dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
     if (do_copy) cp.step(t, nqb);
   }
-  {                                   // dk^ = scale * dS^T q^ = ln 2 * dS^T q~
+  if (TOK) {                          // un-prep in place: u = k^ / k_scale, g = dk^ k_scale, dk = kinv (g - u (u . g)); dscale += dk^ u
+    const int64_t tok = (int64_t)it.seq * L + kj;
+    const float ik = p.kinv[tok * p.H + it.h];
+    float kx[16], dk[16];
+    unpack8(__builtin_bit_cast(u32x4, kf.v[0]), kx); unpack8(__builtin_bit_cast(u32x4, kf.v[1]), kx + 8);
+    float part[2] = {0.f, 0.f};
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = 8 * gq + e;
+        const float ks = p.k_scale[16 * gq + 8 * half + e];
+        const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+        const float gk0 = bf2f(f2bf(dkacc[i] * LN2));            // the bf16 value the planar path stores and the un-prep kernel reads
+        const float uk = kx[i] * rk;
+        ksacc[i] += gk0 * uk;
+        const float gk = gk0 * ks;
+        part[gq] += uk * gk;
+        kx[i] = uk; dk[i] = gk;
+      }
+    // (u . g) over the 32 head dims = the four 8-dim chunks in the un-prep kernel's order: (c0 + c1) + (c2 + c3); this lane holds chunks
+    // half and 2 + half, its partner (lane ^ 32) the other two
+    const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+    bf16_t* dK = p.dk_tok + tok * p.ldk_tok + it.h * D;
+    bf16_t* dV = p.dv_tok + tok * p.ldv_tok + it.h * D;
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      float a8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a8[e] = ik * (dk[8 * gq + e] - kx[8 * gq + e] * dot); b8[e] = dvacc[8 * gq + e]; }
+      store8(dK + 16 * gq + 8 * half, a8);
+      store8(dV + 16 * gq + 8 * half, b8);
+    }
+  } else {                            // dk^ = scale * dS^T q^ = ln 2 * dS^T q~
     const int64_t slab = slab_off(p, it);
     bf16_t* dK = p.dkh + slab + (int64_t)kj * D;
     bf16_t* dV = p.dvh + slab + (int64_t)kj * D;
@@ -504,7 +540,7 @@ __device__ __forceinline__ void dkv_block(const Params& p, const SRel& rel, cons
   }
 }
 
-template <bool TAB>
+template <bool TAB, bool TOK = false>
 __global__ __launch_bounds__(NTH) void dkv_slab_kernel(Params p, Geo g, int items_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   SRel& rel = *reinterpret_cast<SRel*>(dyn);
@@ -519,6 +555,9 @@ __global__ __launch_bounds__(NTH) void dkv_slab_kernel(Params p, Geo g, int item
   copy_now(reinterpret_cast<const char*>(p.qh + slab_off(p, it)), reinterpret_cast<const char*>(p.dop + slab_off(p, it)), slabs, sb, L);
   for (int i = threadIdx.x; i < L; i += NTH) stats[i] = -p.deltap[(int64_t)it.h * p.M + (int64_t)it.seq * L + i];
   const int mine = wave < nqb ? (nqb - wave + SW - 1) / SW : 0;
+  float ksacc[16];     // TOK: this lane's share of the k_scale gradient (its 16 head dims), over every key row it visits
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ksacc[i] = 0.f;
   auto load_kv = [&](Frag& k, Frag& v, const Item& item, int jb) {
     const int64_t so = slab_off(p, item) + (int64_t)(jb * 32 + c) * D;
     k = global_row(p.kh + so, half); v = global_row(p.vh + so, half);
@@ -552,12 +591,33 @@ __global__ __launch_bounds__(NTH) void dkv_slab_kernel(Params p, Geo g, int item
       if (k + 1 < mine) load_kv(kn, vn, it, jb + SW);
       else if (more) load_kv(kn, vn, nx, wave);
       const bool cpy = k == 0;
-      if (rel.safe) dkv_block<true, TAB>(p, rel, g, cur, cur + sb, ndelta, lse_it, cp, cpy, it, jb, lane, kf, vf);
-      else dkv_block<false, TAB>(p, rel, g, cur, cur + sb, ndelta, lse_it, cp, cpy, it, jb, lane, kf, vf);
+      if (rel.safe) dkv_block<true, TAB, TOK>(p, rel, g, cur, cur + sb, ndelta, lse_it, cp, cpy, it, jb, lane, kf, vf, ksacc);
+      else dkv_block<false, TAB, TOK>(p, rel, g, cur, cur + sb, ndelta, lse_it, cp, cpy, it, jb, lane, kf, vf, ksacc);
     }
     if (more) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) { const int q = k * NTH + (int)threadIdx.x; if (q < L) stats[(buf ^ 1) * SL_MAX + q] = sv[k]; }
+    }
+  }
+  if (TOK) {           // k_scale gradient of this workgroup, in a fixed order: the 32 key lanes of a half by an xor tree, then the eight waves
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) ksacc[i] += __shfl_xor(ksacc[i], o, 64);
+    __syncthreads();                                           // the slabs are free now
+    float* red = reinterpret_cast<float*>(slabs);              // [SW][32]
+    if (c == 0) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 32 + 16 * gq + 8 * half + e] = ksacc[8 * gq + e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < SW; ++w) t += red[w * 32 + threadIdx.x];
+      p.kpart[(int64_t)blockIdx.x * 32 + threadIdx.x] = t;
     }
   }
 }
@@ -732,7 +792,25 @@ bool raise_lds(K kern) { return hipFuncSetAttribute((const void*)kern, hipFuncAt
 
 int attn2_slab_fwd(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(fwd_slab_kernel, 0, "attn2_fwd (slab)") }
 int attn2_slab_bwd_dq(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(dq_slab_kernel, 0, "attn2_bwd_dq (slab)") }
-int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream) { SLAB_LAUNCH(dkv_slab_kernel, 2 * SL_MAX * 4, "attn2_bwd_dkv (slab)") }
+int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream, int* nwg_out) {
+  Geo g; size_t shm;
+  if (!make_geo(p, g, 2 * SL_MAX * 4, shm)) return 1;
+  static bool raised = false;
+  if (!raised) {
+    if (!raise_lds(dkv_slab_kernel<true, false>) || !raise_lds(dkv_slab_kernel<false, false>) || !raise_lds(dkv_slab_kernel<true, true>) ||
+        !raise_lds(dkv_slab_kernel<false, true>)) { ctclip_set_error("attn2_bwd_dkv (slab): cannot raise the LDS limit"); return CTCLIP_EBADARG; }
+    raised = true;
+  }
+  const int ncu = num_cus(), total = p.nseq * p.H;
+  const int ipw = (total + ncu - 1) / ncu, nwg = (total + ipw - 1) / ipw;
+  if (nwg_out) *nwg_out = nwg;
+  const bool tok = p.dk_tok != nullptr;
+  if (p.tab) { if (tok) hipLaunchKernelGGL((dkv_slab_kernel<true, true>), dim3((unsigned)nwg), dim3(NTH), shm, stream, p, g, ipw);
+               else hipLaunchKernelGGL((dkv_slab_kernel<true, false>), dim3((unsigned)nwg), dim3(NTH), shm, stream, p, g, ipw); }
+  else { if (tok) hipLaunchKernelGGL((dkv_slab_kernel<false, true>), dim3((unsigned)nwg), dim3(NTH), shm, stream, p, g, ipw);
+         else hipLaunchKernelGGL((dkv_slab_kernel<false, false>), dim3((unsigned)nwg), dim3(NTH), shm, stream, p, g, ipw); }
+  return ctclip_check_launch("attn2_bwd_dkv (slab)");
+}
 
 // dBias slabs (p.dbias_part, p.nsplit must be set): returns 1 when the shape is not eligible
 int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream) {

@@ -838,20 +838,37 @@ def _attn2_register_table(ctx, tab):
 
 def _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, need_dtab):
     """Backward of the slab attention on prepared operands + the l2norm / scale backward (un-prep): -> token-major dq (M, HD), dkv (M, 2 HD),
-    the scale gradients (None when they went to the flat gradient buffer) and the table gradient.  ctx carries dims / scales / tab_users."""
+    the scale gradients (None when they went to the flat gradient buffer) and the table gradient.  ctx carries dims / scales / tab_users.
+    Fast path (ctclip_attn2_bwd_tok): the slab key pass writes row-major dk / dv itself, only dq^ takes the planar round trip."""
     be = B()
     nseq, L, H, D, scale, has_tab, bias_grid, dtype = ctx.dims
     q_scale, k_scale = ctx.scales
     qs, ks = q_scale.detach(), k_scale.detach()
     HD = H * D
     do = do.contiguous()
+    M = o.shape[0]
+    dq = torch.empty((M, HD), dtype=dtype, device=o.device)
+    dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)
+    qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
+    dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
+    dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
     want_dtab = has_tab and need_dtab
     side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
+    tabk = tab if has_tab else None
+    fused = None
+    if os.environ.get("CTCLIP_ATTN_FUSED_UNPREP", "1") != "0":
+        fused = be.attn2_bwd_tok(qh, kh, vh, tabk, bias_grid, qs, ks, scale, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L,
+                                 want_dtab, defer_dtab=side is not None)
+    if fused is not None:
+        dtab, ws = fused
+    elif side is not None:
+        dqh, dkh, dvh, ws = be.attn2_bwd(qh, kh, vh, tab, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, True, defer_dtab=True)
+    else:
+        dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tabk, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, want_dtab)
     if side is not None:
         # The table gradient is a leaf until the position-bias MLP's backward, which runs after the FIRST layer's attention backward.
         # Its pass (a third recomputation of S and dP) goes to the weight-gradient stream, under the rest of this layer's backward;
         # the layers' tables are summed there, in backward order, and the first layer joins the stream and returns the sum.
-        dqh, dkh, dvh, ws = be.attn2_bwd(qh, kh, vh, tab, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, True, defer_dtab=True)
         st = ctx.tab_users
         side.wait_stream(torch.cuda.current_stream(do.device))
         for t in (qh, kh, vh, lse2, tab, ws):
@@ -868,17 +885,10 @@ def _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, need_dtab):
             torch.cuda.current_stream(do.device).wait_stream(side)
             dtab, st["acc"], st["n"] = st["acc"], None, 0
             dtab.record_stream(torch.cuda.current_stream(do.device))
-    else:
-        dqh, dkh, dvh, dtab = be.attn2_bwd(qh, kh, vh, tab if has_tab else None, bias_grid, qs, ks, scale, o, do, lse2, nseq, L, want_dtab)
-        if ctx.tab_users is not None and ctx.tab_index == 0:
-            ctx.tab_users["n"], ctx.tab_users["acc"] = 0, None
-    M = o.shape[0]
-    dq = torch.empty((M, HD), dtype=dtype, device=o.device)
-    dkv = torch.empty((M, 2 * HD), dtype=dtype, device=o.device)
-    qs_sink, ks_sink = sink_of(q_scale), sink_of(k_scale)
-    dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
-    dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
-    be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, scale, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
+    elif ctx.tab_users is not None and ctx.tab_index == 0:
+        ctx.tab_users["n"], ctx.tab_users["acc"] = 0, None
+    if fused is None:
+        be.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, scale, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks)
     return dq, dkv, (None if qs_sink is not None else dqs), (None if ks_sink is not None else dks), dtab
 
 

@@ -65,6 +65,15 @@ int ctclip_attn2_bwd_dbias(const void* qh, const void* kh, const void* vh, const
 /* bytes of workspace ctclip_attn2_unprep needs for the partial sums of the q_scale / k_scale gradients. */
 int64_t ctclip_attn2_unprep_workspace(void);
 
+/* bytes of workspace ctclip_attn2_bwd_tok needs (ctclip_attn2_bwd's regions + the per-workgroup k_scale partials). */
+int64_t ctclip_attn2_bwd_tok_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
+
+/* ctclip_attn2_bwd (backward of the cosine attention, attention.py:145-178) with the k / v half of ctclip_attn2_unprep folded into the slab key pass: dqh head-planar as before, dk (M, lddk) / dv (M, lddv) ROW-MAJOR with the l2norm backward of k applied (kinv = the forward's inverse norms (M, H)), dk_scale (32) ACCUMULATED, dtab as in ctclip_attn2_bwd (NULL: ctclip_attn2_bwd_dbias later from the same workspace).  Follow with ctclip_attn2_unprep_q.  CTCLIP_EUNSUPPORTED when the slab kernels do not serve the shape. */
+int ctclip_attn2_bwd_tok(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, const float* kinv, void* dqh, void* dk, int64_t lddk, void* dv, int64_t lddv, float* dk_scale, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* the q half of ctclip_attn2_unprep: head-planar dq^ -> row-major dq (M, lddq) through the l2norm backward of q (attention.py:152); dq_scale (32) ACCUMULATED; workspace >= ctclip_attn2_unprep_workspace(). */
+int ctclip_attn2_unprep_q(const void* dqh, const void* qh, const float* qinv, const float* q_scale, float scale, void* dq, int64_t lddq, float* dq_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* backward of ctclip_attn2_prep: head-planar dq~, dk^, dv -> row-major dq (M, lddq), dk, dv bf16 through the l2norm backward; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=), summed in a fixed order. */
 int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 

@@ -110,6 +110,14 @@ class RefBackend:
         y = F.conv3d(F.pad(xc, (1, 1, 1, 1, 2, 0)), w.view(C, 1, 3, 3, 3), bias, groups=C)
         return (y.permute(0, 2, 3, 4, 1) + _f(x)).to(x.dtype).contiguous()
 
+    def attn2_bwd_tok(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, qinv, kinv, dq, dk, dv, dq_scale, dk_scale, nseq, L,
+                      want_dtab, defer_dtab=False):
+        assert not defer_dtab, "the checker has no streams: the table gradient is never deferred on the CPU"
+        dqh, dkh, dvh, dtab = self.attn2_bwd(qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab)
+        ws = None
+        self.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale)
+        return dtab, ws
+
     def gemm_headnorm(self, a, b, sections):
         M, K = a.shape
         nsec = len(sections)

@@ -633,6 +633,43 @@ def test_attn2_fwd_bwd(hip, ref, nseq, H, gh, gw, gain, with_tab):
     assert torch.equal(dqs, dqs2) and torch.equal(dks, dks2)
 
 
+@pytest.mark.parametrize("nseq,H,gh,gw,gain,with_tab", [(70, 8, 24, 24, 1.0, True), (9, 8, 24, 24, 4.0, True), (33, 8, 16, 16, 1.0, False), (5, 4, 8, 8, 1.0, True)])
+def test_attn2_bwd_tok_equals_bwd_plus_unprep(hip, ref, nseq, H, gh, gw, gain, with_tab):
+    """ctclip_attn2_bwd_tok + ctclip_attn2_unprep_q (the slab key pass writes row-major dk / dv and the k_scale partials itself) against the
+    pair it replaces, ctclip_attn2_bwd + ctclip_attn2_unprep: dq and dv bit for bit (same accumulators, same rounding), dk to one bf16 ulp, the scale gradients to f32
+    summation order, the table gradient bit for bit; persistent runs across items and heads (70 x 8 items on 256 CUs), the unbounded-logit
+    path (gain 4) and a grid the slab kernels serve without a table."""
+    L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, gain, with_tab, seed=50)
+    HD, bf = H * D, torch.bfloat16
+    grid = (gh, gw) if with_tab else None
+    qh, kh, vh, qinv, kinv = hip.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    o, lse2 = hip.attn2_fwd(qh, kh, vh, tab, grid, qs, ks, 8.0, nseq, L)
+    do = rnd(M, HD, dtype=bf, seed=9)
+    dqh, dkh, dvh, dtab0 = hip.attn2_bwd(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, nseq, L, with_tab)
+    dq0, dkv0 = torch.empty(M, HD, dtype=bf, device=DEV), torch.empty(M, 2 * HD, dtype=bf, device=DEV)
+    dqs0, dks0 = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    hip.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, 8.0, dq0, dkv0[:, :HD], dkv0[:, HD:], dqs0, dks0)
+    dq, dkv = torch.full_like(dq0, float("nan")), torch.full_like(dkv0, float("nan"))
+    dqs, dks = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    res = hip.attn2_bwd_tok(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, with_tab)
+    if L > 576:
+        assert res is None
+        return
+    dtab, ws = res
+    assert ws is None
+    assert torch.equal(dq, dq0)
+    close(dqs, dqs0, rtol=1e-5, atol=1e-5 * float(dqs0.abs().max()))                  # the q-only un-prep sums its partials in another order
+    assert torch.equal(dkv[:, HD:], dkv0[:, HD:])                                     # dv: the same bf16 rounding of the same accumulators
+    close(dkv[:, :HD], dkv0[:, :HD], rtol=2 ** -7, atol=1e-6 * float(dkv0.float().abs().max()) + 1e-30)
+    assert float((dkv[:, :HD] != dkv0[:, :HD]).float().mean()) < 5e-3
+    close(dks, dks0, rtol=1e-4, atol=1e-4 * float(dks0.abs().max()))
+    if with_tab:
+        assert torch.equal(dtab, dtab0)
+    dq2, dkv2, dqs2, dks2 = torch.empty_like(dq), torch.empty_like(dkv), torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    hip.attn2_bwd_tok(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, qinv, kinv, dq2, dkv2[:, :HD], dkv2[:, HD:], dqs2, dks2, nseq, L, with_tab)
+    assert torch.equal(dkv, dkv2) and torch.equal(dks, dks2) and torch.equal(dqs, dqs2)      # no atomics: bit-reproducible
+
+
 def test_attn2_fwd_persistent_runs_across_items_and_heads(hip, ref):
     """The slab-resident forward keeps one workgroup per CU on a run of (head, sequence) items: more items than CUs, and a run
     that crosses a head boundary (the bias table is re-staged)."""
