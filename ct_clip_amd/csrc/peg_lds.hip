@@ -4,20 +4,21 @@
 // The first-generation kernels (conv.hip) let every thread fetch its nine neighbour rows from L1/L2: nine 8-byte loads per step,
 // one memory round trip per step at two waves per SIMD -- latency-bound at 1.9 TB/s (118 us for 113 MB in + 113 MB out).
 // Here a workgroup owns (batch, TB rows of D2, 32 channels) and walks a = 0 .. D1-1:
-//   * a ring of four LDS slots holds the planes a-2, a-1, a (with one halo row either side of the tile and one zero column either
-//     side of D3) while plane a+1 streams in by LDS-DMA (global_load_lds, 16 B per lane): every input byte crosses HBM once, no
-//     VGPR staging.  (Deeper rings are built in -- DEPTH / WDEPTH -- but two planes in flight measured 8 % slower: the march is bound
-//     by vector-instruction issue, 330 VALU + 72 LDS instructions per thread and plane, not by the fetch; see profiles/r02_peg.md);
+//   * ONE input plane is live in LDS at a time (one halo row either side of the tile, one zero column either side of D3) while the next
+//     PEG_DEPTH planes stream in by LDS-DMA (global_load_lds, 16 B per lane): every input byte crosses HBM once, no VGPR staging;
 //   * a dedicated loader wave issues the DMA and is the only wave that waits on vmcnt (counted: vmcnt retires in issue order), so
 //     the compute waves never wait for the acknowledgement of their output stores; one barrier per plane;
-//   * a compute thread owns (row, channel pair, a quarter of D3) and scatters each input column into three rotating output
-//     accumulators (9 ds_read_b32 + 18 unpacks + 54 FMAs per column), the 27 x 2 weights in registers, the residual folded into
-//     the centre tap; rows of a wave are an odd number of 64-byte positions apart -> the two 32-lane halves of a ds_read_b32 hit
-//     disjoint banks;
+//   * a compute thread owns (row, channel pair, a quarter of D3) and SCATTERS: input plane a is tap d1 = 2 of output plane a, d1 = 1 of
+//     a + 1 and d1 = 0 of a + 2, so the thread keeps three sets of L = D3 / 4 output accumulators (rotating by name: the march is unrolled
+//     three times) and reads + unpacks each of its 3 rows x (L + 2) input columns ONCE -- 24 ds_read_b32 + 48 unpacks + 162 packed FMAs per
+//     thread and plane at D3 = 24.  (Round 2 gathered from three live planes: 72 reads + 144 unpacks for the same 162 FMAs, and was bound by
+//     vector-instruction issue at 3.2 TB/s: profiles/r02_peg.md.)  The 27 x 2 weights stay in registers, the residual is folded into the
+//     centre tap; rows of a wave are an odd number of 64-byte positions apart -> the two 32-lane halves of a ds_read_b32 hit disjoint banks;
 //   * grad-in (DIR = -1) is the same march from a = D1-1 downwards with the D2 / D3 taps mirrored;
-//   * the weight gradient keeps the 27 x 2 tap sums of a thread in registers over the whole march (dy planes double-buffered in LDS
-//     next to the x ring), then folds rows -> waves -> workgroup in a fixed order and writes per-workgroup partials that
-//     conv.hip's second stage sums in order: no atomics.
+//   * the weight gradient keeps the 27 x 2 tap sums of a thread in registers over the whole march and the same economy: dy plane s is
+//     unpacked into registers once and kept for three steps, x plane s - 2 is paired with dy planes s - 2, s - 1, s (30 reads + 60 unpacks
+//     per step instead of 78 + 156); then rows -> waves -> workgroup are folded in a fixed order into per-workgroup partials that conv.hip's
+//     second stage sums in order: no atomics.
 // Bytes per launch: forward / grad-in read x (or dy) once and write y once (2 x B*D1*D2*D3*C*2 B; + 2/TB halo rows from L2);
 // the weight gradient reads x and dy once.
 #include "common.h"
@@ -25,6 +26,12 @@
 
 #include <cstdlib>
 
+#ifndef PEG_DEPTH
+#define PEG_DEPTH 2    // input planes in flight ahead of the march (forward / grad-in)
+#endif
+#ifndef PEG_WDEPTH
+#define PEG_WDEPTH 2   // x planes in flight ahead of the weight-gradient march (1 or 2)
+#endif
 #ifndef PEG_ABL
 #define PEG_ABL 0      // ablations (tools/build_ablation.py peg_lds.hip:PEG_ABL ...): 1 deeper prefetch, 2 drain every DMA at each step,
                        // 4 no bf16 unpack instructions (timing only)
@@ -49,16 +56,16 @@ struct Geo {
   static constexpr int NPX = (TB + 2) * PIECES;   // DMA pieces per x plane (halo rows included), per dy plane
   static constexpr int NPD = TB * PIECES;
   static constexpr int LDS_MAX = 160 * 1024;
-  // forward / grad-in: three live planes + as many planes in flight as fit (at most three), + one dump row
-  // (vmcnt is a 6-bit counter: the loader wave never has more than 63 pieces outstanding)
-  static constexpr int DEPTH_LDS = (LDS_MAX - ROWB) / SLOT - 3;
+  // forward / grad-in: ONE live plane (the march scatters each input plane into the three outputs it belongs to) + PEG_DEPTH planes in
+  // flight, + one dump row (vmcnt is a 6-bit counter: the loader wave never has more than 63 pieces outstanding)
+  static constexpr int DEPTH_LDS = (LDS_MAX - ROWB) / SLOT - 1;
   static constexpr int DEPTH_VM = 63 / NPX;
-  static constexpr int DEPTH_CAP = (PEG_ABL & 1) ? 3 : 1;    // measured: 69.8 us with one plane in flight, 76.2 us with two
+  static constexpr int DEPTH_CAP = D3 == 8 ? 1 : PEG_DEPTH;    // (D3 = 8: two unrolled planes of 14 single-piece rows spill in the loader wave)
   static constexpr int DEPTH = DEPTH_LDS < DEPTH_VM ? (DEPTH_LDS < DEPTH_CAP ? DEPTH_LDS : DEPTH_CAP) : (DEPTH_VM < DEPTH_CAP ? DEPTH_VM : DEPTH_CAP);
-  static constexpr int NSLOT = DEPTH + 3;
-  // weight gradient: x planes WDEPTH ahead, the dy planes one ahead (measured: 92 us with one, 104 us with two)
-  static constexpr int WDEPTH = (PEG_ABL & 1) ? 2 : 1;
-  static constexpr int WSLOT = 3 + WDEPTH;
+  static constexpr int NSLOT = DEPTH + 1;
+  // weight gradient: one live x plane + WDEPTH in flight, the dy planes one ahead
+  static constexpr int WDEPTH = PEG_WDEPTH;
+  static constexpr int WSLOT = 1 + WDEPTH;
 };
 
 // s_waitcnt vmcnt(N) only (lgkmcnt / expcnt untouched); vmcnt retires in issue order
@@ -166,7 +173,7 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
   using G = Geo<TB, D3>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NT = (G::NCW + 1) * 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // (wave: uniform -> scalar registers)
   const Tile t = tile_of(C / PCC, ntile, TB);
   for (int i = threadIdx.x; i < G::NSLOT * G::SLOT / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
@@ -226,48 +233,65 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW + 1) * 64) void peg_march_kernel(
                                                                          (COMP && ein) ? (int)(D1 * plane_elems * 2) : 0, 0x00020000);
   const uint32_t lane_off = t.beta0 + r < D2 ? (uint32_t)((((t.beta0 + r) * D3 + g0) * C + ch) * 2) : 0x80000000u;
 
-  for (int m = 0; m < D1; ++m) {
+  // One march step = one INPUT plane: plane m (march order) feeds the outputs m (tap d1 = 2: complete after this step -> stored), m + 1
+  // (d1 = 1) and m + 2 (d1 = 0: started here), so every input value is read from LDS and unpacked ONCE per thread -- 3 rows x (L + 2)
+  // columns per step instead of the 3 planes x 3 rows x (L + 2) of a gather over the three live planes (72 -> 24 ds_read_b32, 144 -> 48
+  // unpacks per thread and plane; the 162 packed FMAs are the arithmetic itself).  The three accumulator sets rotate by NAME: the march
+  // loop is unrolled three times.
+  auto step = [&](int m, float (&P0)[G::L][2], float (&P1)[G::L][2], float (&P2)[G::L][2]) {
     wg_barrier();
-    const char* pl[3];
-#pragma unroll
-    for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 - 2 + G::NSLOT) % G::NSLOT) * G::SLOT + tb;
+    const char* pl = lds + (m % G::NSLOT) * G::SLOT + tb;
     const uint32_t plane_off = (uint32_t)(plane_of(m) * plane_elems * 2);
-    float accm[2] = {0.f, 0.f}, acc0[2] = {bv[0], bv[1]}, accp[2] = {bv[0], bv[1]};
     uint32_t ev[G::L];      // COMP: the compensation terms of this plane's outputs, requested a whole plane body ahead of their use
     if (COMP) {
 #pragma unroll
       for (int j = 0; j < G::L; ++j) ev[j] = __builtin_amdgcn_raw_buffer_load_b32(ein_d, lane_off, plane_off + (uint32_t)(j * C * 2), 0);
     }
-    uint32_t raw[2][9];
-    auto fetch = [&](uint32_t (&dst)[9], int jj) {
 #pragma unroll
-      for (int d1 = 0; d1 < 3; ++d1)
+    for (int c = 0; c < G::L; ++c) { P2[c][0] = bv[0]; P2[c][1] = bv[1]; }
+    uint32_t raw[2][3];
+    auto fetch = [&](uint32_t (&dst)[3], int jj) {
 #pragma unroll
-        for (int d2 = 0; d2 < 3; ++d2) dst[d1 * 3 + d2] = *reinterpret_cast<const uint32_t*>(pl[d1] + d2 * G::ROWB + jj * 64);
+      for (int d2 = 0; d2 < 3; ++d2) dst[d2] = *reinterpret_cast<const uint32_t*>(pl + d2 * G::ROWB + jj * 64);
     };
     fetch(raw[0], 0);
 #pragma unroll
     for (int jj = 0; jj < G::L + 2; ++jj) {
-      if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], jj + 1);   // one column ahead, no further (the barrier below)
+      if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], jj + 1);   // one column ahead
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
+      for (int d2 = 0; d2 < 3; ++d2) {
         float x0, x1;
-        unpack2(raw[jj & 1][k], x0, x1);
-        if (jj <= G::L - 1) { accp[0] = fmaf(wk[k * 3 + 0][0], x0, accp[0]); accp[1] = fmaf(wk[k * 3 + 0][1], x1, accp[1]); }
-        if (jj >= 1 && jj <= G::L) { acc0[0] = fmaf(wk[k * 3 + 1][0], x0, acc0[0]); acc0[1] = fmaf(wk[k * 3 + 1][1], x1, acc0[1]); }
-        if (jj >= 2) { accm[0] = fmaf(wk[k * 3 + 2][0], x0, accm[0]); accm[1] = fmaf(wk[k * 3 + 2][1], x1, accm[1]); }
+        unpack2(raw[jj & 1][d2], x0, x1);
+#pragma unroll
+        for (int d3 = 0; d3 < 3; ++d3) {
+          const int c = jj - d3;                                  // input column jj (halo coordinates) is tap d3 of output column jj - d3
+          if (c >= 0 && c < G::L) {
+            P0[c][0] = fmaf(wk[18 + d2 * 3 + d3][0], x0, P0[c][0]); P0[c][1] = fmaf(wk[18 + d2 * 3 + d3][1], x1, P0[c][1]);
+            P1[c][0] = fmaf(wk[9 + d2 * 3 + d3][0], x0, P1[c][0]);  P1[c][1] = fmaf(wk[9 + d2 * 3 + d3][1], x1, P1[c][1]);
+            P2[c][0] = fmaf(wk[d2 * 3 + d3][0], x0, P2[c][0]);      P2[c][1] = fmaf(wk[d2 * 3 + d3][1], x1, P2[c][1]);
+          }
+        }
       }
-      if (jj >= 2) {
-        if (COMP) { accm[0] += __uint_as_float(ev[jj - 2] << 16); accm[1] += __uint_as_float(ev[jj - 2] & 0xffff0000u); }
-        const uint32_t yv = pack2bf(accm[0], accm[1]);
+      if (jj >= 2) {                                              // output column jj - 2 of plane m has all its 27 taps
+        float o0 = P0[jj - 2][0], o1 = P0[jj - 2][1];
+        if (COMP) { o0 += __uint_as_float(ev[jj - 2] << 16); o1 += __uint_as_float(ev[jj - 2] & 0xffff0000u); }
+        const uint32_t yv = pack2bf(o0, o1);
         __builtin_amdgcn_raw_buffer_store_b32(yv, yres, lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
         if (COMP)
-          __builtin_amdgcn_raw_buffer_store_b32(pack2bf(accm[0] - __uint_as_float(yv << 16), accm[1] - __uint_as_float(yv & 0xffff0000u)), rres_d,
+          __builtin_amdgcn_raw_buffer_store_b32(pack2bf(o0 - __uint_as_float(yv << 16), o1 - __uint_as_float(yv & 0xffff0000u)), rres_d,
                                                 lane_off, plane_off + (uint32_t)((jj - 2) * C * 2), 0);
       }
-      accm[0] = acc0[0]; accm[1] = acc0[1]; acc0[0] = accp[0]; acc0[1] = accp[1]; accp[0] = bv[0]; accp[1] = bv[1];
     }
+  };
+  float PA[G::L][2], PB[G::L][2], PC[G::L][2];
+#pragma unroll
+  for (int c = 0; c < G::L; ++c) { PA[c][0] = PB[c][0] = bv[0]; PA[c][1] = PB[c][1] = bv[1]; }
+#pragma nounroll
+  for (int m = 0; m < D1; m += 3) {
+    step(m, PA, PB, PC);
+    if (m + 1 < D1) step(m + 1, PB, PC, PA);
+    if (m + 2 < D1) step(m + 2, PC, PA, PB);
   }
 }
 
@@ -281,7 +305,7 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kerne
   constexpr int NT = G::NCW * 64;
   constexpr int XR = G::WSLOT * G::SLOT;                  // x ring, then two dy planes, then the dump row
   constexpr int NPX = G::NPX, NPD = G::NPD;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // (wave: uniform -> scalar registers)
   const Tile t = tile_of(C / PCC, ntile, TB);
   for (int i = threadIdx.x; i < (XR + 2 * G::DSLOT) / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
@@ -295,9 +319,12 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kerne
   const int rg = wave % (TB / 4), seg = wave / (TB / 4);
   const int r = rg * 4 + (lane >> 4), pr = lane & 15, g0 = seg * G::L;
 
-  // No stores in the march, so every wave fetches its share of the coming planes itself (pieces wave, wave + NCW, ...): no loader
-  // waves, the twelve compute waves keep 168 registers each.  Step m issues dy plane m + 1, then x plane m + WDEPTH; with WDEPTH = 2 a
-  // wave waits before the barrier of step m until only its pieces of x plane m + 1 (the youngest) are still in flight.
+  // No stores in the march, so every wave fetches its share of the coming planes itself (pieces wave, wave + NCW, ...): no loader wave.
+  // Step s (0 .. D1 + 1) takes dy plane s out of LDS into registers (unpacked, kept for three steps: the sets rotate by NAME, the march is
+  // unrolled three times) and pairs x plane s - 2 with dy planes s - 2, s - 1, s (taps d1 = 2, 1, 0): every x value is read and unpacked
+  // ONCE per thread (3 rows x (L + 2) columns per step, not 3 planes x 3 rows), every dy value once.  dy plane s + 1 is requested in
+  // step s, x plane j in step j + 2 - WDEPTH (WDEPTH steps before its use); with WDEPTH = 2 a wave waits before the barrier of step s
+  // until only its pieces of x plane s - 1 (the youngest) are still in flight.
   const lds_ptr l3 = (lds_ptr)lds;
   constexpr uint32_t dump = XR + 2 * G::DSLOT;
   LaneSrc<D3> ls;
@@ -309,51 +336,61 @@ __global__ __launch_bounds__((Geo<TB, D3>::NCW) * 64) void peg_wgrad_march_kerne
     dma_plane<D3, NPD, G::NCW>(gb + m * plane_elems, l3, (uint32_t)(XR + (m & 1) * G::DSLOT), dump, G::DROWB, 0, t.beta0, wave, D2, C, ls);
   };
   constexpr int XLO = NPX / G::NCW, XEXTRA = NPX % G::NCW;   // x pieces per wave: XLO, + 1 for the first XEXTRA waves
-  issue_x(0); issue_g(0);
-  if (G::WDEPTH == 2 && D1 > 1) issue_x(1);
-  {
-    const uint32_t tb = (uint32_t)((r * G::RSP + g0) * 64 + pr * 4);
-    const uint32_t db = (uint32_t)(XR + (r * G::RSD + g0) * 64 + pr * 4);
-    for (int m = 0; m < D1; ++m) {
-      if (G::WDEPTH == 1 || m + 1 >= D1) wait_vm<0>();
-      else if (wave < XEXTRA) wait_vm<XLO + 1>();
-      else wait_vm<XLO>();
-      wg_barrier();
-      if (m + 1 < D1) issue_g(m + 1);
-      if (m + G::WDEPTH < D1) issue_x(m + G::WDEPTH);
-      const char* pl[3];
+  const uint32_t tb = (uint32_t)((r * G::RSP + g0) * 64 + pr * 4);
+  const uint32_t db = (uint32_t)(XR + (r * G::RSD + g0) * 64 + pr * 4);
+  auto step = [&](int s, float (&Ga)[G::L][2], float (&Gb)[G::L][2], float (&Gc)[G::L][2]) {      // dy planes s - 2, s - 1, s (Gc: filled here)
+    if (G::WDEPTH == 2 && s >= 1 && s <= D1) { if (wave < XEXTRA) wait_vm<XLO + 1>(); else wait_vm<XLO>(); }
+    else wait_vm<0>();
+    wg_barrier();
+    if (s + 1 < D1) issue_g(s + 1);
+    if (s + G::WDEPTH - 2 >= 0 && s + G::WDEPTH - 2 < D1) issue_x(s + G::WDEPTH - 2);
+    {
+      const char* gp = lds + db + (s & 1) * G::DSLOT;
+      const uint32_t live = s < D1 ? 0xffffffffu : 0u;        // past the last plane the slot holds an old plane: dy = 0
 #pragma unroll
-      for (int d1 = 0; d1 < 3; ++d1) pl[d1] = lds + ((m + d1 - 2 + G::WSLOT) % G::WSLOT) * G::SLOT + tb;
-      const char* gp = lds + db + (m & 1) * G::DSLOT;
-      float gm[2] = {0.f, 0.f}, gc[2] = {0.f, 0.f};       // dy[col - 1], dy[col] of the thread's OWN outputs (0 outside its quarter)
-      uint32_t raw[2][9], graw[2] = {0u, 0u};
-      auto fetch = [&](uint32_t (&dst)[9], uint32_t& g, int jj) {
-        if (jj <= G::L - 1) g = *reinterpret_cast<const uint32_t*>(gp + jj * 64);
-#pragma unroll
-        for (int d1 = 0; d1 < 3; ++d1)
-#pragma unroll
-          for (int d2 = 0; d2 < 3; ++d2) dst[d1 * 3 + d2] = *reinterpret_cast<const uint32_t*>(pl[d1] + d2 * G::ROWB + jj * 64);
-      };
-      fetch(raw[0], graw[0], 0);
-#pragma unroll
-      for (int jj = 0; jj < G::L + 2; ++jj) {
-        if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], graw[(jj + 1) & 1], jj + 1);
-        asm volatile("" ::: "memory");
-        float gq[2] = {0.f, 0.f};                         // dy[col + 1]
-        if (jj <= G::L - 1) {
-          unpack2(graw[jj & 1], gq[0], gq[1]);
-          accb[0] += gq[0]; accb[1] += gq[1];
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          float x0, x1;
-          unpack2(raw[jj & 1][k], x0, x1);
-          if (jj <= G::L - 1) { acc[k * 3 + 0][0] = fmaf(gq[0], x0, acc[k * 3 + 0][0]); acc[k * 3 + 0][1] = fmaf(gq[1], x1, acc[k * 3 + 0][1]); }
-          if (jj >= 1 && jj <= G::L) { acc[k * 3 + 1][0] = fmaf(gc[0], x0, acc[k * 3 + 1][0]); acc[k * 3 + 1][1] = fmaf(gc[1], x1, acc[k * 3 + 1][1]); }
-          if (jj >= 2) { acc[k * 3 + 2][0] = fmaf(gm[0], x0, acc[k * 3 + 2][0]); acc[k * 3 + 2][1] = fmaf(gm[1], x1, acc[k * 3 + 2][1]); }
-        }
-        gm[0] = gc[0]; gm[1] = gc[1]; gc[0] = gq[0]; gc[1] = gq[1];
+      for (int c = 0; c < G::L; ++c) {
+        unpack2(*reinterpret_cast<const uint32_t*>(gp + c * 64) & live, Gc[c][0], Gc[c][1]);
+        accb[0] += Gc[c][0]; accb[1] += Gc[c][1];
       }
+    }
+    if (s < 2) return;
+    const char* pl = lds + ((s - 2) % G::WSLOT) * G::SLOT + tb;
+    uint32_t raw[2][3];
+    auto fetch = [&](uint32_t (&dst)[3], int jj) {
+#pragma unroll
+      for (int d2 = 0; d2 < 3; ++d2) dst[d2] = *reinterpret_cast<const uint32_t*>(pl + d2 * G::ROWB + jj * 64);
+    };
+    fetch(raw[0], 0);
+#pragma unroll
+    for (int jj = 0; jj < G::L + 2; ++jj) {
+      if (jj + 1 < G::L + 2) fetch(raw[(jj + 1) & 1], jj + 1);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int d2 = 0; d2 < 3; ++d2) {
+        float x0, x1;
+        unpack2(raw[jj & 1][d2], x0, x1);
+#pragma unroll
+        for (int d3 = 0; d3 < 3; ++d3) {
+          const int c = jj - d3;                       // input column jj (halo coordinates) is tap d3 of output column jj - d3
+          if (c >= 0 && c < G::L) {
+            acc[18 + d2 * 3 + d3][0] = fmaf(Ga[c][0], x0, acc[18 + d2 * 3 + d3][0]); acc[18 + d2 * 3 + d3][1] = fmaf(Ga[c][1], x1, acc[18 + d2 * 3 + d3][1]);
+            acc[9 + d2 * 3 + d3][0] = fmaf(Gb[c][0], x0, acc[9 + d2 * 3 + d3][0]);   acc[9 + d2 * 3 + d3][1] = fmaf(Gb[c][1], x1, acc[9 + d2 * 3 + d3][1]);
+            acc[d2 * 3 + d3][0] = fmaf(Gc[c][0], x0, acc[d2 * 3 + d3][0]);           acc[d2 * 3 + d3][1] = fmaf(Gc[c][1], x1, acc[d2 * 3 + d3][1]);
+          }
+        }
+      }
+    }
+  };
+  issue_g(0);
+  {
+    float GA[G::L][2], GB[G::L][2], GC[G::L][2];
+#pragma unroll
+    for (int c = 0; c < G::L; ++c) { GA[c][0] = GA[c][1] = GB[c][0] = GB[c][1] = 0.f; }
+#pragma nounroll
+    for (int s = 0; s < D1 + 2; s += 3) {
+      step(s, GA, GB, GC);
+      if (s + 1 < D1 + 2) step(s + 1, GB, GC, GA);
+      if (s + 2 < D1 + 2) step(s + 2, GC, GA, GB);
     }
   }
   // ---- fold: the 4 rows of a wave (lanes 16 apart), then the compute waves in order, then out
@@ -399,7 +436,7 @@ int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, 
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
   constexpr int SHM = G::NSLOT * G::SLOT + G::ROWB;
-  static_assert(G::DEPTH >= 1, "three live planes and at least one in flight");
+  static_assert(G::DEPTH >= 1, "one live plane and at least one in flight");
   const size_t shm = SHM;
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_march_kernel<TB, D3, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
   if (!once) { (void)hipGetLastError(); return 1; }
@@ -411,8 +448,8 @@ template <int TB, int D3>
 int launch_wgrad(const bf16_t* dy, const bf16_t* x, float* part, int64_t B, int D1, int D2, int C, hipStream_t s) {
   using G = Geo<TB, D3>;
   const int ntile = (D2 + TB - 1) / TB;
-  constexpr int SHM = G::WSLOT * G::SLOT + 2 * G::DSLOT + G::ROWB;
-  static_assert(SHM >= G::NCW * 16 * 57 * 4, "fold scratch must fit in the ring");
+  constexpr int RING = G::WSLOT * G::SLOT + 2 * G::DSLOT + G::ROWB, FOLD = G::NCW * 16 * 57 * 4;     // (the fold reuses the ring)
+  constexpr int SHM = RING > FOLD ? RING : FOLD;
   if (SHM > G::LDS_MAX) return 1;                        // e.g. 12-row tiles of D3 = 32: the first-generation kernel takes over
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&peg_wgrad_march_kernel<TB, D3>), hipFuncAttributeMaxDynamicSharedMemorySize, SHM) == hipSuccess; }();
   if (!once) { (void)hipGetLastError(); return 1; }
