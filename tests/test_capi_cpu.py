@@ -50,3 +50,32 @@ def test_docs_state_the_header_entry_point_count():
         text = open(os.path.join(root, doc)).read()
         counts = {int(m) for m in re.findall(r"(\d+) `extern \"C\"`", text)} | {int(m) for m in re.findall(r"\((\d+) entry points\)", text)}
         assert counts == {n}, (doc, counts, n)
+
+
+def test_argument_checks_answer_before_any_launch():
+    """Every entry point validates its arguments before it touches the device: null pointers, misaligned strides, missing workspace and
+    geometries no kernel serves come back as CTCLIP_EBADARG (-1) / CTCLIP_EUNSUPPORTED (-2) / CTCLIP_EWORKSPACE (-3) with a message in
+    ctclip_last_error() -- no GPU needed (this container has none), no launch attempted."""
+    from ct_clip_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)            # a 16-byte aligned host address: never dereferenced by the checks
+    p = (p + 255) // 256 * 256
+    BF16 = 1
+    cases = [
+        ("ctclip_gemm_headnorm null output", lambda: lib.ctclip_gemm_headnorm(p, p, 256, 1, 512, 512, 512, None, None, None, 1.0, None, None, None, 1.0, None, None, None, 1.0, BF16, None), -1),
+        ("ctclip_gemm_headnorm f32", lambda: lib.ctclip_gemm_headnorm(p, p, 256, 1, 512, 512, 512, p, None, None, 1.0, None, None, None, 1.0, None, None, None, 1.0, 0, None), -2),
+        ("ctclip_gemm_residual_comp null residue", lambda: lib.ctclip_gemm_residual_comp(p, p, p, None, p, p, 256, 512, 512, 512, 512, 512, 512, BF16, None), -1),
+        ("ctclip_peg_fwd_comp null e_out", lambda: lib.ctclip_peg_fwd_comp(p, p, None, None, p, None, 1, 4, 4, 8, 32, BF16, None), -1),
+        ("ctclip_peg_fwd_comp D3 = 5", lambda: lib.ctclip_peg_fwd_comp(p, p, None, None, p, p, 1, 4, 4, 5, 32, BF16, None), -2),
+        ("ctclip_attn2_bwd_tok odd stride", lambda: lib.ctclip_attn2_bwd_tok(p, p, p, None, 0, 0, p, p, 8.0, p, 257, p, 256, p, p, p, p, 512, p, 512, p, None, 2, 8, 576, p, 1 << 30, None), -1),
+        ("ctclip_attn2_bwd_tok no workspace", lambda: lib.ctclip_attn2_bwd_tok(p, p, p, None, 0, 0, p, p, 8.0, p, 256, p, 256, p, p, p, p, 512, p, 512, p, None, 2, 8, 576, None, 0, None), -3),
+        ("ctclip_attn2_unprep_q null", lambda: lib.ctclip_attn2_unprep_q(None, p, p, p, 8.0, p, 256, p, 1152, 8, p, 1 << 20, None), -1),
+        ("ctclip_patch_embed_param_bwd null", lambda: lib.ctclip_patch_embed_param_bwd(None, p, p, p, p, p, p, p, 512, 4000, 0, None), -1),
+        ("ctclip_adam_step step 0", lambda: lib.ctclip_adam_step(p, p, p, p, 1024, 1e-4, 0.9, 0.99, 1e-8, 0, 0.0, None, None, None), -1),
+    ]
+    for name, call, want in cases:
+        rc = call()
+        assert rc == want, (name, rc, lib.ctclip_last_error())
+        if want != -2:
+            assert lib.ctclip_last_error(), name
