@@ -60,7 +60,7 @@ struct Geo {
   // flight, + one dump row (vmcnt is a 6-bit counter: the loader wave never has more than 63 pieces outstanding)
   static constexpr int DEPTH_LDS = (LDS_MAX - ROWB) / SLOT - 1;
   static constexpr int DEPTH_VM = 63 / NPX;
-  static constexpr int DEPTH_CAP = D3 == 8 ? 1 : PEG_DEPTH;    // (D3 = 8: two unrolled planes of 14 single-piece rows spill in the loader wave)
+  static constexpr int DEPTH_CAP = PEG_DEPTH;
   static constexpr int DEPTH = DEPTH_LDS < DEPTH_VM ? (DEPTH_LDS < DEPTH_CAP ? DEPTH_LDS : DEPTH_CAP) : (DEPTH_VM < DEPTH_CAP ? DEPTH_VM : DEPTH_CAP);
   static constexpr int NSLOT = DEPTH + 1;
   // weight gradient: one live x plane + WDEPTH in flight, the dy planes one ahead
@@ -428,8 +428,9 @@ bool lds_path_enabled() {
   return on;
 }
 
-// TB = 12 when that fills the chip, else TB = 4 (three workgroups per CU)
-int pick_tb(int64_t B, int D2, int C) { return B * ((D2 + 11) / 12) * (C / PCC) >= 200 ? 12 : 4; }
+// TB = 12 when that fills the chip, else TB = 4 (three workgroups per CU).  D3 = 8 always takes TB = 4: at thirteen waves per workgroup (128
+// registers) the two-column threads of that geometry spill, at five waves they do not.
+int pick_tb(int64_t B, int D2, int D3, int C) { return (D3 != 8 && B * ((D2 + 11) / 12) * (C / PCC) >= 200) ? 12 : 4; }
 
 template <int TB, int D3, int DIR>
 int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, const bf16_t* ein, bf16_t* rres, int64_t B, int D1, int D2, int C, hipStream_t s) {
@@ -477,7 +478,7 @@ int64_t peg_lds_wgrad_groups(int64_t B, int D2, int C) { return B * ((D2 + 3) / 
 
 int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dir, hipStream_t s, const void* ein, void* rres) {
   const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* rp = (bf16_t*)rres; const bf16_t* ep = (const bf16_t*)ein;
-  const int tb = pick_tb(B, D2, C);
+  const int tb = pick_tb(B, D2, D3, C);
 #define FWD12(D) launch_march<12, D, 1>(xp, w, bias, yp, nullptr, nullptr, B, D1, D2, C, s)
 #define FWD4(D) launch_march<4, D, 1>(xp, w, bias, yp, nullptr, nullptr, B, D1, D2, C, s)
 #define CMP12(D) launch_march<12, D, 2>(xp, w, bias, yp, ep, rp, B, D1, D2, C, s)
@@ -497,7 +498,7 @@ int peg_lds_march(const void* x, const float* w, const float* bias, void* y, int
 
 int peg_lds_wgrad(const void* dy, const void* x, float* part, int64_t B, int D1, int D2, int D3, int C, int* groups, hipStream_t s) {
   const bf16_t* gp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
-  const int tb = pick_tb(B, D2, C);
+  const int tb = pick_tb(B, D2, D3, C);
   *groups = (int)(B * ((D2 + tb - 1) / tb));
 #define WG12(D) launch_wgrad<12, D>(gp, xp, part, B, D1, D2, C, s)
 #define WG4(D) launch_wgrad<4, D>(gp, xp, part, B, D1, D2, C, s)

@@ -108,6 +108,18 @@ soak("attn2_fwd (slab)", lambda: as_list(be.attn2_fwd(qh, kh, vh, tab, (24, 24),
 o, lse2 = be.attn2_fwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, nseq, L)
 do = rnd(nseq * L, 256, scale=0.1)
 soak("attn2_bwd (dq, dkv, dbias)", lambda: as_list(be.attn2_bwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, nseq, L, True)))
+dq_t, dkv_t = torch.empty(nseq * L, 256, dtype=bf, device=dev), torch.empty(nseq * L, 512, dtype=bf, device=dev)
+dqs2, dks2 = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
+soak("attn2_bwd_tok + unprep_q (round 3: key pass writes row-major dk / dv)",
+     lambda: as_list(be.attn2_bwd_tok(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq_t, dkv_t[:, :256], dkv_t[:, 256:], dqs2.zero_(),
+                                      dks2.zero_(), nseq, L, True))[:1] + [dq_t, dkv_t, dqs2, dks2])
+w_qn, w_kvn = rnd(256, 512, scale=0.05), rnd(512, 512, scale=0.05)
+soak("gemm_headnorm to_q (round 3: attention operands from the epilogue)", lambda: [t for pair in be.gemm_headnorm(x512, w_qn, [(qs, 8.0 * 1.4426950408889634)]) for t in pair])
+soak("gemm_headnorm to_kv", lambda: [t for pair in be.gemm_headnorm(x512, w_kvn, [(ks, 1.0), (None, 1.0)]) for t in pair])
+e5 = rnd(8, 24, 24, 24, 512, scale=0.004)
+soak("peg_fwd_comp (round 3: compensated residual stream)", lambda: as_list(be.peg_fwd_comp(x5, w27, b27, e5)))
+e2 = rnd(M, 512, scale=0.004)
+soak("gemm_residual_comp ff_out (N=512, K=1408)", lambda: as_list(be.gemm_residual_comp(g1408, w_ffout, res, e2)))
 # ---- temporal attention (csrc/attn_short.hip): 4608 sequences x 24 tokens
 nseq_t, L_t = 4608, 24
 soak("attn_short_fwd", lambda: [be.attn_short_fwd(q, kv, qs, ks, nseq_t, L_t, H, 8.0)])
