@@ -5,6 +5,9 @@
 
 namespace {
 
+#ifndef PATCH_LN_XCD
+#define PATCH_LN_XCD 1     // 0 = token = workgroup index (A/B builds)
+#endif
 #ifndef LN_FWD_RU
 #define LN_FWD_RU 4
 #endif
@@ -180,7 +183,16 @@ __global__ __launch_bounds__(256) void patch_ln_kernel(const float* __restrict__
   __shared__ float red[16];
   const int t = F / pt, h = H / p1, w = W / p2;
   const int K = pt * p1 * p2;
+  // Workgroups go to the 8 XCDs round-robin.  The w tokens of one grid row read the same 128-byte lines of the volume (a patch row is p2 floats
+  // = 80 bytes at CT-CLIP's 20 x 20 x 10 patches: neither aligned to nor a multiple of a line), so a whole row of tokens is dealt to ONE XCD:
+  // every line is then fetched into one L2 only.
   int64_t tok = blockIdx.x;
+#if PATCH_LN_XCD
+  if ((gridDim.x / w) % 8 == 0) {
+    const int64_t r = tok >> 3;
+    tok = ((r / w) * 8 + (tok & 7)) * w + r % w;
+  }
+#endif
   const int j = tok % w; const int i = (tok / w) % h; const int tau = (tok / ((int64_t)w * h)) % t; const int64_t b = tok / ((int64_t)w * h * t);
   const float* vb = video + b * (int64_t)F * H * W;
   constexpr int NV = 4;  // up to 256 * 4 * 4 = 4096 patch elements

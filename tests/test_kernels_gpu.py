@@ -153,7 +153,7 @@ def test_layernorm_fwd_bwd(hip, ref, dtype, rows, cols):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("geom", [(2, 32, 64, 64, 16, 16, 16), (1, 20, 40, 60, 10, 20, 20), (1, 6, 9, 6, 3, 3, 3)])
+@pytest.mark.parametrize("geom", [(2, 32, 64, 64, 16, 16, 16), (1, 20, 40, 60, 10, 20, 20), (1, 6, 9, 6, 3, 3, 3), (1, 40, 80, 100, 10, 20, 20)])   # (the last: 16 rows of 5 tokens -> the XCD-grouped token order)
 def test_patch_ln(hip, ref, dtype, geom):
     B, Fr, H, W, pt, p1, p2 = geom
     K = pt * p1 * p2
