@@ -377,3 +377,27 @@ def test_fused_qkv_attention_node_equals_the_composition(ref_backend, monkeypatc
     a, b = run(True), run(False)
     for u, v, name in zip(a, b, ("o", "dxn", "dxkv", "dwq", "dwkv", "dq_scale", "dk_scale", "dtab")):
         torch.testing.assert_close(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max()), msg=lambda m, name=name: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("name", ["default", "lipro", "vocabfine"])
+def test_committed_bench_lines_keep_the_contract(name):
+    """The bench lines committed under profiles/ are what `python bench.py [--workload ...]` printed on the GPU box: one JSON object with the
+    driver's keys, BASELINE.json's metric on a named workload (no model keys), a roofline object priced against the HBM / MFMA peak with
+    frac = achieved / peak, and a bounded cpu_baseline."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = json.loads(open(os.path.join(root, "profiles", f"r03_bench_{name}_1gpu.json")).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["scaling"] == "weak" and b["vs_baseline"] is None and b["dtype"] == "bf16"
+    assert "workload" in b["config"] and "model" not in b["config"] and b["data"].startswith("synthetic")
+    units_per_step = {"default": 8, "lipro": 16, "vocabfine": 1}[name]            # volumes one step processes on one GPU
+    assert abs(b["value"] - units_per_step / (b["ms_per_step"] / 1e3)) / b["value"] < 2e-3
+    r = b["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == (8000.0 if r["bound"] == "hbm" else 2500.0)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    c = b["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == b["unit"] and c["sample"]
+    assert b["value"] / c["value"] > 10           # (reported beside the GPU number, not the target)
