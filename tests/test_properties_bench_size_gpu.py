@@ -11,7 +11,11 @@ per step on the CPU); these tests run every hot kernel and the whole forward at 
   * the vector quantiser maps its own codebook to itself (idempotence);
   * Adam with zero gradient and zero moments leaves 284 M parameters untouched, the two-stage gradient norm of a known vector is exact;
   * the image tower is equivariant under permutations of the batch, BIT FOR BIT (no kernel's arithmetic depends on where a volume sits), and the
-    symmetric InfoNCE loss is invariant when the (report, volume) pairs are permuted together.
+    symmetric InfoNCE loss is invariant when the (report, volume) pairs are permuted together;
+  * every backward kernel is the ADJOINT of its forward (<F x, dy> = <x, F^T dy>: the dot-product test): PEG, the three products of a Linear
+    layer, LayerNorm (whose Jacobian is symmetric), attention in its values, spatial and temporal;
+  * one training step (forward + backward into the flat gradient buffer) repeated on the same batch gives the same 284 M gradients bit for bit,
+    and the same loss / gradient norm when the pairs are permuted.
 """
 import os
 import sys
@@ -152,8 +156,58 @@ def test_adam_with_zero_gradient_is_the_identity_and_the_norm_of_ones_is_exact(b
     assert abs(float(out[0]) - n ** 0.5) / n ** 0.5 < 1e-6 and abs(float(out[1]) - 0.5 / (n ** 0.5 + 1e-6)) < 1e-9
 
 
-# ------------------------------------------------------------------------------------------------------------------ the whole forward
-def test_batch_permutation_equivariance_of_the_bench_model():
+# ------------------------------------------------------------------------------------------------------------------ backward = adjoint
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def same(a, b, rel):
+    assert abs(a - b) <= rel * max(abs(a), abs(b)), (a, b)
+
+
+def test_backward_kernels_are_the_adjoints_of_their_forwards(be):
+    # PEG: F(x) = x + K x (no bias), backward B(dy) = dy + K^T dy
+    B, G, C = 8, 24, 512
+    w = rnd(C, 27, seed=20, scale=0.1, dtype=torch.float32)
+    x5, n5 = rnd(B, G, G, G, C, seed=21), rnd(B, G, G, G, C, seed=22)
+    y5 = be.peg_fwd(x5, w, None)
+    dy5 = (y5.float() + 0.5 * n5.float()).to(BF)                    # correlated with F(x): the inner products are of the order of |F x|^2
+    same(dot(y5, dy5), dot(x5, be.peg_bwd(dy5, x5, w, None, None)), 2e-3)
+    # Linear: y = x W^T, dx = dy W, dW = dy^T x
+    x, n = rnd(M, D, seed=23), rnd(M, D, seed=24)
+    W = rnd(D, D, seed=25, scale=0.05)
+    y = be.gemm(x, W)
+    dy = (y.float() + 0.5 * n.float()).to(BF)
+    ref = dot(y, dy)
+    same(ref, dot(x, be.gemm(dy, W.t().contiguous())), 2e-3)
+    dW = torch.zeros(D, D, device=DEV)
+    be.gemm(dy, x, a_kc=False, b_kc=False, out=dW, accumulate=True, split_k=0, M=D, N=D, K=M)
+    same(ref, dot(W, dW), 2e-3)
+    # LayerNorm (no affine): dx = J dy with J symmetric
+    xl = (rnd(M, D, seed=26, scale=2.0) + 1).contiguous()
+    _, mean, rstd = be.layernorm_fwd(xl, None, None, 1e-5)
+    u = rnd(M, D, seed=27)
+    v = (u.float() + 0.5 * rnd(M, D, seed=28).float()).to(BF)
+    same(dot(be.layernorm_bwd(u, xl, None, mean, rstd), v), dot(u, be.layernorm_bwd(v, xl, None, mean, rstd)), 2e-3)
+    # attention is linear in its values: <P V, dO> = <V, P^T dO>
+    nseq, L, H = 192, 576, 8
+    q, k, vv = rnd(nseq * L, 256, seed=29), rnd(nseq * L, 256, seed=30), rnd(nseq * L, 256, seed=31)
+    qs, ks = torch.rand(32, device=DEV) + 0.5, torch.rand(32, device=DEV) + 0.5
+    tab = rnd(47 * 47, H, seed=32, scale=0.5, dtype=torch.float32)
+    qh, kh, vh, _, _ = be.attn2_prep(q, k, vv, qs, ks, 8.0, H)
+    o, lse2 = be.attn2_fwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, nseq, L)
+    do = (o.float() + 0.5 * rnd(nseq * L, 256, seed=33).float() * float(o.float().std())).to(BF)
+    dvh = be.attn2_bwd(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, nseq, L, True)[2]
+    same(dot(o, do), dot(vh, dvh), 5e-3)
+    kv = torch.cat([k, vv], dim=1).contiguous()
+    ot = be.attn_short_fwd(q, kv, qs, ks, 4608, 24, H, 8.0)
+    dot_ = (ot.float() + 0.5 * rnd(nseq * L, 256, seed=34).float() * float(ot.float().std())).to(BF)
+    dkv = be.attn_short_bwd(q, kv, qs, ks, dot_, 4608, 24, H, 8.0)[1]
+    same(dot(ot, dot_), dot(vv, dkv[:, 256:]), 5e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------ the whole forward / step
+def test_bench_model_batch_equivariance_and_training_step_repeatability():
     sys.path.insert(0, ROOT)
     import bench
     args = type("A", (), dict(image=480, frames=240, spatial_depth=12, temporal_depth=12, bert_dropout=0.1, batch=8, text_len=128))()
@@ -180,6 +234,26 @@ def test_batch_permutation_equivariance_of_the_bench_model():
             l0 = float(clip(bench.Text(ids, mask), video2, return_loss=True, device=DEV))
             l1 = float(clip(bench.Text(ids[perm].contiguous(), mask[perm].contiguous()), video2[perm].contiguous(), return_loss=True, device=DEV))
             assert l0 == l0 and abs(l0 - l1) <= 1e-5 * abs(l0)
+        # one training step's forward + backward at the bench batch (eval mode: no dropout, no EMA update -- the only run-to-run inputs): the
+        # 284 M gradients of the flat buffer repeat bit for bit, loss and gradient norm survive a permutation of the pairs
+        from ct_clip_amd import functional as Fn
+        from ct_clip_amd import backend
+
+        def step(text, vid):
+            trainer.optim.zero_grad()
+            loss = trainer.forward_backward(vid, text)
+            Fn.join_side_streams()
+            torch.cuda.synchronize()
+            flat = trainer.optim.flat_grad
+            return float(loss.detach()), float(backend.get().grad_norm_clip(flat, 0.5)[0]), flat.clone()
+
+        la, na, ga = step(bench.Text(ids, mask), video2)
+        lb, nb, gb = step(bench.Text(ids, mask), video2)
+        assert la == lb and torch.equal(ga, gb) and na > 0 and torch.isfinite(ga).all()
+        del gb
+        lc, nc, gc = step(bench.Text(ids[perm].contiguous(), mask[perm].contiguous()), video2[perm].contiguous())
+        assert abs(la - lc) <= 1e-5 * abs(la) and abs(na - nc) <= 2e-3 * na
+        assert float((ga - gc).norm() / ga.norm()) < 2e-2               # (bf16 activations: the reductions over the batch run in another order)
     finally:
         trainer.close()
         del clip, trainer
