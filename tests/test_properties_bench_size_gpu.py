@@ -229,6 +229,13 @@ def test_bench_model_batch_equivariance_and_training_step_repeatability():
             assert torch.equal(tok_p, tok[perm])
             codes = vit(video, return_only_codebook_ids=True)
             assert torch.equal(codes[:4], codes[4:])
+            # batch-size independence: one volume alone (13 824 tokens: the small-problem dispatch of several kernels -- unfused attention
+            # operands, other GEMM tile counts) against the same volume inside the batch of 8: the same function up to bf16 evaluation order
+            tok1 = vit.tokens_before_vq(video[:1].contiguous())[0].view(-1, D).float()
+            rel1 = float((tok1 - tok[0].float()).norm() / tok[0].float().norm())
+            agree1 = float((vit(video[:1].contiguous(), return_only_codebook_ids=True)[0] == codes[0]).float().mean())
+            print(f"[bench size] one volume alone against the batch of 8: token rel. difference {rel1:.2e}, code agreement {agree1:.4f}")
+            assert rel1 < 3e-2 and agree1 > 0.93
             # symmetric InfoNCE over (report, volume) pairs: distinct volumes, pairs permuted together
             video2 = torch.rand(8, 1, 240, 480, 480, generator=g, device=DEV) * 2 - 1
             l0 = float(clip(bench.Text(ids, mask), video2, return_loss=True, device=DEV))
