@@ -6,7 +6,6 @@ keys and -- because sub-modules are created in the refere
 initialisers -- the same random initialisation for a given seed.  The modules below are parameter containers;
 all arithmetic goes through ``ct_clip_amd.functional`` (HIP kernels via the C-ABI library).
 """
-import math
 import os
 from pathlib import Path
 

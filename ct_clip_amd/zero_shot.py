@@ -12,7 +12,6 @@ import torch
 from torch import nn
 
 from . import distributed as _dist
-from . import functional as Fn
 
 PATHOLOGIES = ['Medical material', 'Arterial wall calcification', 'Cardiomegaly', 'Pericardial effusion',
                'Coronary artery wall calcification', 'Hiatal hernia', 'Lymphadenopathy', 'Emphysema', 'Atelectasis', 'Lung nodule',

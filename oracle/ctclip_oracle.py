@@ -16,7 +16,7 @@ vector-quantiser is an un-vendored third-party package restated from its publish
 All tensors are taken from a state dict that uses the reference's ``CTCLIP.state_dict()`` key
 names, so the same dict drives the reference, this oracle and the product.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 import math
 
 import torch
