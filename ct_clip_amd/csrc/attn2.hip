@@ -663,11 +663,6 @@ int dbias_splits(int nseq, int H, int L) {
   return ns < 1 ? 1 : ns;
 }
 inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
-int num_cus() {
-  static int ncu = 0;
-  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-  return ncu;
-}
 }  // namespace
 
 // slabs [nsplit][H][L][L] -> table gradient (ncls, H), deterministic; bins_ws: cdiv(L, DBIN_ROWS) * H * ncls floats of scratch

@@ -194,7 +194,6 @@ __global__ __launch_bounds__(WPB_F * 64) void attn_short_fwd_kernel(ShortParams 
   float sq[16], sk[16];
   load_scales(p.q_scale, half, sq); load_scales(p.k_scale, half, sk);
   const int HD = p.H * 32;
-  const bool valid = row < p.L;
   const int64_t nitems = (int64_t)p.nseq * p.H, stride = (int64_t)gridDim.x * WPB_F;
   auto fetch = [&](int64_t it, int vb) {
     const int64_t t0 = (it / p.H) * p.L; const int hh = (int)(it % p.H);

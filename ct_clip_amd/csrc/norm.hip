@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // out[c] += sum_b part[b][which][c].  One workgroup of 1024 threads per 64 columns: sixteen interleaved slices of the partial rows are
 // summed in parallel and combined in a fixed order (deterministic: the previous version combined chunks with f32 atomics; the
 // first version walked all 1024 partial rows with 16 workgroups of 64 threads: 58 us of pure latency, 76 times per step).
-constexpr int LN_RED_CHUNK = 64;      // (kept for the launch-shape arithmetic of the callers)
 __global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, int nblocks, int cols) {
   __shared__ float red[16][64];
