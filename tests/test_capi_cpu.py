@@ -79,3 +79,41 @@ def test_argument_checks_answer_before_any_launch():
         assert rc == want, (name, rc, lib.ctclip_last_error())
         if want != -2:
             assert lib.ctclip_last_error(), name
+
+
+def test_ctypes_signatures_agree_with_the_header():
+    """ct_clip_amd/_lib.py binds every entry point by hand (restype + argtypes); a wrong width there corrupts the call silently.  Every
+    prototype of include/ctclip_hip.h is parsed and compared with its binding: same number of parameters, and each parameter the same ABI
+    class (pointer / int / int64 / uint32 / uint64 / float / double)."""
+    import ctypes as C
+    from ct_clip_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "ctclip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+    def cls_of_c(decl):
+        d = decl.strip()
+        if "*" in d or d.startswith("hipStream_t"):
+            return "ptr"
+        base = " ".join(d.split()[:-1]) if len(d.split()) > 1 else d
+        base = base.replace("const ", "").strip()
+        return {"int": "i32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "unsigned": "u32", "unsigned int": "u32", "float": "f32",
+                "double": "f64", "void": "void"}[base]
+
+    def cls_of_ctypes(t):
+        if t in (C.c_void_p, C.c_char_p):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_uint32: "u32", C.c_float: "f32", C.c_double: "f64", None: "void"}[t]
+
+    protos = re.findall(r"^\s*([A-Za-z_][\w\s\*]*?)\b(ctclip_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.M)
+    assert len(protos) >= 85
+    for ret, name, params in protos:
+        assert name in _lib.SIGNATURES, name
+        restype, argtypes = _lib.SIGNATURES[name]
+        cparams = [] if params.strip() in ("", "void") else [p for p in params.split(",")]
+        assert len(cparams) == len(argtypes), (name, len(cparams), len(argtypes))
+        for i, (cp, at) in enumerate(zip(cparams, argtypes)):
+            assert cls_of_c(cp) == cls_of_ctypes(at), (name, i, cp.strip(), at)
+        r = ret.replace("const ", "").strip()
+        want = "ptr" if "*" in r else {"int": "i32", "int64_t": "i64", "void": "void"}[r]
+        assert want == cls_of_ctypes(restype), (name, ret, restype)
