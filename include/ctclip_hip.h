@@ -23,25 +23,25 @@ extern "C" {
 #endif
 typedef struct ihipStream_t* hipStream_t;
 
-/* per-(sequence, head) transposed copy [seq][h][d][Lp] used as MFMA A-operands by the attention kernels. */
+/* per-(sequence, head) transposed copy [seq][h][d][Lp] used as MFMA A-operands by the attention kernels.  [replaces the rearrange 'b n (h d) -> b h n d' of attention.py:147-150 and HF BertSelfAttention.transpose_for_scores] */
 int ctclip_head_transpose(const void* x, void* xt, int nseq, int H, int L, int Lp, int D, int64_t ldx, int dtype, hipStream_t stream);
 
 /* l2norm(q)*q_scale / l2norm(k)*k_scale per head (attention.py:152-154). */
 int ctclip_qk_norm_fwd(const void* x, const float* scale_vec, void* y, float* inv, int64_t M, int H, int D, int64_t ldx, int64_t ldy, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_qk_norm_bwd needs for the per-workgroup partial sums of the learned-scale gradient (deterministic two-stage sum). */
+/* bytes of workspace ctclip_qk_norm_bwd needs for the per-workgroup partial sums of the learned-scale gradient (deterministic two-stage sum). [workspace query of ctclip_qk_norm_bwd (autograd through attention.py:152-156)] */
 int64_t ctclip_qk_norm_bwd_workspace(int64_t M, int H, int D);
 
-/* backward of the above; dscale (D) ACCUMULATED (+=) through per-workgroup partials in `workspace` (>= ctclip_qk_norm_bwd_workspace bytes), summed in a fixed order. */
+/* backward of the above; dscale (D) ACCUMULATED (+=) through per-workgroup partials in `workspace` (>= ctclip_qk_norm_bwd_workspace bytes), summed in a fixed order. [replaces autograd through l2norm + the learned scales, attention.py:22-23,152-156] */
 int ctclip_qk_norm_bwd(const void* dy, const void* x, const float* inv, const float* scale_vec, void* dx, float* dscale, int64_t M, int H, int D, int64_t lddy, int64_t ldx, int64_t lddx, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* softmax(scale*q k^T + bias[h] + keymask[seq]) v (attention.py:156-178; HF BertSelfAttention). */
 int ctclip_attn_fwd(const void* q, const void* k, const void* vt, const float* bias, int bias_gh, int bias_gw, const float* keymask, void* out, float* lse, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldo, float scale, float dropout_p, uint64_t dropout_seed, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs). */
+/* bytes of workspace ctclip_attn_bwd needs when dbias is requested (per-split partial dBias slabs). [workspace query of ctclip_attn_bwd (autograd through attention.py:158-178; HF BertSelfAttention)] */
 int64_t ctclip_attn_bwd_workspace(int nseq, int H, int L);
 
-/* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). */
+/* backward of the above: dq, dk, dv and (optional, ACCUMULATED) dbias (H,L,L). [replaces autograd through einsum / softmax / dropout / einsum, attention.py:158-178 and HF BertSelfAttention.forward] */
 int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* o, const void* dout, const void* dot, const float* lse, const float* bias, int bias_gh, int bias_gw, const float* keymask, float* delta, void* dq, void* dk, void* dv, float* dbias, int nseq, int H, int L, int Lp, int D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* 1 when the second-generation cosine-attention kernels (csrc/attn2*.hip) serve the shape: bf16, d_head 32, L a multiple of 32 in [64, 1024]; with a position-bias table (has_bias) the grid gh x gw must equal L, gw % 8 == 0, (2gh-1)(2gw-1) <= 4096 classes.  attention.py:145-178. */
@@ -53,19 +53,19 @@ int ctclip_attn2_prep(const void* q, const void* k, const void* v, int64_t ldq, 
 /* softmax(q~ k^T + bias) v on head-planar operands (attention.py:162-178).  tab: the (nclass, H) f32 continuous-position-bias table of attention.py:257-276 (nclass = (2 bias_gh - 1)(2 bias_gw - 1)) or null; out (M, ldo) row-major bf16; lse2 [H][M] f32 log2-domain log-sum-exp for the backward. */
 int ctclip_attn2_fwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, void* out, int64_t ldo, float* lse2, int nseq, int H, int L, hipStream_t stream);
 
-/* bytes of workspace for ctclip_attn2_bwd: dO' / delta' planes passed from the query pass to the key pass, and (with a bias table) the per-workgroup dBias slabs and bins of the deterministic fold. */
+/* bytes of workspace for ctclip_attn2_bwd: dO' / delta' planes passed from the query pass to the key pass, and (with a bias table) the per-workgroup dBias slabs and bins of the deterministic fold. [workspace query of ctclip_attn2_bwd (autograd through attention.py:152-178)] */
 int64_t ctclip_attn2_bwd_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
 
-/* backward of ctclip_attn2_fwd: head-planar dq~, dk^, dv [H][M][32] bf16 (the l2norm / scale backward is ctclip_attn2_unprep) and, when dtab is non-null, the gradient of the position-bias table (nclass, H) f32, ACCUMULATED (+=) in a fixed summation order. */
+/* backward of ctclip_attn2_fwd: head-planar dq~, dk^, dv [H][M][32] bf16 (the l2norm / scale backward is ctclip_attn2_unprep) and, when dtab is non-null, the gradient of the position-bias table (nclass, H) f32, ACCUMULATED (+=) in a fixed summation order. [replaces autograd through attention.py:158-178 incl. the position-bias gradient of attention.py:257-276] */
 int ctclip_attn2_bwd(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, void* dqh, void* dkh, void* dvh, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* The position-bias table gradient of ctclip_attn2_bwd as a call of its own (the scatter-add of dBias over the (2h-1)(2w-1) offset classes that autograd performs through `ContinuousPositionBias`, attention.py:257-276): dtab (ncls, H) OVERWRITTEN.  `workspace` must be the SAME buffer (>= ctclip_attn2_bwd_workspace(nseq, H, L, bias_gh, bias_gw)) a preceding ctclip_attn2_bwd(..., dtab = NULL, ...) of the same problem was given: its first two regions hold dO' and delta' of the query pass.  The host runs this call on a side stream, under the rest of the layer's backward. */
 int ctclip_attn2_bwd_dbias(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const float* lse2, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* bytes of workspace ctclip_attn2_unprep needs for the partial sums of the q_scale / k_scale gradients. */
+/* bytes of workspace ctclip_attn2_unprep needs for the partial sums of the q_scale / k_scale gradients. [workspace query of ctclip_attn2_unprep (autograd through attention.py:152-156)] */
 int64_t ctclip_attn2_unprep_workspace(void);
 
-/* bytes of workspace ctclip_attn2_bwd_tok needs (ctclip_attn2_bwd's regions + the per-workgroup k_scale partials). */
+/* bytes of workspace ctclip_attn2_bwd_tok needs (ctclip_attn2_bwd's regions + the per-workgroup k_scale partials). [workspace query of ctclip_attn2_bwd_tok (autograd through attention.py:152-178)] */
 int64_t ctclip_attn2_bwd_tok_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
 
 /* ctclip_attn2_bwd (backward of the cosine attention, attention.py:145-178) with the k / v half of ctclip_attn2_unprep folded into the slab key pass: dqh head-planar as before, dk (M, lddk) / dv (M, lddv) ROW-MAJOR with the l2norm backward of k applied (kinv = the forward's inverse norms (M, H)), dk_scale (32) ACCUMULATED, dtab as in ctclip_attn2_bwd (NULL: ctclip_attn2_bwd_dbias later from the same workspace).  Follow with ctclip_attn2_unprep_q.  CTCLIP_EUNSUPPORTED when the slab kernels do not serve the shape. */
@@ -74,7 +74,7 @@ int ctclip_attn2_bwd_tok(const void* qh, const void* kh, const void* vh, const f
 /* the q half of ctclip_attn2_unprep: head-planar dq^ -> row-major dq (M, lddq) through the l2norm backward of q (attention.py:152); dq_scale (32) ACCUMULATED; workspace >= ctclip_attn2_unprep_workspace(). */
 int ctclip_attn2_unprep_q(const void* dqh, const void* qh, const float* qinv, const float* q_scale, float scale, void* dq, int64_t lddq, float* dq_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* backward of ctclip_attn2_prep: head-planar dq~, dk^, dv -> row-major dq (M, lddq), dk, dv bf16 through the l2norm backward; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=), summed in a fixed order. */
+/* backward of ctclip_attn2_prep: head-planar dq~, dk^, dv -> row-major dq (M, lddq), dk, dv bf16 through the l2norm backward; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=), summed in a fixed order. [replaces autograd through l2norm + the learned scales + the head split, attention.py:145-156] */
 int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* 1 when ctclip_attn_short_* serves the shape (bf16, d_head 32, 1 <= L <= 32 tokens per sequence, no bias, no mask): CTViT's temporal transformer (attention.py:145-178 on (b h w, t, d) sequences, ctvit.py:297-305). */
@@ -83,19 +83,19 @@ int ctclip_attn_short_supported(int L, int D, int dtype);
 /* out[(s L + i), h*32 + :] = softmax_j(scale * <l2norm(q_i) q_scale, l2norm(k_j) k_scale>) v_j for nseq sequences of L tokens, H heads (attention.py:145-178): q (nseq*L, ldq >= H*32), kv (nseq*L, ldkv >= 2*H*32) = [k | v], out (nseq*L, ldo) row-major bf16; q_scale, k_scale (32) f32.  One wave per (sequence, head); nothing is saved for the backward. */
 int ctclip_attn_short_fwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, void* out, int64_t ldo, int nseq, int H, int L, float scale, hipStream_t stream);
 
-/* bytes of workspace ctclip_attn_short_bwd needs (one 64-float row of learned-scale gradient partials per workgroup). */
+/* bytes of workspace ctclip_attn_short_bwd needs (one 64-float row of learned-scale gradient partials per workgroup). [workspace query of ctclip_attn_short_bwd (autograd through attention.py:145-178 in the temporal transformer, ctvit.py:205-206)] */
 int64_t ctclip_attn_short_bwd_workspace(int nseq, int H);
 
-/* backward of ctclip_attn_short_fwd from q, kv and dout alone (the 32 x 32 softmax is recomputed): dq (nseq*L, lddq), dkv (nseq*L, lddkv) = [dk | dv] bf16 are overwritten; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=) when non-null, in a fixed summation order. */
+/* backward of ctclip_attn_short_fwd from q, kv and dout alone (the 32 x 32 softmax is recomputed): dq (nseq*L, lddq), dkv (nseq*L, lddkv) = [dk | dv] bf16 are overwritten; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=) when non-null, in a fixed summation order. [replaces autograd through attention.py:145-178 in the temporal transformer (ctvit.py:205-206)] */
 int ctclip_attn_short_bwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, const void* dout, int64_t lddo, void* dq, int64_t lddq, void* dkv, int64_t lddkv, float* dq_scale, float* dk_scale, int nseq, int H, int L, float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* thread-local message of the last failing call. */
+/* thread-local message of the last failing call. [C-ABI plumbing: the reference has no FFI of its own, it raises Python exceptions] */
 const char* ctclip_last_error(void);
 
-/* ABI version (1). */
+/* ABI version (1). [C-ABI plumbing, no reference counterpart] */
 int ctclip_abi_version(void);
 
-/* "gfx950". */
+/* "gfx950".  [C-ABI plumbing, no reference counterpart] */
 const char* ctclip_target_arch(void);
 
 /* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
@@ -104,10 +104,10 @@ int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, in
 /* ctclip_peg_fwd (attention.py:63-84 + the residual of :324) on the compensated residual stream: s = x + e_in (may be NULL) + conv(x) + bias in f32, y = bf16(s), e_out = bf16(s - y).  bf16 grids the LDS-marching kernels serve; CTCLIP_EUNSUPPORTED otherwise. */
 int ctclip_peg_fwd_comp(const void* x, const float* w, const float* bias, const void* e_in, void* y, void* e_out, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_peg_bwd needs when dw is requested (per-workgroup partial weight gradients of the deterministic two-stage sum). */
+/* bytes of workspace ctclip_peg_bwd needs when dw is requested (per-workgroup partial weight gradients of the deterministic two-stage sum). [workspace query of ctclip_peg_bwd (autograd through attention.py:63-84,324)] */
 int64_t ctclip_peg_bwd_workspace(int64_t B, int D1, int D2, int C);
 
-/* backward of the above; dw (C,27) / db (C) ACCUMULATED (+=), may be NULL; with dw, `workspace` holds >= ctclip_peg_bwd_workspace bytes of per-workgroup partials (two-stage sum in a fixed order, no atomics). */
+/* backward of the above; dw (C,27) / db (C) ACCUMULATED (+=), may be NULL; with dw, `workspace` holds >= ctclip_peg_bwd_workspace bytes of per-workgroup partials (two-stage sum in a fixed order, no atomics). [replaces autograd through nn.Conv3d(groups=dim) + F.pad + the residual, attention.py:63-84,324] */
 int ctclip_peg_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int64_t B, int D1, int D2, int D3, int C, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ClassFine / CT-LiPro head (scripts/ct_lipro_train.py:33-36): out = relu(x) * dropout_mask / (1 - p) when dy is null, else the gradient dy * mask / (1 - p) * [x > 0]; f32, n % 4 == 0; the mask is Philox(seed, element, stream_id) as in ctclip_dropout. */
@@ -125,10 +125,10 @@ int ctclip_latent_similarity(const float* text, const float* image, const float*
 /* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
 int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* bytes of optional workspace for ctclip_gemm (split-K partial slabs); split_k <= 0 = auto. */
+/* bytes of optional workspace for ctclip_gemm (split-K partial slabs); split_k <= 0 = auto. [workspace query of ctclip_gemm (nn.Linear, attention.py:48,51,119,120,125)] */
 int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k);
 
-/* bytes of workspace ctclip_gemm_argmax needs. */
+/* bytes of workspace ctclip_gemm_argmax needs. [workspace query of ctclip_gemm_argmax (the code search of vector-quantize-pytorch called at ctvit.py:403)] */
 int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
 
 /* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
@@ -152,13 +152,13 @@ int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, co
 /* the q and k|v projections of the spatial attention with the operand layout of the attention kernels written by the GEMM (replaces nn.Linear at attention.py:141-143 + the head split / l2norm / learned scale of :145-154, i.e. nn.Linear + ctclip_attn2_prep): A (M, K) bf16, B (nsec * 256, K) bf16; per 256-column section s (8 heads x 32): inv_s != NULL -> out_s[h][m][d] = bf16(a_m . b_n) / max(|head row|, 1e-12) * scale_s[d] * mult_s, inv_s[m * 8 + h] = the inverse norm; inv_s == NULL -> head-planar copy (v).  CTCLIP_EUNSUPPORTED unless bf16, M % 256 == 0, K % 64 == 0, 1 <= nsec <= 3. */
 int ctclip_gemm_headnorm(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb, void* out0, float* inv0, const float* scale0, float mult0, void* out1, float* inv1, const float* scale1, float mult1, void* out2, float* inv2, const float* scale2, float mult2, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). */
+/* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). [workspace query of ctclip_visual_latent_fwd (to_visual_latent, ct_clip.py:549,771)] */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 
 /* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767); `workspace` >= ctclip_visual_latent_fwd_workspace bytes (split-K partials, fixed summation order). */
 int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
-/* backward of the above (dX and dW). */
+/* backward of the above (dX and dW). [replaces autograd through to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False), ct_clip.py:549,771] */
 int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K, int accumulate, int dtype, hipStream_t s);
 
 /* l2norm + logits*exp(temperature) + symmetric InfoNCE, forward and backward (ct_clip.py:771,796,845-901). */
@@ -170,61 +170,61 @@ int ctclip_clip_loss_logits(float* S, int64_t lds, const float* temperature, flo
 /* Backward of F.normalize on rows (ct_clip.py:49-50,771): out = inv * (du - u <u, du>) with u = raw * inv; all f32, (rows, cols) contiguous. */
 int ctclip_l2norm_bwd_rows(const float* raw, const float* inv, const float* du, float* out, int rows, int cols, hipStream_t s);
 
-/* dst[i] += src[i] over n f32 values (n % 4 == 0, 16-byte aligned): the row blocks of a stacked weight gradient (one GEMM over [x | gate]) added into the flat gradient buffer. */
+/* dst[i] += src[i] over n f32 values (n % 4 == 0, 16-byte aligned): the row blocks of a stacked weight gradient (one GEMM over [x | gate]) added into the flat gradient buffer. [replaces autograd gradient accumulation (AccumulateGrad) into param.grad under scripts/CTCLIPTrainer.py:259] */
 int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s);
 
-/* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). */
+/* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). [replaces the temperature multiply of ct_clip.py:786,805-807] */
 int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s);
 
 /* GEGLU: gelu(gate) * x (attention.py:39-42) on the padded [x | gate] layout. */
 int ctclip_geglu_fwd(const void* u, void* g, int64_t M, int Hp, int dtype, hipStream_t s);
 
-/* backward of GEGLU. */
+/* backward of GEGLU. [replaces autograd through GEGLU.forward, attention.py:39-43] */
 int ctclip_geglu_bwd(const void* dg, const void* u, void* du, int64_t M, int Hp, int dtype, hipStream_t s);
 
 /* erf-GELU (HF BertIntermediate). */
 int ctclip_gelu_fwd(const void* u, void* h, int64_t n, int dtype, hipStream_t s);
 
-/* backward of erf-GELU. */
+/* backward of erf-GELU. [replaces autograd through HF BertIntermediate GELU (gelu = erf form)] */
 int ctclip_gelu_bwd(const void* dh, const void* u, void* du, int64_t n, int dtype, hipStream_t s);
 
 /* nn.LeakyReLU(0.1) of ContinuousPositionBias (attention.py:19-20,247-250). */
 int ctclip_leaky_relu_fwd(const float* x, float* y, int64_t n, float slope, hipStream_t s);
 
-/* backward of LeakyReLU. */
+/* backward of LeakyReLU. [replaces autograd through nn.LeakyReLU(0.1) of ContinuousPositionBias, attention.py:247-252] */
 int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, float slope, hipStream_t s);
 
-/* bytes of workspace ctclip_colsum needs (per-row-block partial sums of the deterministic two-stage reduction). */
+/* bytes of workspace ctclip_colsum needs (per-row-block partial sums of the deterministic two-stage reduction). [workspace query of ctclip_colsum (bias gradients of nn.Linear: HF BERT dense layers, ctvit.py:173)] */
 int64_t ctclip_colsum_workspace(int64_t M, int N);
 
-/* bias gradients: out[n] += sum_m x[m][n]; `workspace` >= ctclip_colsum_workspace bytes (row-block partials, fixed summation order). */
+/* bias gradients: out[n] += sum_m x[m][n]; `workspace` >= ctclip_colsum_workspace bytes (row-block partials, fixed summation order). [replaces autograd of the bias of nn.Linear (HF BERT dense layers, ctvit.py:173, attention.py:247-252)] */
 int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 /* rearrange '(b t)(h w) d <-> (b h w) t d' between the spatial and temporal phases (ctvit.py:297-305). */
 int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, int dtype, hipStream_t s);
 
-/* y (C,R) = x (R,C)^T: transposed weight shadows for the grad-input GEMMs. */
+/* y (C,R) = x (R,C)^T: transposed weight shadows for the grad-input GEMMs. [builds the transposed weight operand of the grad-input GEMM of nn.Linear (attention.py:48,51,119,120,125)] */
 int ctclip_transpose2d(const void* x, void* y, int R, int C, int64_t ldx, int64_t ldy, int dtype, hipStream_t s);
 
 /* torch.mean(enc_image, dim=1) (ct_clip.py:724). */
 int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
 
-/* backward of the depth mean-pool. */
+/* backward of the depth mean-pool. [replaces autograd through torch.mean(enc_image, dim=1), ct_clip.py:724] */
 int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
 
-/* f32 master weight -> padded compute-dtype shadow (optionally scaled per column). */
+/* f32 master weight -> padded compute-dtype shadow (optionally scaled per column). [replaces tensor.to(dtype) casts around the latent projections (ct_clip.py:762-771) and gradient bucket staging (accelerate DDP, scripts/CTCLIPTrainer.py:138-140)] */
 int ctclip_convert_pad(const void* src, void* dst, const float* colscale, int64_t rows, int64_t cols, int64_t lds_, int64_t rows_dst, int64_t cols_dst, int64_t ldd, int src_dtype, int dst_dtype, hipStream_t s);
 
 /* ContinuousPositionBias: gather the per-offset MLP table to (heads, hw, hw) (attention.py:261-276). */
 int ctclip_cpb_expand(const float* tab, float* bias, int H, int gh, int gw, hipStream_t s);
 
-/* backward of the gather (deterministic segmented sum). */
+/* backward of the gather (deterministic segmented sum). [replaces autograd through the rel_pos_indices gather of ContinuousPositionBias.forward, attention.py:261-276] */
 int ctclip_cpb_reduce(const float* dbias, float* dtab, int H, int gh, int gw, hipStream_t s);
 
 /* nn.Dropout of HF BertEmbeddings / BertSelfOutput / BertOutput fused with the residual add that follows it (modeling_bert.py BertSelfOutput.forward): y = x * mask / (1 - p) (+ residual); the mask is Philox4x32-10(seed, element / 4, stream_id), so the backward re-applies the same call to dy. */
 int ctclip_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, int dtype, hipStream_t s);
 
-/* test helper: writes the 0 / 1 keep mask (nseq, H, L, L) u8 that ctclip_attn_fwd / bwd apply to the attention probabilities for (dropout_p, dropout_seed). */
+/* test helper: writes the 0 / 1 keep mask (nseq, H, L, L) u8 that ctclip_attn_fwd / bwd apply to the attention probabilities for (dropout_p, dropout_seed). [test helper: the attention-probability dropout mask of HF BertSelfAttention as the kernels draw it] */
 int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint64_t seed, hipStream_t s);
 
 /* HF BertEmbeddings: word + position + token_type(0) lookup. */
@@ -233,7 +233,7 @@ int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* po
 /* quantize = embed[ind] (vector_quantize_pytorch, ctvit.py:403). */
 int ctclip_vq_gather(const float* embed, const int64_t* idx, void* out, int64_t M, int d, int dtype, hipStream_t s);
 
-/* VQ EMA buffer update (decay 0.8) of cluster_size and embed. */
+/* VQ EMA buffer update (decay 0.8) of cluster_size and embed. [replaces the EMA codebook update of vector-quantize-pytorch (ema_inplace + laplace smoothing + l2norm) behind ctvit.py:403] */
 int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const float* esum, int C, int d, float decay, hipStream_t s);
 
 /* parameter-space epilogue of the patch-embedding backward (replaces the autograd of nn.LayerNorm(K) + nn.Linear(K, d), ctvit.py:172-173, with the LayerNorm affine folded into the GEMM): from G = dZ^T xhat (N x K) and dbp = colsum(dZ): dW (+)= G * gamma1 + dbp (x) beta1, dgamma1 (+)= sum_n W G, dbeta1 (+)= W^T dbp; all f32, fixed summation order. */
@@ -242,10 +242,10 @@ int ctclip_patch_embed_param_bwd(const float* G, const float* W, const float* ga
 /* F.layer_norm (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm). gamma/beta may be NULL. */
 int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. */
+/* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. [workspace query of ctclip_layernorm_bwd (autograd through F.layer_norm, attention.py:28-35,45)] */
 int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols);
 
-/* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. */
+/* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. [replaces autograd through F.layer_norm, attention.py:28-35,45,333, ctvit.py:172,174 and HF LayerNorm] */
 int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* CTViT.to_patch_emb[0:2]: Rearrange 'b c (t pt)(h p1)(w p2) -> b t h w (c pt p1 p2)' + LayerNorm statistics (ctvit.py:171-172). */
@@ -257,7 +257,7 @@ int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int col
 /* F.normalize rows as the three-term bf16 expansion the vector-quantiser code search multiplies on the matrix cores (vector_quantize_pytorch 1.1.2 CosineSimCodebook.forward computes the distances in f32): y (rows, 3 cols) bf16 = [hi | hi | lo] (order 0, tokens) or [hi | lo | hi] (order 1, codes) with hi = bf16(x^), lo = bf16(x^ - hi); inv (rows) f32 inverse norms or null. */
 int ctclip_l2norm_split3(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int order, hipStream_t stream);
 
-/* bytes of workspace ctclip_grad_norm_clip needs. */
+/* bytes of workspace ctclip_grad_norm_clip needs. [workspace query of ctclip_grad_norm_clip (accelerator.clip_grad_norm_, scripts/CTCLIPTrainer.py:259-260)] */
 int64_t ctclip_grad_norm_workspace(void);
 
 /* accelerator.clip_grad_norm_(params, 0.5) (CTCLIPTrainer.py:259-260): out = [norm, clip coefficient]. */
@@ -269,7 +269,7 @@ int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* scripts/data.py:92-162 (CTReportDataset.nii_img_to_tensor) without the file decode: src = the (H, W, D) voxel array as nibabel returns it (src_dtype 0 int16, 1 f32, 2 f64, device memory) -> HU = slope * v + intercept, trilinear resample to target_xy / target_z mm (F.interpolate align_corners=False, new size int(n * spacing / target)), clip to [hu_lo, hu_hi], / hu_div, centre crop / pad with pad_value -> out (out_d, out_h, out_w) f32 = (240, 480, 480). */
 int ctclip_preprocess_volume(const void* src, int src_dtype, int H, int W, int D, double slope, double intercept, double xy_spacing, double z_spacing, double target_xy, double target_z, float* out, int out_h, int out_w, int out_d, double hu_lo, double hu_hi, double hu_div, float pad_value, hipStream_t stream);
 
-/* bytes of workspace ctclip_segment_sum needs (row histogram, scan and the row order of each segment). */
+/* bytes of workspace ctclip_segment_sum needs (row histogram, scan and the row order of each segment). [workspace query of ctclip_segment_sum (EMA statistics of vector-quantize-pytorch behind ctvit.py:403; nn.Embedding backward of HF BertEmbeddings)] */
 int64_t ctclip_segment_sum_workspace(int64_t M, int nseg);
 
 /* out[key[r]] (+)= rowscale[r] * x[r, :d] summed in ascending row order per segment (deterministic scatter-add: the EMA statistics of the vector quantiser and the embedding-table gradients of HF BertEmbeddings).  keys (M) int64 or null (then key(r) = r % key_mod); x (M, ldx) f32 / bf16; rowscale (M) f32 or null; out (nseg, d) f32; counts_f (nseg) f32 row counts or null; accumulate 0 overwrites. */

@@ -117,3 +117,14 @@ def test_ctypes_signatures_agree_with_the_header():
         r = ret.replace("const ", "").strip()
         want = "ptr" if "*" in r else {"int": "i32", "int64_t": "i64", "void": "void"}[r]
         assert want == cls_of_ctypes(restype), (name, ret, restype)
+
+
+def test_every_entry_point_cites_what_it_replaces():
+    """include/ctclip_hip.h documents each entry point with the reference call it replaces: a file:line of the reference, or the third-party /
+    framework call behind such a line (HF BERT, vector-quantize-pytorch, torch / accelerate), or says that it is C-ABI plumbing."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "ctclip_hip.h")).read()
+    items = re.findall(r"/\* ([^\n]*?) \*/\n[^\n]*?(ctclip_\w+)\(", text)
+    assert len(items) >= 85
+    bad = [n for c, n in items if not re.search(r"\w+\.py:\d+|HF |vector.quantize|accelerate|no reference counterpart|no FFI of its own", c)]
+    assert not bad, bad
