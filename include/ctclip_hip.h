@@ -23,7 +23,7 @@ extern "C" {
 #endif
 typedef struct ihipStream_t* hipStream_t;
 
-/* per-(sequence, head) transposed copy [seq][h][d][Lp] used as MFMA A-operands by the attention kernels.  [replaces the rearrange 'b n (h d) -> b h n d' of attention.py:147-150 and HF BertSelfAttention.transpose_for_scores] */
+/* per-(sequence, head) transposed copy [seq][h][d][Lp] used as MFMA A-operands by the attention kernels.  [replaces the rearrange 'b n (h d) -> b h n d' of attention.py:145 and HF BertSelfAttention.transpose_for_scores] */
 int ctclip_head_transpose(const void* x, void* xt, int nseq, int H, int L, int Lp, int D, int64_t ldx, int dtype, hipStream_t stream);
 
 /* l2norm(q)*q_scale / l2norm(k)*k_scale per head (attention.py:152-154). */
@@ -173,7 +173,7 @@ int ctclip_l2norm_bwd_rows(const float* raw, const float* inv, const float* du, 
 /* dst[i] += src[i] over n f32 values (n % 4 == 0, 16-byte aligned): the row blocks of a stacked weight gradient (one GEMM over [x | gate]) added into the flat gradient buffer. [replaces autograd gradient accumulation (AccumulateGrad) into param.grad under scripts/CTCLIPTrainer.py:259] */
 int ctclip_accumulate_f32(float* dst, const float* src, int64_t n, hipStream_t s);
 
-/* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). [replaces the temperature multiply of ct_clip.py:786,805-807] */
+/* x *= scalar[0] (device scalar; scales the saved loss gradients by the upstream grad). [replaces the temperature multiply of ct_clip.py:796,805-807,845] */
 int ctclip_scale_by_scalar(float* x, const float* scalar, int64_t n, hipStream_t s);
 
 /* GEGLU: gelu(gate) * x (attention.py:39-42) on the padded [x | gate] layout. */
