@@ -1,6 +1,6 @@
 // Cosine-similarity attention (attention.py:145-178: l2norm(q) * q_scale, l2norm(k) * k_scale, sim * scale, softmax, @ v) for SHORT
 // sequences: L <= 32 tokens, d_head = 32, no bias, no mask, bf16 -- CTViT's temporal transformer (4608 sequences x 24 frames x 8 heads
-// per volume batch of 8; ctvit.py:205-206, attention.py:280-333).
+// per volume batch of 8; ctvit.py:187,303, attention.py:280-333).
 //
 // The general kernels spend this case on layout passes (qk-norm, head transposes, delta, a 128-key tile loop): 615 us per layer
 // forward + backward.  A whole (sequence, head) problem is ONE 32 x 32 MFMA tile, so here one wave owns one problem end to end:

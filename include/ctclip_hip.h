@@ -83,10 +83,10 @@ int ctclip_attn_short_supported(int L, int D, int dtype);
 /* out[(s L + i), h*32 + :] = softmax_j(scale * <l2norm(q_i) q_scale, l2norm(k_j) k_scale>) v_j for nseq sequences of L tokens, H heads (attention.py:145-178): q (nseq*L, ldq >= H*32), kv (nseq*L, ldkv >= 2*H*32) = [k | v], out (nseq*L, ldo) row-major bf16; q_scale, k_scale (32) f32.  One wave per (sequence, head); nothing is saved for the backward. */
 int ctclip_attn_short_fwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, void* out, int64_t ldo, int nseq, int H, int L, float scale, hipStream_t stream);
 
-/* bytes of workspace ctclip_attn_short_bwd needs (one 64-float row of learned-scale gradient partials per workgroup). [workspace query of ctclip_attn_short_bwd (autograd through attention.py:145-178 in the temporal transformer, ctvit.py:205-206)] */
+/* bytes of workspace ctclip_attn_short_bwd needs (one 64-float row of learned-scale gradient partials per workgroup). [workspace query of ctclip_attn_short_bwd (autograd through attention.py:145-178 in the temporal transformer, ctvit.py:187,303)] */
 int64_t ctclip_attn_short_bwd_workspace(int nseq, int H);
 
-/* backward of ctclip_attn_short_fwd from q, kv and dout alone (the 32 x 32 softmax is recomputed): dq (nseq*L, lddq), dkv (nseq*L, lddkv) = [dk | dv] bf16 are overwritten; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=) when non-null, in a fixed summation order. [replaces autograd through attention.py:145-178 in the temporal transformer (ctvit.py:205-206)] */
+/* backward of ctclip_attn_short_fwd from q, kv and dout alone (the 32 x 32 softmax is recomputed): dq (nseq*L, lddq), dkv (nseq*L, lddkv) = [dk | dv] bf16 are overwritten; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=) when non-null, in a fixed summation order. [replaces autograd through attention.py:145-178 in the temporal transformer (ctvit.py:187,303)] */
 int ctclip_attn_short_bwd(const void* q, int64_t ldq, const void* kv, int64_t ldkv, const float* q_scale, const float* k_scale, const void* dout, int64_t lddo, void* dq, int64_t lddq, void* dkv, int64_t lddkv, float* dq_scale, float* dk_scale, int nseq, int H, int L, float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* thread-local message of the last failing call. [C-ABI plumbing: the reference has no FFI of its own, it raises Python exceptions] */
@@ -242,10 +242,10 @@ int ctclip_patch_embed_param_bwd(const float* G, const float* W, const float* ga
 /* F.layer_norm (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm). gamma/beta may be NULL. */
 int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps, int dtype, hipStream_t stream);
 
-/* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. [workspace query of ctclip_layernorm_bwd (autograd through F.layer_norm, attention.py:28-35,45)] */
+/* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. [workspace query of ctclip_layernorm_bwd (autograd through F.layer_norm, attention.py:28-35,47)] */
 int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols);
 
-/* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. [replaces autograd through F.layer_norm, attention.py:28-35,45,333, ctvit.py:172,174 and HF LayerNorm] */
+/* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. [replaces autograd through F.layer_norm, attention.py:28-35,47,333, ctvit.py:172,174 and HF LayerNorm] */
 int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* CTViT.to_patch_emb[0:2]: Rearrange 'b c (t pt)(h p1)(w p2) -> b t h w (c pt p1 p2)' + LayerNorm statistics (ctvit.py:171-172). */
