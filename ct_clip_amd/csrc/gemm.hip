@@ -521,7 +521,7 @@ extern "C" int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, v
   return rc == 1 ? CTCLIP_EUNSUPPORTED : rc;
 }
 
-// A residual add of the transformer (attention.py:325,331: x + attn(x), x + ff(x)) on a COMPENSATED residual stream: the stream is the bf16
+// A residual add of the transformer (attention.py:326,331: x + attn(x), x + ff(x)) on a COMPENSATED residual stream: the stream is the bf16
 // pair (x, e), x what every consumer reads, e the rounding residue of the last add.  C (M, ldc) = bf16(s), E (M, ldc) = bf16(s - C) with
 // s = A B^T + residual + comp in f32; A (M, K), B (N, K) bf16 k-contiguous, residual / comp rows with stride ldr.
 // Replaces `x = out_proj(...) + x` where bf16 storage rounds x at every add: 72 roundings over 24 layers are the bf16 mode's error

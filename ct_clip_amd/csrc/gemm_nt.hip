@@ -796,7 +796,7 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
   return nt_launch(p, nontemporal, stream);
 }
 
-// out = A B^T + residual + comp, stored as the bf16 pair (C, E = the rounding residue): the residual adds of attention.py:325,331 on a
+// out = A B^T + residual + comp, stored as the bf16 pair (C, E = the rounding residue): the residual adds of attention.py:326,331 on a
 // compensated residual stream.  Whole 256-row tiles, N a multiple of 128.  Returns 1 when the shape is not eligible.
 int ctclip_gemm_nt_rescomp_try(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp,
                                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, hipStream_t stream) {

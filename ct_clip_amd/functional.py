@@ -583,7 +583,7 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 class LayerNormBranchFn(Function):
     """y = LayerNorm(x) together with `nviews` pass-through views of x for x's OTHER consumers (the residual connection,
-    the k/v projection of the raw tokens: attention.py:139-143, 324-325).  Routing those uses through this node lets the
+    the k/v projection of the raw tokens: attention.py:139-143, 324-326).  Routing those uses through this node lets the
     backward add their gradients inside the LayerNorm backward kernel (ctclip_layernorm_bwd add1/add2) instead of through
     autograd's elementwise accumulation kernels -- three passes over a 113-MB tensor each, 72 times per step."""
 

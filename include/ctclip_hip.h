@@ -146,7 +146,7 @@ int ctclip_gemm_geglu_bwd(const void* A, const void* B, const void* dG, void* dU
 /* Backward of the feed-forward block between FeedForward[4] and the GEGLU in ONE launch (replaces torch autograd through `Linear(inner, dim)` and `x * F.gelu(gate)`, attention.py:39-51): dU (M, lddu >= 2 hp) = [dg * gelu(gate) | dg * x * gelu'(gate)] where dg = dY W_out exists only in the accumulators (A = dY (M, K = model width) bf16, B = W_out^T (hp, ldb >= K), hidden feature j in row j) and U = [x | gate] (M, ldu >= 2 hp) is what ctclip_gemm_geglu stored.  No dg tensor, no ctclip_geglu_bwd pass.  CTCLIP_EUNSUPPORTED when the shape does not fill whole 256-row tiles / 128-column halves (caller: ctclip_gemm + ctclip_geglu_bwd). */
 int ctclip_gemm_dgeglu(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu, int64_t lddu, int dtype, hipStream_t stream);
 
-/* a residual add of the transformer (attention.py:325,331: `x = attn(x) + x`, `x = ff(x) + x`) on a COMPENSATED bf16 residual stream: s = A B^T + residual + comp in f32 (comp = the residue of `residual`), C = bf16(s), E = bf16(s - C) (the rounding residue the next add takes back in): replaces nn.Linear + the torch add, whose bf16 storage rounds the stream at every add.  bf16, M % 256 == 0, N % 128 == 0, K % 64 == 0; CTCLIP_EUNSUPPORTED otherwise. */
+/* a residual add of the transformer (attention.py:326,331: `x = attn(x) + x`, `x = ff(x) + x`) on a COMPENSATED bf16 residual stream: s = A B^T + residual + comp in f32 (comp = the residue of `residual`), C = bf16(s), E = bf16(s - C) (the rounding residue the next add takes back in): replaces nn.Linear + the torch add, whose bf16 storage rounds the stream at every add.  bf16, M % 256 == 0, N % 128 == 0, K % 64 == 0; CTCLIP_EUNSUPPORTED otherwise. */
 int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, const void* residual, const void* comp, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int dtype, hipStream_t stream);
 
 /* the q and k|v projections of the spatial attention with the operand layout of the attention kernels written by the GEMM (replaces nn.Linear at attention.py:141-143 + the head split / l2norm / learned scale of :145-154, i.e. nn.Linear + ctclip_attn2_prep): A (M, K) bf16, B (nsec * 256, K) bf16; per 256-column section s (8 heads x 32): inv_s != NULL -> out_s[h][m][d] = bf16(a_m . b_n) / max(|head row|, 1e-12) * scale_s[d] * mult_s, inv_s[m * 8 + h] = the inverse norm; inv_s == NULL -> head-planar copy (v).  CTCLIP_EUNSUPPORTED unless bf16, M % 256 == 0, K % 64 == 0, 1 <= nsec <= 3. */
