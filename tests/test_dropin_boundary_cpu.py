@@ -84,3 +84,32 @@ def test_run_train_calls_exist_and_inference_ctor_binds():
         for name, npos, kws in _calls(path, {"CTClipInference"}):
             inspect.signature(mod.CTClipInference.__init__).bind(None, *([object()] * npos), **{k: object() for k in kws})
         assert callable(mod.CTClipInference.infer)
+
+
+def test_every_file_line_citation_points_into_the_reference():
+    """Docstrings, kernel headers, include/ctclip_hip.h and the design documents cite the reference as file.py:LINE[-LINE]: every such citation
+    must name a file of the reference checkout and lines that exist in it (a citation that drifted past the end of its file is a dead pointer)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = {}
+    for path in glob.glob("/root/reference/**/*.py", recursive=True):
+        ref.setdefault(os.path.basename(path), []).append(len(open(path, errors="replace").read().split("\n")))
+    files = (glob.glob(os.path.join(root, "include", "*.h")) + glob.glob(os.path.join(root, "ct_clip_amd", "**", "*.py"), recursive=True)
+             + glob.glob(os.path.join(root, "ct_clip_amd", "csrc", "*")) + glob.glob(os.path.join(root, "oracle", "*.py"))
+             + glob.glob(os.path.join(root, "dropin", "**", "*.py"), recursive=True)
+             + [os.path.join(root, f) for f in ("DESIGN.md", "INTEGRATION.md", "README.md", "bench.py")])
+    n, bad = 0, []
+    for f in files:
+        text = open(f, errors="replace").read()
+        for m in re.finditer(r"([A-Za-z_]\w*\.py):(\d+(?:-\d+)?(?:,\s*\d+(?:-\d+)?)*)", text):
+            name = m.group(1)
+            if name not in ref:
+                if not os.path.exists(os.path.join(root, name)) and not glob.glob(os.path.join(root, "**", name), recursive=True):
+                    bad.append((os.path.relpath(f, root), m.group(0), "no such file in the reference"))
+                continue
+            for part in m.group(2).split(","):
+                n += 1
+                if int(part.strip().split("-")[-1]) > max(ref[name]):
+                    bad.append((os.path.relpath(f, root), f"{name}:{part.strip()}", f"file has {max(ref[name])} lines"))
+    assert n > 300 and not bad, bad[:10]
