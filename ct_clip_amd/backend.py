@@ -470,6 +470,26 @@ class HipBackend:
                                                   _p(wsu), wsu.numel(), _stream()), "ctclip_attn2_unprep_q")
         return dtab, (ws if defer_dtab else None)
 
+    def attn2_bwd_fused(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, qinv, kinv, dq, dk, dv, dq_scale, dk_scale, nseq, L,
+                        want_dtab):
+        """Backward of attn2_fwd in ONE pass over the score tiles (csrc/attn2_bwd1.hip): row-major dq / dk / dv with the l2norm backward applied,
+        dq_scale / dk_scale accumulated and the position-bias table gradient from the same sweep (fixed-point scatter, deterministic).
+        -> (dtab | None,) or None when the kernel does not serve the shape (caller: attn2_bwd_tok)."""
+        H, M, _ = qh.shape
+        gh, gw = bias_grid if tab is not None else (0, 0)
+        if not self.lib.ctclip_attn2_bwd_fused_supported(nseq, H, L, 32, gh, gw, int(tab is not None)):
+            return None
+        dtab = torch.empty_like(tab) if (want_dtab and tab is not None) else None
+        ws = self.workspace(qh.device, self.lib.ctclip_attn2_bwd_fused_workspace(nseq, H, L, gh, gw))
+        rc = self.lib.ctclip_attn2_bwd_fused(_p(qh), _p(kh), _p(vh), _p(tab), gh, gw, _p(q_scale), _p(k_scale), float(scale), _p(o), _rowmajor(o, "o"),
+                                             _p(dout), _rowmajor(dout, "dout"), _p(lse2), _p(qinv), _p(kinv), _p(dq), _rowmajor(dq, "dq"), _p(dk),
+                                             _rowmajor(dk, "dk"), _p(dv), _rowmajor(dv, "dv"), _p(dq_scale), _p(dk_scale), _p(dtab), nseq, H, L,
+                                             _p(ws), ws.numel(), _stream())
+        if rc == -2:      # CTCLIP_EUNSUPPORTED
+            return None
+        _lib.check(rc, "ctclip_attn2_bwd_fused")
+        return (dtab,)
+
     def attn2_bwd_dbias(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, lse2, nseq, L, ws):
         """The table gradient (ncls, H) from the workspace a deferred attn2_bwd left behind."""
         H = qh.shape[0]

@@ -1,0 +1,617 @@
+// ONE-PASS backward of the CTViT spatial cosine attention (attention.py:145-178 with the position bias of attention.py:257-276; bf16,
+// d_head 32, 256 <= L <= 576 tokens): dq, dk, dv (row-major, l2norm backward of attention.py:152-154 applied), the two learned-scale
+// gradients and the position-bias TABLE gradient from a single sweep over the score tiles.  Replaces the query pass + key pass + dBias
+// pass + dBias fold + q un-prep of attn2_slab.hip / attn2.hip (round 3: 178 + 238 + 273 + 68 + 35 us per layer), which computed
+// S, P = exp2(S), dP and dS three times per tile.
+//
+// Work decomposition.  One persistent workgroup of eight waves per CU walks a run of (sequence, head) items of ONE head.  Per item the
+// LDS holds the head-planar Q~ slab, the dO'' = K w dO slab (both L x 64 B, the swizzled 32-row tiles of attn2_common.h), -delta'' per
+// query, the f32 accumulators of dQ^T (L x 128 B, stored in MFMA accumulator order: [tile][register][lane]) and an integer class table
+// for the bias gradient.  The L/32 x L/32 score tiles are enumerated row-major, g = kb * nkb + t (key block kb, query tile t), and wave
+// w owns the contiguous positions [P w, P w + P): it keeps dK^T / dV^T of the current key block in registers and, per tile, computes
+//     S^T-oriented  s = Q~ K^^T + bias,  dp = dO'' V^T - delta''      (rows = queries in registers, lane = key)
+//     p = exp2(s), ds = p dp;   dV^T += dO''^T p,  dK^T += Q~^T ds   (transposing LDS reads, as the key pass did)
+//     dQ^T[t] += K^^T ds^T                                            (ds transposed through LDS: written row-major, read with
+//                                                                      ds_read_b64_tr_b16; the tile's own accumulator block is the scratch)
+//     table[class(q, k)] += round(ds)                                  (ds_add_u32, see below)
+// dQ^T[t] is a read-modify-write of LDS by whichever wave works on query tile t.  All waves advance one tile per STEP with one barrier
+// per step, and P is chosen so that P (w - w') != 0 (mod nkb): in every step the eight waves are on eight different query tiles, so the
+// updates never collide and every tile sees its addends in a FIXED order (deterministic; no floating-point atomic anywhere).  A key block
+// whose positions straddle two waves (7 of 18 at L = 576) has two partial dK^T / dV^T.  A wave PARKS its accumulators in global scratch
+// (L2) when it leaves a key block; after the last step the waves add the parts in a fixed order and apply the l2norm backward -- inside
+// the tile loop that epilogue cost 140 registers on top of a loop that needs all 256.
+//
+// Bias-table gradient.  ds_add_f32 costs 161 cycles per wave instruction on gfx950 (tools/ubench/lds_atomic_rates.hip), ds_add_u32 4 --
+// the same as a plain store.  So the scatter is done in FIXED POINT: per item a power of two K is chosen from the rigorous bound
+// |dS| <= 2 max_q |dO_q| max_k |v_k| such that |K dS| < 2^21, folded into dO'' (exact: every product of the item is scaled by K and
+// un-scaled by 1/K in the epilogues), and round(K dS) is obtained as the low bits of fma(p, dp, 1.5 * 2^23).  Integer addition is
+// associative: the table is bit-identical from run to run whatever the order in which the waves' atomics retire.  576 addends per class
+// and item stay below 2^31; the table is flushed (x 1/K, f32) into a per-workgroup partial after every item.
+//
+// The bias itself comes from a per-head f32 table in GLOBAL memory (8.8 KB: L1-resident), log2 e applied and the logit bound subtracted
+// by a one-workgroup-per-head stage kernel; a tile's 16 values per lane are requested one step ahead.  The LDS budget (160 KiB to the
+// byte in the slab kernels) has no room for a second table.
+#include "attn2_common.h"
+
+namespace {
+
+constexpr int NW1 = 8, NTH1 = NW1 * 64;
+constexpr int NPIECE = 5;                    // 16-byte pieces per thread and slab: 4 L <= NPIECE * NTH1
+constexpr float MAGIC = 12582912.f;          // 1.5 * 2^23: fma(x, y, MAGIC) has round(x y) in its low mantissa bits for |x y| < 2^22
+constexpr uint32_t MAGIC_BITS = 0x4B400000u;
+constexpr int FIX_BITS = 21;
+
+struct G1 {                                  // token -> class arithmetic (table row stride S = 2 gw - 1: the natural class index)
+  int gw, S, c0, magic, ncls, gh;
+  __device__ __forceinline__ int u(int t) const { const int r = (t * magic) >> 16; return r * S + (t - r * gw); }
+};
+
+struct X1 {                                  // arguments of the fused backward beyond ctclip_attn2::Params
+  const float* qinv; bf16_t* dq_tok; int64_t lddq;
+  float* qpart;                              // [nwg][32] q_scale gradient partials (kpart: Params)
+  const float* tabadj;                       // [H][ncls] staged table (log2 domain, bound subtracted when safe)
+  const float* hinfo;                        // [H][2]: m2, safe
+  float* dtpart;                             // [wph][H][ncls] table-gradient partials, or null
+  float* park;                               // [nwg][nkb][2][32][64] parked dK^T / dV^T accumulators (part 0 / 1 of a key block)
+  float* sacc;                               // [nwg][32][NTH1] per-thread partials of the k_scale / q_scale gradients across items
+  int P, ipw, wph;                           // positions per wave, items per workgroup, workgroups per head
+  unsigned long long* stamps;                // profiling aid (tools/bench_attn2_bwd.py): 100-MHz clock at the phase boundaries of workgroup 0, or null
+};
+
+__device__ __forceinline__ void unpack8u(const u32x4& a, float* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(a[i] << 16); v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u); }
+}
+// every LDS operation of this wave has completed, then the workgroup barrier; global loads stay in flight
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void put_rows(char* tile, int row, int half, const Frag& f) {
+  *reinterpret_cast<bf16x8*>(tile + swz(row, half)) = f.v[0];
+  *reinterpret_cast<bf16x8*>(tile + swz(row, 2 + half)) = f.v[1];
+}
+
+// per head: log2-domain table, the logit bound m2 and whether the bounded-logit softmax is safe (stage_srel of attn2_slab.hip)
+__global__ __launch_bounds__(256) void bwd1_stage_kernel(Params p, float* __restrict__ tabadj, float* __restrict__ hinfo, int ncls) {
+  __shared__ float red[2][4];
+  __shared__ float bc[2];
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY, mn = INFINITY;
+  if (p.tab) {
+    for (int i = tid; i < ncls; i += 256) { const float t = p.tab[(int64_t)i * p.H + h] * LOG2E; mx = fmaxf(mx, t); mn = fminf(mn, t); }
+  } else { mx = 0.f; mn = 0.f; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+  if (lane == 0) { red[0][wave] = mx; red[1][wave] = mn; }
+  __syncthreads();
+  if (wave == 0) {
+    float a = lane < 32 ? fabsf(p.q_scale[lane]) : fabsf(p.k_scale[lane - 32]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    const float qk = a * __shfl_xor(a, 32, 64) * p.c;
+    float tmx = -INFINITY, tmn = INFINITY;
+    for (int w = 0; w < 4; ++w) { tmx = fmaxf(tmx, red[0][w]); tmn = fminf(tmn, red[1][w]); }
+    if (lane == 0) {
+      const float span = 2.f * qk + (tmx - tmn);
+      const int safe = (span <= SAFE_SPAN && span == span) ? 1 : 0;
+      bc[0] = qk + tmx; bc[1] = (float)safe;
+      hinfo[2 * h] = qk + tmx; hinfo[2 * h + 1] = (float)safe;
+    }
+  }
+  __syncthreads();
+  const float sub = bc[1] != 0.f ? bc[0] : 0.f;
+  if (p.tab) {
+    for (int i = tid; i < ncls; i += 256) tabadj[(int64_t)h * ncls + i] = p.tab[(int64_t)i * p.H + h] * LOG2E - sub;
+  } else if (tid == 0) tabadj[(int64_t)h * ncls] = -sub;
+}
+
+template <bool TAB, bool DTAB, bool SAFE>
+__device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1& g, char* dyn) {
+  const int L = p.L, nkb = L / 32, NT = nkb * nkb;
+  char* qs = dyn;                                               // Q~ slab
+  char* dos = dyn + L * 64;                                     // dO'' slab
+  char* dqa = dyn + L * 128;                                    // dQ^T accumulators [tile][16][64] f32
+  float* nd = reinterpret_cast<float*>(dyn + L * 256);          // -delta''
+  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);  // class table (fixed point)
+  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));       // [64] reductions
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const TrOff tr = tr_offsets(lane);
+  const int h = (int)blockIdx.x / x.wph, wgh = (int)blockIdx.x % x.wph;
+  const int seq0 = wgh * x.ipw;
+  const float m2 = x.hinfo[2 * h];
+  constexpr bool safe = SAFE;
+  const float* tabh = x.tabadj + (int64_t)h * g.ncls;
+  if (DTAB) { for (int i = tid; i < g.ncls; i += NTH1) dtab[i] = 0u; }
+  const int g0 = x.P * wave;                                     // first position of this wave
+  const int kb0 = g0 / nkb, t0 = g0 - kb0 * nkb;
+  const bool has_work = g0 < NT;
+
+#define BWD1_STAMP(i) do { if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + (i)] = wall_clock64(); } while (0)
+  for (int it = 0; it < x.ipw; ++it) {
+    const int seq = seq0 + it;
+    BWD1_STAMP(0);
+    const int64_t so = ((int64_t)h * p.M + (int64_t)seq * L) * D;
+    const int64_t tok0 = (int64_t)seq * L;
+    auto load_kv = [&](Frag& k, Frag& v, int jb) {
+      const int64_t o2 = so + (int64_t)(jb * 32 + c) * D;
+      k = global_row(p.kh + o2, half); v = global_row(p.vh + o2, half);
+    };
+    // ------------------------------------------------------------------------------------------------ load phase
+    Frag kn, vn;
+    if (has_work) load_kv(kn, vn, kb0);
+    float K = 1.f, invK = 1.f;
+    {
+      u32x4 dpc[NPIECE];
+      float wrow[NPIECE], drow[NPIECE];
+      float mxd = 0.f, mxv = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k) {
+        const int pc = k * NTH1 + tid;
+        const bool ok = pc < 4 * L;
+        const int pcc = ok ? pc : 4 * L - 1, row = pcc >> 2, ch = pcc & 3;
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(p.qh + so + row * D + ch * 8);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(p.vh + so + row * D + ch * 8);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dout + (tok0 + row) * p.lddo + h * D + ch * 8);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.o + (tok0 + row) * p.ldo + h * D + ch * 8);
+        const float ls = p.lse2[(int64_t)h * p.M + tok0 + row];
+        if (ok) *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = qv;
+        float a[8], b[8], v8[8];
+        unpack8u(dv, a); unpack8u(ov, b); unpack8u(vv, v8);
+        float ds = 0.f, dn = 0.f, vnn = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ds += a[e] * b[e]; dn += a[e] * a[e]; vnn += v8[e] * v8[e]; }
+        ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
+        dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
+        vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
+        const float w = safe ? __builtin_amdgcn_exp2f(m2 - ls) : 1.f;
+        wrow[k] = w; drow[k] = ds * w; dpc[k] = dv;
+        if (ok) { mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn); }      // |dS| <= P 2 |dO_q| |v_k| with the TRUE probability P <= 1: no w here
+      }
+      BWD1_STAMP(1);
+      mxd = wave_max(mxd); mxv = wave_max(mxv);
+      if (lane == 0) { misc[wave] = mxd; misc[8 + wave] = mxv; }
+      // zero the dQ^T accumulators
+      for (int i = tid; i < L * 8; i += NTH1) *reinterpret_cast<u32x4*>(dqa + (int64_t)i * 16) = u32x4{0u, 0u, 0u, 0u};
+      __syncthreads();
+      float bd = 0.f, bv = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW1; ++w8) { bd = fmaxf(bd, misc[w8]); bv = fmaxf(bv, misc[8 + w8]); }
+      const float B = 2.f * sqrtf(bd) * sqrtf(bv);
+      if (B > 0.f && B < 3.0e38f) {
+        int e; (void)frexpf(B, &e);                              // B < 2^e
+        int kk = FIX_BITS - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
+        K = ldexpf(1.f, kk); invK = ldexpf(1.f, -kk);
+      }
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k) {
+        const int pc = k * NTH1 + tid;
+        if (pc < 4 * L) {
+          const int row = pc >> 2, ch = pc & 3;
+          float a[8];
+          unpack8u(dpc[k], a);
+          const float f = wrow[k] * K;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] *= f;
+          u32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = pack2bf(a[2 * e], a[2 * e + 1]);
+          *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = o4;
+          if (ch == 0) nd[row] = -(drow[k] * K);
+        }
+      }
+    }
+    __syncthreads();
+    BWD1_STAMP(2);
+    unsigned long long tbar = 0;
+
+    // ------------------------------------------------------------------------------------------------ tile steps
+    f32x16 dkacc, dvacc;
+    Frag kf, vf, ktf;
+    int kb = kb0, t = t0;
+    int ucol = 0;
+    bool need_ktf = false;
+    f32x16 cbn;
+    auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
+    auto bias_req = [&](f32x16& cb, int tt, int uc) {
+      if (TAB) {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          const float* b = tabh + class0(tt, gq, uc);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cb[8 * gq + e] = b[e];
+        }
+      } else {
+        const float tv = tabh[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cb[r] = tv;
+      }
+    };
+    if (has_work) bias_req(cbn, t0, g.u(kb0 * 32 + c));
+    for (int s = 0; s < x.P; ++s) {
+      const unsigned long long tb0 = x.stamps ? wall_clock64() : 0ull;
+      step_barrier();
+      if (x.stamps) tbar += wall_clock64() - tb0;
+      const int gpos = g0 + s;
+      if (gpos < NT) {
+        if (s == 0 || t == 0) {                                  // a new key block starts here
+          kf = kn; vf = vn;
+          ucol = g.u(kb * 32 + c);
+          need_ktf = true;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
+          const int last = (g0 + x.P < NT ? g0 + x.P : NT) - 1;  // last position of this wave
+          if ((kb + 1) * nkb <= last) load_kv(kn, vn, kb + 1);   // the next block of this wave, requested a block ahead
+        }
+        float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
+        f32x16 dqc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
+        asm volatile("" ::: "memory");                           // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
+        f32x16 cb = cbn;
+        const char* qtile = qs + t * TILE;
+        const char* dotile = dos + t * TILE;
+        const Frag qf = lds_rows(qtile, ar, half);
+        const Frag dof = lds_rows(dotile, ar, half);
+        f32x16 cdel;
+        {
+          const float* sp = nd + t * 32 + 8 * half;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sp + 16), b1 = *reinterpret_cast<const f32x4*>(sp + 20);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
+        }
+        if (!safe) {                                             // slow path: the queries' lse2 from global memory
+          const float* sp = p.lse2 + (int64_t)h * p.M + tok0 + t * 32 + 8 * half;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cb[e] -= sp[e]; cb[8 + e] -= sp[16 + e]; }
+        }
+        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[0], kf.v[0], cb, 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[0], vf.v[0], cdel, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[1], kf.v[1], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[1], vf.v[1], dp, 0, 0, 0);
+        const Frag dotf = lds_cols(dotile, tr);
+        const Frag qtf = lds_cols(qtile, tr);
+        float pr[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(sc[r]); ds[r] = pr[r] * dp[r]; }
+        if (DTAB) {
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            uint32_t* b = dtab + class0(t, gq, ucol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              (void)__hip_atomic_fetch_add(b + e, __float_as_uint(__builtin_fmaf(pr[8 * gq + e], dp[8 * gq + e], MAGIC)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        const Frag pf = pack(pr), dsf = pack(ds);
+        dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);
+        dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
+        dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
+        dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
+        char* scratch = reinterpret_cast<char*>(dqt);            // this wave owns query tile t in this step; its accumulators are in dqc
+        if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
+        put_rows(scratch, c, half, dsf);
+        const Frag dstf = lds_cols(scratch, tr);
+        dqc = mma(dqc, ktf, dstf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[r * 64 + lane] = dqc[r];
+        {                                                        // the next tile's bias (L1-resident table): requested at the END of the tile, when
+          int tn = t + 1, kbn = kb;                              // the tile's temporaries are dead, consumed after the next barrier
+          if (tn == nkb) { tn = 0; kbn = kb + 1; }
+          if (s + 1 < x.P && gpos + 1 < NT) bias_req(cbn, tn, g.u(kbn * 32 + c));
+        }
+
+        if (t == nkb - 1 || s == x.P - 1 || gpos == NT - 1) {   // this wave's tiles of the key block are done: park dK^T / dV^T (the
+          // l2norm backward and the stores run after the last step, where the registers of the tile loop are free).  part 1 = the block
+          // began in the previous wave's range
+          float* pk = x.park + ((((int64_t)blockIdx.x * nkb + kb) * 2 + (kb * nkb < g0 ? 1 : 0)) * 32) * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { pk[r * 64] = dkacc[r]; pk[(16 + r) * 64] = dvacc[r]; }
+        }
+        if (++t == nkb) { t = 0; ++kb; }
+      }
+    }
+    BWD1_STAMP(3);
+    wait_stores();                                               // the parked accumulators have reached L2 before any wave reads them back
+    __syncthreads();
+    BWD1_STAMP(4);
+    if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + 9] = tbar;
+
+    // ------------------------------------------------------------------------------------------------ dQ and dK / dV: un-prep in place
+    // (attn_unprep_kernel of attn2.hip: u = x^ / scale_vec, g = dx^ scale_vec, dx = inv (g - u (u . g)), dscale += dx^ u on the bf16-rounded
+    // planar gradient).  The scale-gradient partials of this thread live in global scratch between items (16 + 16 floats, [i][thread]).
+    {
+      float ksacc[16], qsacc[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ksacc[i] = 0.f; qsacc[i] = 0.f; }
+      const float scq = p.c * LN2 * invK;
+      for (int tq = wave; tq < nkb; tq += NW1) {
+        const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
+        const int qi = tq * 32 + ar;                             // lane n of the transposed product holds query pi32(n & 31)
+        const int64_t tok = tok0 + qi;
+        const float iq = x.qinv[tok * p.H + h];
+        const Frag qrow = lds_rows(qs + tq * TILE, ar, half);
+        float qx[16], dq[16];
+        unpack8u(__builtin_bit_cast(u32x4, qrow.v[0]), qx); unpack8u(__builtin_bit_cast(u32x4, qrow.v[1]), qx + 8);
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = 8 * gq + e;
+            const float qsv = p.q_scale[16 * gq + 8 * half + e];
+            const float qc = qsv * p.c;
+            const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
+            const float gq0 = bf2f(f2bf(dqt[i * 64 + lane] * scq));
+            const float uq = qx[i] * rq;
+            qsacc[i] += gq0 * uq;
+            const float gv = gq0 * qsv;
+            part[gq] += uq * gv;
+            qx[i] = uq; dq[i] = gv;
+          }
+        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+        bf16_t* dQ = x.dq_tok + tok * x.lddq + h * D;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          float a8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a8[e] = iq * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
+          store8(dQ + 16 * gq + 8 * half, a8);
+        }
+      }
+      BWD1_STAMP(5);
+      const float kmul = LN2 * invK;
+      for (int jb = wave; jb < nkb; jb += NW1) {
+        // the parked accumulators of key block jb: one part, or two when its positions straddle two waves (first part + second part, in that order)
+        const bool split = (jb * nkb) / x.P != (jb * nkb + nkb - 1) / x.P;
+        const float* pk = x.park + (((int64_t)blockIdx.x * nkb + jb) * 2 * 32) * 64 + lane;
+        float dka[16], dva[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dka[r] = __hip_atomic_load(pk + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dva[r] = __hip_atomic_load(pk + (16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (split) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            dka[r] += __hip_atomic_load(pk + (32 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dva[r] += __hip_atomic_load(pk + (48 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const int kj = jb * 32 + c;
+        const int64_t tok = tok0 + kj;
+        const float ik = p.kinv[tok * p.H + h];
+        const Frag krow = global_row(p.kh + so + (int64_t)kj * D, half);
+        float kx[16], dk[16];
+        unpack8u(__builtin_bit_cast(u32x4, krow.v[0]), kx); unpack8u(__builtin_bit_cast(u32x4, krow.v[1]), kx + 8);
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = 8 * gq + e;
+            const float ks = p.k_scale[16 * gq + 8 * half + e];
+            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+            const float gk0 = bf2f(f2bf(dka[i] * kmul));
+            const float uk = kx[i] * rk;
+            ksacc[i] += gk0 * uk;
+            const float gk = gk0 * ks;
+            part[gq] += uk * gk;
+            kx[i] = uk; dk[i] = gk;
+          }
+        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+        bf16_t* dK = p.dk_tok + tok * p.ldk_tok + h * D;
+        bf16_t* dV = p.dv_tok + tok * p.ldv_tok + h * D;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          float a8[8], b8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a8[e] = ik * (dk[8 * gq + e] - kx[8 * gq + e] * dot); b8[e] = dva[8 * gq + e] * invK; }
+          store8(dK + 16 * gq + 8 * half, a8);
+          store8(dV + 16 * gq + 8 * half, b8);
+        }
+      }
+      BWD1_STAMP(6);
+      float* sa = x.sacc + (int64_t)blockIdx.x * 32 * NTH1 + tid;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sa[i * NTH1] = it == 0 ? ksacc[i] : sa[i * NTH1] + ksacc[i];
+        sa[(16 + i) * NTH1] = it == 0 ? qsacc[i] : sa[(16 + i) * NTH1] + qsacc[i];
+      }
+    }
+    BWD1_STAMP(7);
+    // ------------------------------------------------------------------------------------------------ flush the class table
+    if (DTAB) {
+      const int W = 2 * g.gw - 1;
+      for (int i = tid; i < g.ncls; i += NTH1) {
+        const int dyi = i / W, dxi = i - dyi * W;
+        const int ady = dyi - (g.gh - 1), adx = dxi - (g.gw - 1);
+        const uint32_t cnt = (uint32_t)((g.gh - (ady < 0 ? -ady : ady)) * (g.gw - (adx < 0 ? -adx : adx)));
+        const int32_t v = (int32_t)(dtab[i] - cnt * MAGIC_BITS);
+        const float f = (float)v * invK;
+        float* dst = x.dtpart + ((int64_t)wgh * p.H + h) * g.ncls + i;
+        *dst = it == 0 ? f : *dst + f;
+        dtab[i] = 0u;
+      }
+    }
+    __syncthreads();
+    BWD1_STAMP(8);
+  }
+
+  // scale gradients of this workgroup, in a fixed order: the 32 lanes of a half by an xor tree, then the eight waves
+  float ksacc[16], qsacc[16];
+  {
+    const float* sa = x.sacc + (int64_t)blockIdx.x * 32 * NTH1 + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ksacc[i] = sa[i * NTH1]; qsacc[i] = sa[(16 + i) * NTH1]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { ksacc[i] += __shfl_xor(ksacc[i], o, 64); qsacc[i] += __shfl_xor(qsacc[i], o, 64); }
+  float* red = reinterpret_cast<float*>(qs);                     // [2][NW1][32]
+  if (c == 0) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[wave * 32 + 16 * gq + 8 * half + e] = ksacc[8 * gq + e];
+        red[NW1 * 32 + wave * 32 + 16 * gq + 8 * half + e] = qsacc[8 * gq + e];
+      }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, d = tid & 31;
+    float tsum = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < NW1; ++w8) tsum += red[which * NW1 * 32 + w8 * 32 + d];
+    (which ? x.qpart : p.kpart)[(int64_t)blockIdx.x * 32 + d] = tsum;
+  }
+}
+
+template <bool TAB, bool DTAB>
+__global__ __launch_bounds__(NTH1) void bwd1_kernel(Params p, X1 x, G1 g) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  // the bounded-logit softmax (no row maximum) when the head's logit span allows it, else the classical form: a workgroup-uniform choice
+  if (x.hinfo[2 * ((int)blockIdx.x / x.wph) + 1] != 0.f) bwd1_body<TAB, DTAB, true>(p, x, g, dyn);
+  else bwd1_body<TAB, DTAB, false>(p, x, g, dyn);
+}
+
+// part[nblk][32] -> dst (+=), two vectors per launch (blockIdx.x: 0 = k, 1 = q): 32 interleaved slices, then the slices in a fixed order
+__global__ __launch_bounds__(1024) void bwd1_scale_sum_kernel(const float* __restrict__ kpart, const float* __restrict__ qpart, int nblk,
+                                                              float* __restrict__ dks, float* __restrict__ dqs) {
+  __shared__ float red[32][32];
+  const float* part = blockIdx.x ? qpart : kpart;
+  float* dst = blockIdx.x ? dqs : dks;
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  float t = 0.f;
+  for (int b = sl; b < nblk; b += 32) t += part[(int64_t)b * 32 + o];
+  red[sl][o] = t;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a += red[i][o];
+    dst[o] += a;
+  }
+}
+// dtpart[wph][H][ncls] -> dtab (ncls, H), overwritten; workgroup partials in index order
+__global__ __launch_bounds__(256) void bwd1_dtab_sum_kernel(const float* __restrict__ part, int wph, float* __restrict__ dtab, int H, int ncls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncls * H) return;
+  const int cls = i / H, h = i % H;
+  float t = 0.f;
+  for (int b = 0; b < wph; ++b) t += part[((int64_t)b * H + h) * ncls + cls];
+  dtab[i] = t;
+}
+
+int ncus1() {
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+  return ncu;
+}
+inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct Plan1 { G1 g; int P, ipw, wph, nwg, ncls; size_t shm; };
+bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
+  const char* e = getenv("CTCLIP_ATTN_BWD1");
+  if (e && e[0] == '0') return false;
+  if (L % 32 || L < 256 || 4 * L > NPIECE * NTH1 || nseq <= 0 || H <= 0) return false;
+  const int nkb = L / 32, NT = nkb * nkb;
+  pl.ncls = 1;
+  pl.g = G1{1, 1, 0, 65536, 1, 1};
+  if (tab) {
+    if (gh * gw != L || gw % 8 || gw > 64) return false;
+    const int S = 2 * gw - 1;
+    pl.ncls = (2 * gh - 1) * S;
+    pl.g = G1{gw, S, (gh - 1) * S + (gw - 1), (65536 + gw - 1) / gw, pl.ncls, gh};
+  }
+  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256;
+  if (pl.shm > 160 * 1024) return false;
+  int P = (NT + NW1 - 1) / NW1;
+  if (P < nkb) P = nkb;
+  for (;; ++P) {
+    bool ok = true;
+    for (int d = 1; d < NW1; ++d) ok = ok && (P * d) % nkb != 0;
+    if (ok) break;
+  }
+  pl.P = P;
+  const int ncu = ncus1(), total = nseq * H;
+  int ipw = (total + ncu - 1) / ncu;
+  while (nseq % ipw) ++ipw;                                     // a workgroup stays inside one head
+  pl.ipw = ipw; pl.wph = nseq / ipw; pl.nwg = pl.wph * H;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int ctclip_attn2_bwd_fused_supported(int nseq, int H, int L, int D_, int bias_gh, int bias_gw, int has_bias) {
+  Plan1 pl;
+  return D_ == D && plan1(nseq, H, L, bias_gh, bias_gw, has_bias != 0, pl) ? 1 : 0;
+}
+extern "C" int64_t ctclip_attn2_bwd_fused_workspace(int nseq, int H, int L, int bias_gh, int bias_gw) {
+  Plan1 pl;
+  if (!plan1(nseq, H, L, bias_gh, bias_gw, bias_gh > 0, pl)) return 0;
+  return a256((int64_t)H * pl.ncls * 4) + a256(H * 2 * 4) + a256((int64_t)pl.wph * H * pl.ncls * 4) + 2 * a256((int64_t)pl.nwg * 32 * 4) +
+         a256((int64_t)pl.nwg * (L / 32) * 2 * 32 * 64 * 4) + a256((int64_t)pl.nwg * 32 * NTH1 * 4) + 4096;
+}
+
+// Backward of ctclip_attn2_fwd in ONE pass over the score tiles (attention.py:145-178 differentiated; the l2norm / learned-scale backward of
+// attention.py:152-154 and the position-bias table gradient of attention.py:257-276 included): row-major dq (M, lddq), dk (M, lddk), dv (M, lddv)
+// w.r.t. the projections q, k, v; dq_scale / dk_scale (32) ACCUMULATED; dtab (ncls, H) OVERWRITTEN when non-null.  qh / kh / vh: the head-planar
+// operands of ctclip_attn2_prep (or ctclip_gemm_headnorm), qinv / kinv (M, H) their inverse norms, o / dout (M, ldo / lddo), lse2 [H][M] of the
+// forward.  Deterministic (no floating-point atomics; the table gradient is accumulated in fixed point, see the file header).
+// CTCLIP_EUNSUPPORTED when the shape is not served (ctclip_attn2_bwd_fused_supported): callers fall back to ctclip_attn2_bwd_tok.
+extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale,
+                                      const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2,
+                                      const float* qinv, const float* kinv, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                      float* dq_scale, float* dk_scale, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes,
+                                      hipStream_t stream) {
+  if (!qh || !kh || !vh || !o || !dout || !lse2 || !qinv || !kinv || !dq || !dk || !dv || !dq_scale || !dk_scale || !q_scale || !k_scale || ldo % 8 ||
+      lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) { ctclip_set_error("attn2_bwd_fused: bad args"); return CTCLIP_EBADARG; }
+  if (dtab && !tab) { ctclip_set_error("attn2_bwd_fused: dtab without a table"); return CTCLIP_EBADARG; }
+  Plan1 pl;
+  if (!plan1(nseq, H, L, bias_gh, bias_gw, tab != nullptr, pl)) return CTCLIP_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < ctclip_attn2_bwd_fused_workspace(nseq, H, L, tab ? bias_gh : 0, bias_gw)) { ctclip_set_error("attn2_bwd_fused: workspace too small"); return CTCLIP_EWORKSPACE; }
+  const int64_t M = (int64_t)nseq * L;
+  Params p{};
+  p.qh = (const bf16_t*)qh; p.kh = (const bf16_t*)kh; p.vh = (const bf16_t*)vh; p.tab = tab; p.q_scale = q_scale; p.k_scale = k_scale;
+  p.gh = bias_gh; p.gw = bias_gw; p.H = H; p.L = L; p.nseq = nseq; p.M = M; p.c = scale * LOG2E;
+  p.o = (const bf16_t*)o; p.ldo = ldo; p.dout = (const bf16_t*)dout; p.lddo = lddo; p.lse2 = const_cast<float*>(lse2);
+  p.dk_tok = (bf16_t*)dk; p.dv_tok = (bf16_t*)dv; p.ldk_tok = lddk; p.ldv_tok = lddv; p.kinv = kinv;
+  char* w = (char*)workspace;
+  float* tabadj = (float*)w; w += a256((int64_t)H * pl.ncls * 4);
+  float* hinfo = (float*)w; w += a256(H * 2 * 4);
+  float* dtpart = (float*)w; w += a256((int64_t)pl.wph * H * pl.ncls * 4);
+  p.kpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
+  float* qpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
+  float* park = (float*)w; w += a256((int64_t)pl.nwg * (L / 32) * 2 * 32 * 64 * 4);
+  float* sacc = (float*)w; w += a256((int64_t)pl.nwg * 32 * NTH1 * 4);
+  static const bool stamp = getenv("CTCLIP_BWD1_STAMPS") != nullptr;          // the last 4 KB of the workspace: phase clocks of workgroup 0
+  X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, hinfo, dtab ? dtpart : nullptr, park, sacc, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
+  hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, hinfo, pl.ncls);
+  int rc = ctclip_check_launch("attn2_bwd_fused (stage)");
+  if (rc) return rc;
+  static bool raised = false;
+  if (!raised) {
+    bool ok = true;
+    ok = ok && hipFuncSetAttribute((const void*)bwd1_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)bwd1_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)bwd1_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) { ctclip_set_error("attn2_bwd_fused: cannot raise the LDS limit"); return CTCLIP_EBADARG; }
+    raised = true;
+  }
+  const dim3 grid((unsigned)pl.nwg), block(NTH1);
+  if (tab && dtab) hipLaunchKernelGGL((bwd1_kernel<true, true>), grid, block, pl.shm, stream, p, x, pl.g);
+  else if (tab) hipLaunchKernelGGL((bwd1_kernel<true, false>), grid, block, pl.shm, stream, p, x, pl.g);
+  else hipLaunchKernelGGL((bwd1_kernel<false, false>), grid, block, pl.shm, stream, p, x, pl.g);
+  rc = ctclip_check_launch("attn2_bwd_fused");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd1_scale_sum_kernel, dim3(2), dim3(1024), 0, stream, (const float*)p.kpart, (const float*)qpart, pl.nwg, dk_scale, dq_scale);
+  rc = ctclip_check_launch("attn2_bwd_fused (scale sums)");
+  if (rc || !dtab) return rc;
+  hipLaunchKernelGGL(bwd1_dtab_sum_kernel, dim3((unsigned)cdiv((int64_t)pl.ncls * H, 256)), dim3(256), 0, stream, (const float*)dtpart, pl.wph, dtab, H, pl.ncls);
+  return ctclip_check_launch("attn2_bwd_fused (table sum)");
+}

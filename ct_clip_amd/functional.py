@@ -853,8 +853,25 @@ def _attn2_backward(ctx, do, qh, kh, vh, qinv, kinv, o, lse2, tab, need_dtab):
     dqs = qs_sink if qs_sink is not None else torch.zeros_like(q_scale)
     dks = ks_sink if ks_sink is not None else torch.zeros_like(k_scale)
     want_dtab = has_tab and need_dtab
-    side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
     tabk = tab if has_tab else None
+    # One pass over the score tiles (csrc/attn2_bwd1.hip): dq / dk / dv, both scale gradients AND the table gradient.  The layers that share
+    # the table add theirs up in backward order; the first layer hands the sum to autograd.
+    one = be.attn2_bwd_fused(qh, kh, vh, tabk, bias_grid, qs, ks, scale, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L,
+                             want_dtab)
+    if one is not None:
+        dtab = one[0]
+        st = ctx.tab_users
+        if st is not None:
+            if dtab is not None:
+                if st["acc"] is None:
+                    st["acc"] = dtab
+                else:
+                    be.accumulate(st["acc"], dtab)
+                dtab = None
+            if ctx.tab_index == 0:
+                dtab, st["acc"], st["n"] = st["acc"], None, 0
+        return dq, dkv, (None if qs_sink is not None else dqs), (None if ks_sink is not None else dks), dtab
+    side = _wgrad_side(do) if (want_dtab and ctx.tab_users is not None) else None
     fused = None
     if os.environ.get("CTCLIP_ATTN_FUSED_UNPREP", "1") != "0":
         fused = be.attn2_bwd_tok(qh, kh, vh, tabk, bias_grid, qs, ks, scale, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L,

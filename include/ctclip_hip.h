@@ -77,6 +77,15 @@ int ctclip_attn2_unprep_q(const void* dqh, const void* qh, const float* qinv, co
 /* backward of ctclip_attn2_prep: head-planar dq~, dk^, dv -> row-major dq (M, lddq), dk, dv bf16 through the l2norm backward; dq_scale, dk_scale (32) f32 are ACCUMULATED (+=), summed in a fixed order. [replaces autograd through l2norm + the learned scales + the head split, attention.py:145-156] */
 int ctclip_attn2_unprep(const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh, const float* qinv, const float* kinv, const float* q_scale, const float* k_scale, float scale, void* dq, void* dk, void* dv, int64_t lddq, int64_t lddk, int64_t lddv, float* dq_scale, float* dk_scale, int64_t M, int H, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* 1 when ctclip_attn2_bwd_fused serves the shape: bf16, d_head 32, L % 32 == 0, 256 <= L <= 576 (the one-pass kernel keeps Q~, dO'', the f32 dQ accumulators and the class table of one (sequence, head) in 160 KiB of LDS); with a bias table gw % 8 == 0. [capability query; attention.py:145-178] */
+int ctclip_attn2_bwd_fused_supported(int nseq, int H, int L, int D_, int bias_gh, int bias_gw, int has_bias);
+
+/* bytes of workspace ctclip_attn2_bwd_fused needs (staged table, per-workgroup table / scale partials, parked key-block accumulators); 0 when the shape is not served. [workspace query of ctclip_attn2_bwd_fused (autograd through attention.py:152-178)] */
+int64_t ctclip_attn2_bwd_fused_workspace(int nseq, int H, int L, int bias_gh, int bias_gw);
+
+/* Backward of ctclip_attn2_fwd in ONE pass over the score tiles: row-major dq (M, lddq), dk (M, lddk), dv (M, lddv) w.r.t. the projections (l2norm / learned-scale backward applied), dq_scale / dk_scale (32) ACCUMULATED, dtab (ncls, H) OVERWRITTEN when non-null (fixed-point scatter: deterministic). qh / kh / vh head-planar operands and qinv / kinv (M, H) of ctclip_attn2_prep or ctclip_gemm_headnorm; o / dout (M, ldo / lddo); lse2 [H][M]. CTCLIP_EUNSUPPORTED when the shape is not served (then ctclip_attn2_bwd_tok). [torch autograd through F.normalize, q_scale / k_scale, einsum('b h i d, b h j d'), + attn_bias, softmax, einsum('b h i j, b h j d') of attention.py:152-178, and the gather of the bias table attention.py:257-276] */
+int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void* vh, const float* tab, int bias_gh, int bias_gw, const float* q_scale, const float* k_scale, float scale, const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse2, const float* qinv, const float* kinv, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, float* dq_scale, float* dk_scale, float* dtab, int nseq, int H, int L, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* 1 when ctclip_attn_short_* serves the shape (bf16, d_head 32, 1 <= L <= 32 tokens per sequence, no bias, no mask): CTViT's temporal transformer (attention.py:145-178 on (b h w, t, d) sequences, ctvit.py:297-305). */
 int ctclip_attn_short_supported(int L, int D, int dtype);
 

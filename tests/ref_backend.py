@@ -118,6 +118,12 @@ class RefBackend:
         self.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale)
         return dtab, ws
 
+    def attn2_bwd_fused(self, qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, qinv, kinv, dq, dk, dv, dq_scale, dk_scale, nseq, L,
+                        want_dtab):
+        dqh, dkh, dvh, dtab = self.attn2_bwd(qh, kh, vh, tab, bias_grid, q_scale, k_scale, scale, o, dout, lse2, nseq, L, want_dtab)
+        self.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, q_scale, k_scale, scale, dq, dk, dv, dq_scale, dk_scale)
+        return (dtab,)
+
     def gemm_headnorm(self, a, b, sections):
         M, K = a.shape
         nsec = len(sections)

@@ -670,6 +670,67 @@ def test_attn2_bwd_tok_equals_bwd_plus_unprep(hip, ref, nseq, H, gh, gw, gain, w
     assert torch.equal(dkv, dkv2) and torch.equal(dks, dks2) and torch.equal(dqs, dqs2)      # no atomics: bit-reproducible
 
 
+@pytest.mark.parametrize("nseq,H,gh,gw,gain,with_tab,want_dtab", [(70, 8, 24, 24, 1.0, True, True), (6, 8, 24, 24, 4.0, True, True), (33, 4, 16, 16, 1.0, False, False),
+                                                                   (5, 2, 16, 24, 1.0, True, True), (24, 8, 24, 24, 1.0, True, False), (3, 8, 16, 32, 1.0, True, True)])
+def test_attn2_bwd_fused_one_pass(hip, ref, nseq, H, gh, gw, gain, with_tab, want_dtab):
+    """ctclip_attn2_bwd_fused (csrc/attn2_bwd1.hip: dq, dk, dv, both scale gradients and the bias-table gradient from ONE sweep over the score
+    tiles) against (a) the f32 checker and (b) the three-pass path it replaces (ctclip_attn2_bwd + ctclip_attn2_unprep).  dv is the same sum in
+    the same order -> bit for bit when the key block is not split between two waves; dq / dk are f32 sums in another order -> one bf16 ulp on few
+    elements; the table gradient is a fixed-point sum (2^-21 of the item's bound per addend).  Twice: bit-reproducible.  Cases: 70 x 8 items on
+    256 CUs (persistent runs of 3 items), the unbounded-logit path (gain 4), no table (16 x 16), L = 384 (nkb = 12) and L = 512 (nkb = 16: the
+    position stride P is not the plain quotient), no table gradient wanted."""
+    L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, gain, with_tab, seed=70)
+    HD, bf = H * D, torch.bfloat16
+    grid = (gh, gw) if with_tab else None
+    qh, kh, vh, qinv, kinv = hip.attn2_prep(q, kv[:, :HD], kv[:, HD:], qs, ks, 8.0, H)
+    o, lse2 = hip.attn2_fwd(qh, kh, vh, tab, grid, qs, ks, 8.0, nseq, L)
+    do = rnd(M, HD, dtype=bf, seed=9) * 1e-3                                           # gradients are small numbers: the fixed-point scale must adapt
+    outs = []
+    for be in (hip, ref):
+        dq, dkv = torch.full((M, HD), float("nan"), dtype=bf, device=DEV), torch.full((M, 2 * HD), float("nan"), dtype=bf, device=DEV)
+        dqs, dks = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+        res = be.attn2_bwd_fused(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, want_dtab)
+        assert res is not None
+        outs.append((dq, dkv, dqs, dks, res[0]))
+    (dq, dkv, dqs, dks, dtab), (rq, rkv, rqs, rks, rtab) = outs
+    for name, a, b in (("dq", dq, rq), ("dk", dkv[:, :HD], rkv[:, :HD]), ("dv", dkv[:, HD:], rkv[:, HD:])):
+        assert torch.isfinite(a.float()).all(), name
+        err = (a.float() - b.float()).norm() / b.float().norm()
+        assert err < 2e-2, (name, float(err))
+    close(dqs, rqs, rtol=2e-2, atol=2e-2 * float((rqs - 1).abs().max())); close(dks, rks, rtol=2e-2, atol=2e-2 * float((rks - 1).abs().max()))
+    if want_dtab:
+        err = (dtab - rtab).norm() / rtab.norm()
+        assert err < 1e-2, float(err)
+    else:
+        assert dtab is None
+    # (b) the three-pass path on the same operands
+    dqh, dkh, dvh, dtab0 = hip.attn2_bwd(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, nseq, L, want_dtab)
+    dq0, dkv0 = torch.empty(M, HD, dtype=bf, device=DEV), torch.empty(M, 2 * HD, dtype=bf, device=DEV)
+    dqs0, dks0 = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    hip.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, 8.0, dq0, dkv0[:, :HD], dkv0[:, HD:], dqs0, dks0)
+    for name, a, b in (("dq", dq, dq0), ("dk", dkv[:, :HD], dkv0[:, :HD]), ("dv", dkv[:, HD:], dkv0[:, HD:])):
+        close(a, b, rtol=2 ** -6, atol=2e-3 * float(b.float().abs().max()) + 1e-30)
+        assert float((a != b).float().mean()) < 0.08, name                          # another summation order: a bf16 ulp here and there
+    close(dqs, dqs0, rtol=1e-3, atol=1e-3 * float((dqs0 - 1).abs().max())); close(dks, dks0, rtol=1e-3, atol=1e-3 * float((dks0 - 1).abs().max()))
+    if want_dtab:
+        err = (dtab - dtab0).norm() / dtab0.norm()
+        assert err < 2e-3, float(err)
+    # bit-reproducible (integer scatter, fixed summation orders)
+    dq2, dkv2, dqs2, dks2 = torch.empty_like(dq), torch.empty_like(dkv), torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    res2 = hip.attn2_bwd_fused(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, qinv, kinv, dq2, dkv2[:, :HD], dkv2[:, HD:], dqs2, dks2, nseq, L, want_dtab)
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2) and torch.equal(dks, dks2) and torch.equal(dqs, dqs2)
+    if want_dtab:
+        assert torch.equal(dtab, res2[0])
+
+
+def test_attn2_bwd_fused_declines_small_and_large_shapes(hip):
+    """L < 256 (fewer than eight key blocks: the waves could not be on eight different query tiles) and L > 576 (LDS) go to the three-pass path."""
+    for gh, gw in ((8, 8), (8, 16), (32, 32)):
+        assert not hip.lib.ctclip_attn2_bwd_fused_supported(4, 8, gh * gw, 32, gh, gw, 1)
+    assert hip.lib.ctclip_attn2_bwd_fused_supported(4, 8, 576, 32, 24, 24, 1)
+    assert not hip.lib.ctclip_attn2_bwd_fused_supported(4, 8, 576, 64, 24, 24, 1)
+
+
 def test_attn2_fwd_persistent_runs_across_items_and_heads(hip, ref):
     """The slab-resident forward keeps one workgroup per CU on a run of (head, sequence) items: more items than CUs, and a run
     that crosses a head boundary (the bias table is re-staged)."""
