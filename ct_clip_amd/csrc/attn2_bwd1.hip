@@ -51,9 +51,8 @@ struct X1 {                                  // arguments of the fused backward 
   float* qpart;                              // [nwg][32] q_scale gradient partials (kpart: Params)
   const float* tabadj;                       // [H][ncls] staged table (log2 domain, bound subtracted when safe)
   const float* hinfo;                        // [H][2]: m2, safe
-  float* dtpart;                             // [wph][H][ncls] table-gradient partials, or null
-  float* park;                               // [nwg][nkb][2][32][64] parked dK^T / dV^T accumulators (part 0 / 1 of a key block)
-  float* sacc;                               // [nwg][32][NTH1] per-thread partials of the k_scale / q_scale gradients across items
+  float* dtpart;                             // [nseq][H][ncls] table-gradient partials, one per (workgroup, item), or null
+  float* park;                               // [nwg][NW1][64][32] a wave's parked dK^T / dV^T accumulators (second part of a split key block)
   int P, ipw, wph;                           // positions per wave, items per workgroup, workgroups per head
   unsigned long long* stamps;                // profiling aid (tools/bench_attn2_bwd.py): 100-MHz clock at the phase boundaries of workgroup 0, or null
 };
@@ -64,6 +63,13 @@ __device__ __forceinline__ void unpack8u(const u32x4& a, float* v) {
 }
 // every LDS operation of this wave has completed, then the workgroup barrier; global loads stay in flight
 __device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// one dword of LDS, read now / written in program order (asm: a volatile generic pointer becomes a FLAT access that drains vmcnt)
+__device__ __forceinline__ int lds_peek(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_poke(uint32_t addr, int v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void put_rows(char* tile, int row, int half, const Frag& f) {
   *reinterpret_cast<bf16x8*>(tile + swz(row, half)) = f.v[0];
@@ -104,28 +110,316 @@ __global__ __launch_bounds__(256) void bwd1_stage_kernel(Params p, float* __rest
   } else if (tid == 0) tabadj[(int64_t)h * ncls] = -sub;
 }
 
+template <class T>
+__device__ __forceinline__ T* uni(T* ptr) {                     // a wave-uniform pointer that arrived in vector registers (a function argument)
+  const uint64_t v = (uint64_t)ptr;
+  return (T*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+__device__ __forceinline__ float uni(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+
+struct StepArgs {
+  const bf16_t *k, *v;                       // the item's K^ / V slabs (head-planar)
+  const float* lse;                          // its lse2 at this head (only read on the unbounded-logit path)
+  const float* tabh;                         // the head's staged table
+  const float *kinv, *k_scale;               // inverse norms at (row 0, this head); learned scale
+  bf16_t *dk, *dv; int64_t ldk, ldv;         // row 0 at this head of the two outputs
+  float* park;                               // this workgroup's parked accumulators [NW1][64][32]
+  const bf16_t *nq, *nv, *nk, *ndout, *no;   // the NEXT item's load-phase operands (touched line by line; this item's when there is none)
+  const float* nlse; int64_t lddo, ldo;
+  float invK; int H, L, P;
+  G1 g;
+  unsigned long long* wstamp;                // profiling aid: spin time of wave 0 (100-MHz ticks), or null
+};
+
+// The tile steps of one item (see the file header): a call, so that the loop has the whole register file to itself -- inlined into the kernel
+// it shared an allocation with the load phase (twenty 16-byte loads in flight per thread) and the un-prep arithmetic, and one side or the other
+// spilled.  Ends with this item's k_scale-gradient sums in the waves' LDS rows; the caller's barrier publishes the dQ^T accumulators.
+template <bool TAB, bool DTAB, bool SAFE>
+__device__ __noinline__ void bwd1_steps(StepArgs a_) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  StepArgs a = a_;
+  a.k = uni(a.k); a.v = uni(a.v); a.lse = uni(a.lse); a.tabh = uni(a.tabh); a.kinv = uni(a.kinv); a.k_scale = uni(a.k_scale);
+  a.dk = uni(a.dk); a.dv = uni(a.dv); a.ldk = uni(a.ldk); a.ldv = uni(a.ldv); a.park = uni(a.park);
+  a.nq = uni(a.nq); a.nv = uni(a.nv); a.nk = uni(a.nk); a.ndout = uni(a.ndout); a.no = uni(a.no); a.nlse = uni(a.nlse);
+  a.lddo = uni(a.lddo); a.ldo = uni(a.ldo); a.invK = uni(a.invK); a.H = uni(a.H); a.L = uni(a.L); a.P = uni(a.P);
+  a.g.gw = uni(a.g.gw); a.g.S = uni(a.g.S); a.g.c0 = uni(a.g.c0); a.g.magic = uni(a.g.magic); a.g.ncls = uni(a.g.ncls); a.g.gh = uni(a.g.gh);
+  a.wstamp = uni(a.wstamp);
+  const G1& g = a.g;
+  const int L = a.L, nkb = L / 32, NT = nkb * nkb, P = a.P;
+  char* qs = dyn;
+  char* dos = dyn + L * 64;
+  char* dqa = dyn + L * 128;
+  float* nd = reinterpret_cast<float*>(dyn + L * 256);
+  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);
+  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));
+  float* sred = misc + 64;
+  const uint32_t tcnt_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 16);    // [32] tile counters
+  const uint32_t pflag_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 48);   // [NW1] "wave w has parked its part"
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const TrOff tr = tr_offsets(lane);
+  const int g0 = P * wave;                                       // first position of this wave
+  if (g0 >= NT) return;
+  int pmod[NW1];
+#pragma unroll
+  for (int w8 = 0; w8 < NW1; ++w8) pmod[w8] = (P * w8) % nkb;
+  const int last = (g0 + P < NT ? g0 + P : NT) - 1;              // last position of this wave
+  int kb = g0 / nkb, t = g0 - kb * nkb;
+  float ksacc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ksacc[i] = 0.f;
+  auto load_kv = [&](Frag& kk, Frag& vv, int jb) {
+    const int64_t o2 = (int64_t)(jb * 32 + c) * D;
+    kk = global_row(a.k + o2, half); vv = global_row(a.v + o2, half);
+  };
+  auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
+  auto bias_req = [&](f32x16& cb, int tt, int uc) {
+    if (TAB) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        const float* b = a.tabh + class0(tt, gq, uc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cb[8 * gq + e] = b[e];
+      }
+    } else {
+      const float tv = a.tabh[0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[r] = tv;
+    }
+  };
+  // touch j covers lines [64 j, 64 j + 64) of: K^ of this item (L / 2 lines), then Q~, V, K^ of the next item, then its dout and o rows (one
+  // line per row) and lse2
+  auto touch_line = [&](int j) -> uint32_t {
+    const int ln = j * 64 + lane, hl = L / 2;
+    const char* ad = reinterpret_cast<const char*>(a.k) + (ln < hl ? ln : 0) * 128;
+    if (ln >= hl) ad = reinterpret_cast<const char*>(a.nq) + (ln - hl) * 128;
+    if (ln >= 2 * hl) ad = reinterpret_cast<const char*>(a.nv) + (ln - 2 * hl) * 128;
+    if (ln >= 3 * hl) ad = reinterpret_cast<const char*>(a.nk) + (ln - 3 * hl) * 128;
+    if (ln >= 4 * hl) ad = reinterpret_cast<const char*>(a.ndout + (int64_t)(ln - 4 * hl) * a.lddo);
+    if (ln >= 4 * hl + L) ad = reinterpret_cast<const char*>(a.no + (int64_t)(ln - 4 * hl - L) * a.ldo);
+    if (ln >= 4 * hl + 2 * L) ad = reinterpret_cast<const char*>(a.nlse + ((ln - 4 * hl - 2 * L) * 32) % L);
+    return *reinterpret_cast<const uint32_t*>(ad);
+  };
+  f32x16 dkacc, dvacc;
+  Frag kf, vf, ktf, kn, vn;
+  load_kv(kn, vn, kb);
+  int ucol = 0;
+  bool need_ktf = false, newblk = false;
+  f32x16 cbn;
+  bias_req(cbn, t, g.u(kb * 32 + c));
+  uint32_t tch = 0u;
+  unsigned long long tspin = 0;
+  for (int s = 0; s < P; ++s) {
+    const int gpos = g0 + s;
+    if (gpos > last) break;
+    int texp;
+    {   // wait until every earlier update of query tile t is complete: the steps of ALL waves order the updates of a tile (in one step the
+        // eight waves are on eight different tiles), so the number of updates before step s is a closed form -- no workgroup barrier
+      int expect = 0;
+#pragma unroll
+      for (int w8 = 0; w8 < NW1; ++w8) {
+        const int len = NT - P * w8 < P ? NT - P * w8 : P;                      // positions of wave w8 (may be <= 0)
+        const int lim = s < len ? s : len;
+        int f = t - pmod[w8]; f = f < 0 ? f + nkb : f;                            // its first step on tile t (pmod = P w8 mod nkb)
+        int d = lim - 1 - f, n = 0;                                               // (no integer division in here: ~25 instructions each on this chip)
+        if (d >= 0) { n = 1; while (d >= nkb) { d -= nkb; ++n; } }
+        expect += n;
+      }
+      const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
+      while (__builtin_amdgcn_readfirstlane(lds_peek(tcnt_a + 4 * t)) < expect) __builtin_amdgcn_s_sleep(1);
+      if (a.wstamp) tspin += wall_clock64() - tb0;
+      asm volatile("" ::: "memory");
+      texp = expect + 1;
+    }
+    if (s == 0 || t == 0) {                                      // a new key block starts here
+      kf = kn; vf = vn;
+      ucol = g.u(kb * 32 + c);
+      need_ktf = true; newblk = true;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
+    }
+    asm volatile("" :: "v"(tch));
+    float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
+    f32x16 dqc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
+    asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
+    f32x16 cb = cbn;
+    const char* qtile = qs + t * TILE;
+    const char* dotile = dos + t * TILE;
+    const Frag qf = lds_rows(qtile, ar, half);
+    const Frag dof = lds_rows(dotile, ar, half);
+    f32x16 cdel;
+    {
+      const float* sp = nd + t * 32 + 8 * half;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sp + 16), b1 = *reinterpret_cast<const f32x4*>(sp + 20);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
+    }
+    if (!SAFE) {                                                 // slow path: the queries' lse2 from global memory
+      const float* sp = a.lse + t * 32 + 8 * half;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cb[e] -= sp[e]; cb[8 + e] -= sp[16 + e]; }
+    }
+    f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[0], kf.v[0], cb, 0, 0, 0);
+    f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[0], vf.v[0], cdel, 0, 0, 0);
+    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[1], kf.v[1], sc, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[1], vf.v[1], dp, 0, 0, 0);
+    // L2 prefetch, trickled: vmcnt retires in order, so an HBM miss anywhere in this loop holds up the next step's bias -- the operands the
+    // loop reads from global memory (K^ / V rows of THIS item) and the whole load phase of the NEXT item are therefore touched line by line
+    // (one dword per 128 bytes), one wave instruction every fourth step, issued here and consumed at the top of the next step
+    if ((s & 3) == 1) tch = touch_line((s >> 2) * NW1 + wave);
+    const Frag dotf = lds_cols(dotile, tr);
+    const Frag qtf = lds_cols(qtile, tr);
+    float pr[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(sc[r]); ds[r] = pr[r] * dp[r]; }
+    if (DTAB) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        uint32_t* b = dtab + class0(t, gq, ucol);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          (void)__hip_atomic_fetch_add(b + e, __float_as_uint(__builtin_fmaf(pr[8 * gq + e], dp[8 * gq + e], MAGIC)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    const Frag pf = pack(pr), dsf = pack(ds);
+    dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);
+    dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
+    dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
+    dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
+    char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t in this step; its accumulators are in dqc
+    if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
+    put_rows(scratch, c, half, dsf);
+    const Frag dstf = lds_cols(scratch, tr);
+    dqc = mma(dqc, ktf, dstf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[r * 64 + lane] = dqc[r];
+    asm volatile("" ::: "memory");
+    if (lane == 0) lds_poke(tcnt_a + 4 * t, texp);               // (LDS executes a wave's operations in order: the accumulators are written when this is seen)
+    {                                                            // the next tile's bias (L1-resident table): requested at the END of the tile, when
+      int tn = t + 1, kbn = kb;                                  // the tile's temporaries are dead, consumed at the start of the next step
+      if (tn == nkb) { tn = 0; kbn = kb + 1; }
+      if (gpos + 1 <= last) bias_req(cbn, tn, g.u(kbn * 32 + c));
+    }
+    if (newblk) {                                                // the next block's K^ / V rows, a block ahead -- requested AFTER the bias (the bias wait
+      newblk = false;                                            // of the next step is then a counted one that leaves these in flight)
+      if ((kb + 1) * nkb <= last) load_kv(kn, vn, kb + 1);
+    }
+    if (t == nkb - 1 || gpos == last) {                          // this wave's tiles of key block kb are done
+      float* pk = a.park + ((int64_t)wave * 64 + lane) * 32;
+      if (kb * nkb < g0) {                                       // the block began in the previous wave's range: park this part for it
+        f32x4* pv = reinterpret_cast<f32x4*>(pk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pv[j] = f32x4{dkacc[4 * j], dkacc[4 * j + 1], dkacc[4 * j + 2], dkacc[4 * j + 3]};
+          pv[4 + j] = f32x4{dvacc[4 * j], dvacc[4 * j + 1], dvacc[4 * j + 2], dvacc[4 * j + 3]};
+        }
+        wait_stores();
+        if (lane == 0) lds_poke(pflag_a + 4 * wave, 1);
+      } else {
+        if ((kb + 1) * nkb - 1 > gpos) {                         // the rest of the block belongs to the next wave: add the part it parked (first
+          while (__builtin_amdgcn_readfirstlane(lds_peek(pflag_a + 4 * (wave + 1))) == 0) __builtin_amdgcn_s_sleep(1);     // part + second part)
+          asm volatile("" ::: "memory");
+          const f32x4* pv = reinterpret_cast<const f32x4*>(pk + 64 * 32);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 u = pv[j], w = pv[4 + j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dkacc[4 * j + e] += u[e]; dvacc[4 * j + e] += w[e]; }
+          }
+        }
+        // un-prep in place (attn_unprep_kernel of attn2.hip): u = k^ / k_scale, g = dk^ k_scale, dk = kinv (g - u (u . g)); dscale += dk^ u.  Written
+        // for few live registers (dV out first; the dot product in one pass, the outputs in a second one that recomputes u and g)
+        const int row = kb * 32 + c;
+        bf16_t* dV = a.dv + (int64_t)row * a.ldv;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          float b8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b8[e] = dvacc[8 * gq + e] * a.invK;
+          store8(dV + 16 * gq + 8 * half, b8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float ik = a.kinv[(int64_t)row * a.H];
+        const float kmul = LN2 * a.invK;
+        const u32x4 kw0 = __builtin_bit_cast(u32x4, kf.v[0]), kw1 = __builtin_bit_cast(u32x4, kf.v[1]);
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = 8 * gq + e;
+            const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
+            const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
+            const float ks = a.k_scale[16 * gq + 8 * half + e];
+            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+            const float gk0 = bf2f(f2bf(dkacc[i] * kmul));
+            const float uk = kx * rk;
+            ksacc[i] += gk0 * uk;
+            part[gq] += uk * (gk0 * ks);
+            dkacc[i] = gk0;
+          }
+        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+        __builtin_amdgcn_sched_barrier(0);
+        bf16_t* dK = a.dk + (int64_t)row * a.ldk;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          float a8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
+            const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
+            const float ks = a.k_scale[16 * gq + 8 * half + e];
+            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+            a8[e] = ik * (dkacc[8 * gq + e] * ks - (kx * rk) * dot);
+          }
+          store8(dK + 16 * gq + 8 * half, a8);
+        }
+      }
+    }
+    if (++t == nkb) { t = 0; ++kb; }
+  }
+  if (a.wstamp && wave == 0 && lane == 0) *a.wstamp = tspin;
+  // this item's k_scale-gradient sums: the 32 lanes of a half by an xor tree, then added to the wave's row of the LDS accumulator
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) ksacc[i] += __shfl_xor(ksacc[i], o, 64);
+  if (c == 0) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sred[wave * 32 + 16 * gq + 8 * half + e] += ksacc[8 * gq + e];
+  }
+}
+
 template <bool TAB, bool DTAB, bool SAFE>
 __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1& g, char* dyn) {
-  const int L = p.L, nkb = L / 32, NT = nkb * nkb;
+  const int L = p.L, nkb = L / 32;
   char* qs = dyn;                                               // Q~ slab
   char* dos = dyn + L * 64;                                     // dO'' slab
   char* dqa = dyn + L * 128;                                    // dQ^T accumulators [tile][16][64] f32
   float* nd = reinterpret_cast<float*>(dyn + L * 256);          // -delta''
   uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);  // class table (fixed point)
-  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));       // [64] reductions
+  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));       // [0,16) reductions, [16,48) tile counters, [48,56) park flags
+  float* sred = misc + 64;                                      // [2][NW1][32] scale-gradient sums of the waves (k, q) over the items
+  int* cnts = reinterpret_cast<int*>(misc + 16);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
-  const TrOff tr = tr_offsets(lane);
   const int h = (int)blockIdx.x / x.wph, wgh = (int)blockIdx.x % x.wph;
   const int seq0 = wgh * x.ipw;
   const float m2 = x.hinfo[2 * h];
-  constexpr bool safe = SAFE;
-  const float* tabh = x.tabadj + (int64_t)h * g.ncls;
   if (DTAB) { for (int i = tid; i < g.ncls; i += NTH1) dtab[i] = 0u; }
-  const int g0 = x.P * wave;                                     // first position of this wave
-  const int kb0 = g0 / nkb, t0 = g0 - kb0 * nkb;
-  const bool has_work = g0 < NT;
+  if (tid < 2 * NW1 * 32) sred[tid] = 0.f;
 
 #define BWD1_STAMP(i) do { if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + (i)] = wall_clock64(); } while (0)
   for (int it = 0; it < x.ipw; ++it) {
@@ -133,46 +427,48 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     BWD1_STAMP(0);
     const int64_t so = ((int64_t)h * p.M + (int64_t)seq * L) * D;
     const int64_t tok0 = (int64_t)seq * L;
-    auto load_kv = [&](Frag& k, Frag& v, int jb) {
-      const int64_t o2 = so + (int64_t)(jb * 32 + c) * D;
-      k = global_row(p.kh + o2, half); v = global_row(p.vh + o2, half);
-    };
-    // ------------------------------------------------------------------------------------------------ load phase
-    Frag kn, vn;
-    if (has_work) load_kv(kn, vn, kb0);
+    // ------------------------------------------------------------------------------------------------ load phase: the item's operands -> LDS
+    // Q~ slab, dO'' = K w dO (w = exp2(m2 - lse2): the factor between the bounded exponentials and the probabilities; K: the fixed-point scale),
+    // -delta'' = -K w sum_d dO O, zeroed dQ^T accumulators, tile counters and park flags
     float K = 1.f, invK = 1.f;
     {
+      const bf16_t* qsl = p.qh + so;
+      const bf16_t* vsl = p.vh + so;
+      const bf16_t* dsl = p.dout + tok0 * p.lddo + h * D;
+      const bf16_t* osl = p.o + tok0 * p.ldo + h * D;
+      const float* lsl = p.lse2 + (int64_t)h * p.M + tok0;
       u32x4 dpc[NPIECE];
       float wrow[NPIECE], drow[NPIECE];
       float mxd = 0.f, mxv = 0.f;
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
         const int pc = k * NTH1 + tid;
-        const bool ok = pc < 4 * L;
-        const int pcc = ok ? pc : 4 * L - 1, row = pcc >> 2, ch = pcc & 3;
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(p.qh + so + row * D + ch * 8);
-        const u32x4 vv = *reinterpret_cast<const u32x4*>(p.vh + so + row * D + ch * 8);
-        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dout + (tok0 + row) * p.lddo + h * D + ch * 8);
-        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.o + (tok0 + row) * p.ldo + h * D + ch * 8);
-        const float ls = p.lse2[(int64_t)h * p.M + tok0 + row];
-        if (ok) *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = qv;
-        float a[8], b[8], v8[8];
-        unpack8u(dv, a); unpack8u(ov, b); unpack8u(vv, v8);
+        const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(qsl + row * D + ch * 8);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(vsl + row * D + ch * 8);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(dsl + (int64_t)row * p.lddo + ch * 8);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(osl + (int64_t)row * p.ldo + ch * 8);
+        const float ls = lsl[row];
+        // (no branch in this loop: a branch would end the basic block and the next piece's loads would wait for this piece's -- five HBM
+        // round trips instead of one; a clamped piece re-writes the last piece's bytes)
+        *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = qv;
+        float x8[8], b[8], v8[8];
+        unpack8u(dv, x8); unpack8u(ov, b); unpack8u(vv, v8);
         float ds = 0.f, dn = 0.f, vnn = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ds += a[e] * b[e]; dn += a[e] * a[e]; vnn += v8[e] * v8[e]; }
+        for (int e = 0; e < 8; ++e) { ds += x8[e] * b[e]; dn += x8[e] * x8[e]; vnn += v8[e] * v8[e]; }
         ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
         dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
         vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
-        const float w = safe ? __builtin_amdgcn_exp2f(m2 - ls) : 1.f;
+        const float w = SAFE ? __builtin_amdgcn_exp2f(m2 - ls) : 1.f;
         wrow[k] = w; drow[k] = ds * w; dpc[k] = dv;
-        if (ok) { mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn); }      // |dS| <= P 2 |dO_q| |v_k| with the TRUE probability P <= 1: no w here
+        mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);                  // |dS| <= P 2 |dO_q| |v_k| with the TRUE probability P <= 1: no w here
       }
       BWD1_STAMP(1);
       mxd = wave_max(mxd); mxv = wave_max(mxv);
       if (lane == 0) { misc[wave] = mxd; misc[8 + wave] = mxv; }
-      // zero the dQ^T accumulators
       for (int i = tid; i < L * 8; i += NTH1) *reinterpret_cast<u32x4*>(dqa + (int64_t)i * 16) = u32x4{0u, 0u, 0u, 0u};
+      if (tid < 40) cnts[tid] = 0;
       __syncthreads();
       float bd = 0.f, bv = 0.f;
 #pragma unroll
@@ -186,253 +482,107 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
         const int pc = k * NTH1 + tid;
-        if (pc < 4 * L) {
-          const int row = pc >> 2, ch = pc & 3;
-          float a[8];
-          unpack8u(dpc[k], a);
-          const float f = wrow[k] * K;
+        const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
+        float x8[8];
+        unpack8u(dpc[k], x8);
+        const float f = wrow[k] * K;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] *= f;
-          u32x4 o4;
+        for (int e = 0; e < 8; ++e) x8[e] *= f;
+        u32x4 o4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = pack2bf(a[2 * e], a[2 * e + 1]);
-          *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = o4;
-          if (ch == 0) nd[row] = -(drow[k] * K);
-        }
+        for (int e = 0; e < 4; ++e) o4[e] = pack2bf(x8[2 * e], x8[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = o4;
+        nd[row] = -(drow[k] * K);                                // (the four chunk threads of a row hold the same value)
       }
     }
     __syncthreads();
     BWD1_STAMP(2);
-    unsigned long long tbar = 0;
-
-    // ------------------------------------------------------------------------------------------------ tile steps
-    f32x16 dkacc, dvacc;
-    Frag kf, vf, ktf;
-    int kb = kb0, t = t0;
-    int ucol = 0;
-    bool need_ktf = false;
-    f32x16 cbn;
-    auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
-    auto bias_req = [&](f32x16& cb, int tt, int uc) {
-      if (TAB) {
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-          const float* b = tabh + class0(tt, gq, uc);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cb[8 * gq + e] = b[e];
-        }
-      } else {
-        const float tv = tabh[0];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cb[r] = tv;
-      }
-    };
-    if (has_work) bias_req(cbn, t0, g.u(kb0 * 32 + c));
-    for (int s = 0; s < x.P; ++s) {
-      const unsigned long long tb0 = x.stamps ? wall_clock64() : 0ull;
-      step_barrier();
-      if (x.stamps) tbar += wall_clock64() - tb0;
-      const int gpos = g0 + s;
-      if (gpos < NT) {
-        if (s == 0 || t == 0) {                                  // a new key block starts here
-          kf = kn; vf = vn;
-          ucol = g.u(kb * 32 + c);
-          need_ktf = true;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
-          const int last = (g0 + x.P < NT ? g0 + x.P : NT) - 1;  // last position of this wave
-          if ((kb + 1) * nkb <= last) load_kv(kn, vn, kb + 1);   // the next block of this wave, requested a block ahead
-        }
-        float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
-        f32x16 dqc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
-        asm volatile("" ::: "memory");                           // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
-        f32x16 cb = cbn;
-        const char* qtile = qs + t * TILE;
-        const char* dotile = dos + t * TILE;
-        const Frag qf = lds_rows(qtile, ar, half);
-        const Frag dof = lds_rows(dotile, ar, half);
-        f32x16 cdel;
-        {
-          const float* sp = nd + t * 32 + 8 * half;
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sp + 16), b1 = *reinterpret_cast<const f32x4*>(sp + 20);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
-        }
-        if (!safe) {                                             // slow path: the queries' lse2 from global memory
-          const float* sp = p.lse2 + (int64_t)h * p.M + tok0 + t * 32 + 8 * half;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { cb[e] -= sp[e]; cb[8 + e] -= sp[16 + e]; }
-        }
-        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[0], kf.v[0], cb, 0, 0, 0);
-        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[0], vf.v[0], cdel, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[1], kf.v[1], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[1], vf.v[1], dp, 0, 0, 0);
-        const Frag dotf = lds_cols(dotile, tr);
-        const Frag qtf = lds_cols(qtile, tr);
-        float pr[16], ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(sc[r]); ds[r] = pr[r] * dp[r]; }
-        if (DTAB) {
-#pragma unroll
-          for (int gq = 0; gq < 2; ++gq) {
-            uint32_t* b = dtab + class0(t, gq, ucol);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              (void)__hip_atomic_fetch_add(b + e, __float_as_uint(__builtin_fmaf(pr[8 * gq + e], dp[8 * gq + e], MAGIC)), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-        const Frag pf = pack(pr), dsf = pack(ds);
-        dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);
-        dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
-        dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
-        dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
-        char* scratch = reinterpret_cast<char*>(dqt);            // this wave owns query tile t in this step; its accumulators are in dqc
-        if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
-        put_rows(scratch, c, half, dsf);
-        const Frag dstf = lds_cols(scratch, tr);
-        dqc = mma(dqc, ktf, dstf);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqt[r * 64 + lane] = dqc[r];
-        {                                                        // the next tile's bias (L1-resident table): requested at the END of the tile, when
-          int tn = t + 1, kbn = kb;                              // the tile's temporaries are dead, consumed after the next barrier
-          if (tn == nkb) { tn = 0; kbn = kb + 1; }
-          if (s + 1 < x.P && gpos + 1 < NT) bias_req(cbn, tn, g.u(kbn * 32 + c));
-        }
-
-        if (t == nkb - 1 || s == x.P - 1 || gpos == NT - 1) {   // this wave's tiles of the key block are done: park dK^T / dV^T (the
-          // l2norm backward and the stores run after the last step, where the registers of the tile loop are free).  part 1 = the block
-          // began in the previous wave's range
-          float* pk = x.park + ((((int64_t)blockIdx.x * nkb + kb) * 2 + (kb * nkb < g0 ? 1 : 0)) * 32) * 64 + lane;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { pk[r * 64] = dkacc[r]; pk[(16 + r) * 64] = dvacc[r]; }
-        }
-        if (++t == nkb) { t = 0; ++kb; }
-      }
+    // ------------------------------------------------------------------------------------------------ tile steps (+ dK / dV un-prep inside)
+    {
+      const bool more = it + 1 < x.ipw;
+      const int64_t so2 = more ? so + (int64_t)L * D : so, tok2 = more ? tok0 + L : tok0;
+      bwd1_steps<TAB, DTAB, SAFE>(StepArgs{p.kh + so, p.vh + so, p.lse2 + (int64_t)h * p.M + tok0, x.tabadj + (int64_t)h * g.ncls, p.kinv + tok0 * p.H + h,
+                                           p.k_scale, p.dk_tok + tok0 * p.ldk_tok + h * D, p.dv_tok + tok0 * p.ldv_tok + h * D, p.ldk_tok, p.ldv_tok,
+                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, p.qh + so2, p.vh + so2, p.kh + so2,
+                                           p.dout + tok2 * p.lddo + h * D, p.o + tok2 * p.ldo + h * D, p.lse2 + (int64_t)h * p.M + tok2, p.lddo, p.ldo,
+                                           invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr});
     }
     BWD1_STAMP(3);
-    wait_stores();                                               // the parked accumulators have reached L2 before any wave reads them back
     __syncthreads();
     BWD1_STAMP(4);
-    if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + 9] = tbar;
-
-    // ------------------------------------------------------------------------------------------------ dQ and dK / dV: un-prep in place
-    // (attn_unprep_kernel of attn2.hip: u = x^ / scale_vec, g = dx^ scale_vec, dx = inv (g - u (u . g)), dscale += dx^ u on the bf16-rounded
-    // planar gradient).  The scale-gradient partials of this thread live in global scratch between items (16 + 16 floats, [i][thread]).
+    // ------------------------------------------------------------------------------------------------ dQ: un-prep of q in place
+    // (attn_unprep_kernel of attn2.hip: u = q~ / (q_scale c), g = dq^ q_scale, dq = qinv (g - u (u . g)), dscale += dq^ u on the bf16-rounded dq^)
     {
-      float ksacc[16], qsacc[16];
+      constexpr int MAXB = 3;                                    // query tiles per wave: ceil(18 / 8)
+      float iq[MAXB];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { ksacc[i] = 0.f; qsacc[i] = 0.f; }
+      for (int j = 0; j < MAXB; ++j) {
+        const int tq = wave + j * NW1 < nkb ? wave + j * NW1 : nkb - 1;
+        iq[j] = x.qinv[(tok0 + tq * 32 + ar) * p.H + h];
+      }
+      float qsacc[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) qsacc[i] = 0.f;
       const float scq = p.c * LN2 * invK;
-      for (int tq = wave; tq < nkb; tq += NW1) {
-        const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
-        const int qi = tq * 32 + ar;                             // lane n of the transposed product holds query pi32(n & 31)
-        const int64_t tok = tok0 + qi;
-        const float iq = x.qinv[tok * p.H + h];
-        const Frag qrow = lds_rows(qs + tq * TILE, ar, half);
-        float qx[16], dq[16];
-        unpack8u(__builtin_bit_cast(u32x4, qrow.v[0]), qx); unpack8u(__builtin_bit_cast(u32x4, qrow.v[1]), qx + 8);
-        float part[2] = {0.f, 0.f};
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
+      for (int j = 0; j < MAXB; ++j) {
+        const int tq = wave + j * NW1;
+        if (tq < nkb) {
+          const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
+          const int64_t tok = tok0 + tq * 32 + ar;               // lane n of the transposed product holds query pi32(n & 31)
+          const Frag qrow = lds_rows(qs + tq * TILE, ar, half);
+          float qx[16], dq[16];
+          unpack8u(__builtin_bit_cast(u32x4, qrow.v[0]), qx); unpack8u(__builtin_bit_cast(u32x4, qrow.v[1]), qx + 8);
+          float part[2] = {0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int i = 8 * gq + e;
-            const float qsv = p.q_scale[16 * gq + 8 * half + e];
-            const float qc = qsv * p.c;
-            const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
-            const float gq0 = bf2f(f2bf(dqt[i * 64 + lane] * scq));
-            const float uq = qx[i] * rq;
-            qsacc[i] += gq0 * uq;
-            const float gv = gq0 * qsv;
-            part[gq] += uq * gv;
-            qx[i] = uq; dq[i] = gv;
+          for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int i = 8 * gq + e;
+              const float qsv = p.q_scale[16 * gq + 8 * half + e];
+              const float qc = qsv * p.c;
+              const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
+              const float gq0 = bf2f(f2bf(dqt[i * 64 + lane] * scq));
+              const float uq = qx[i] * rq;
+              qsacc[i] += gq0 * uq;
+              const float gv = gq0 * qsv;
+              part[gq] += uq * gv;
+              qx[i] = uq; dq[i] = gv;
+            }
+          const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+          bf16_t* dQ = x.dq_tok + tok * x.lddq + h * D;
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            float a8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] = iq[j] * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
+            store8(dQ + 16 * gq + 8 * half, a8);
           }
-        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
-        bf16_t* dQ = x.dq_tok + tok * x.lddq + h * D;
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-          float a8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a8[e] = iq * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
-          store8(dQ + 16 * gq + 8 * half, a8);
         }
       }
       BWD1_STAMP(5);
-      const float kmul = LN2 * invK;
-      for (int jb = wave; jb < nkb; jb += NW1) {
-        // the parked accumulators of key block jb: one part, or two when its positions straddle two waves (first part + second part, in that order)
-        const bool split = (jb * nkb) / x.P != (jb * nkb + nkb - 1) / x.P;
-        const float* pk = x.park + (((int64_t)blockIdx.x * nkb + jb) * 2 * 32) * 64 + lane;
-        float dka[16], dva[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dka[r] = __hip_atomic_load(pk + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dva[r] = __hip_atomic_load(pk + (16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (split) {
+      for (int i = 0; i < 16; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            dka[r] += __hip_atomic_load(pk + (32 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dva[r] += __hip_atomic_load(pk + (48 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        const int kj = jb * 32 + c;
-        const int64_t tok = tok0 + kj;
-        const float ik = p.kinv[tok * p.H + h];
-        const Frag krow = global_row(p.kh + so + (int64_t)kj * D, half);
-        float kx[16], dk[16];
-        unpack8u(__builtin_bit_cast(u32x4, krow.v[0]), kx); unpack8u(__builtin_bit_cast(u32x4, krow.v[1]), kx + 8);
-        float part[2] = {0.f, 0.f};
+        for (int o = 1; o < 32; o <<= 1) qsacc[i] += __shfl_xor(qsacc[i], o, 64);
+      if (c == 0) {
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int i = 8 * gq + e;
-            const float ks = p.k_scale[16 * gq + 8 * half + e];
-            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
-            const float gk0 = bf2f(f2bf(dka[i] * kmul));
-            const float uk = kx[i] * rk;
-            ksacc[i] += gk0 * uk;
-            const float gk = gk0 * ks;
-            part[gq] += uk * gk;
-            kx[i] = uk; dk[i] = gk;
-          }
-        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
-        bf16_t* dK = p.dk_tok + tok * p.ldk_tok + h * D;
-        bf16_t* dV = p.dv_tok + tok * p.ldv_tok + h * D;
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-          float a8[8], b8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { a8[e] = ik * (dk[8 * gq + e] - kx[8 * gq + e] * dot); b8[e] = dva[8 * gq + e] * invK; }
-          store8(dK + 16 * gq + 8 * half, a8);
-          store8(dV + 16 * gq + 8 * half, b8);
-        }
-      }
-      BWD1_STAMP(6);
-      float* sa = x.sacc + (int64_t)blockIdx.x * 32 * NTH1 + tid;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sa[i * NTH1] = it == 0 ? ksacc[i] : sa[i * NTH1] + ksacc[i];
-        sa[(16 + i) * NTH1] = it == 0 ? qsacc[i] : sa[(16 + i) * NTH1] + qsacc[i];
+          for (int e = 0; e < 8; ++e) sred[NW1 * 32 + wave * 32 + 16 * gq + 8 * half + e] += qsacc[8 * gq + e];
       }
     }
     BWD1_STAMP(7);
-    // ------------------------------------------------------------------------------------------------ flush the class table
+    // ------------------------------------------------------------------------------------------------ flush the class table (stores only)
     if (DTAB) {
       const int W = 2 * g.gw - 1;
+      float* dst = x.dtpart + (((int64_t)wgh * x.ipw + it) * p.H + h) * g.ncls;
       for (int i = tid; i < g.ncls; i += NTH1) {
         const int dyi = i / W, dxi = i - dyi * W;
         const int ady = dyi - (g.gh - 1), adx = dxi - (g.gw - 1);
         const uint32_t cnt = (uint32_t)((g.gh - (ady < 0 ? -ady : ady)) * (g.gw - (adx < 0 ? -adx : adx)));
         const int32_t v = (int32_t)(dtab[i] - cnt * MAGIC_BITS);
-        const float f = (float)v * invK;
-        float* dst = x.dtpart + ((int64_t)wgh * p.H + h) * g.ncls + i;
-        *dst = it == 0 ? f : *dst + f;
+        dst[i] = (float)v * invK;
         dtab[i] = 0u;
       }
     }
@@ -440,33 +590,12 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     BWD1_STAMP(8);
   }
 
-  // scale gradients of this workgroup, in a fixed order: the 32 lanes of a half by an xor tree, then the eight waves
-  float ksacc[16], qsacc[16];
-  {
-    const float* sa = x.sacc + (int64_t)blockIdx.x * 32 * NTH1 + tid;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { ksacc[i] = sa[i * NTH1]; qsacc[i] = sa[(16 + i) * NTH1]; }
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { ksacc[i] += __shfl_xor(ksacc[i], o, 64); qsacc[i] += __shfl_xor(qsacc[i], o, 64); }
-  float* red = reinterpret_cast<float*>(qs);                     // [2][NW1][32]
-  if (c == 0) {
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[wave * 32 + 16 * gq + 8 * half + e] = ksacc[8 * gq + e];
-        red[NW1 * 32 + wave * 32 + 16 * gq + 8 * half + e] = qsacc[8 * gq + e];
-      }
-  }
-  __syncthreads();
+  // scale gradients of this workgroup: the eight waves in order
   if (tid < 64) {
     const int which = tid >> 5, d = tid & 31;
     float tsum = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < NW1; ++w8) tsum += red[which * NW1 * 32 + w8 * 32 + d];
+    for (int w8 = 0; w8 < NW1; ++w8) tsum += sred[which * NW1 * 32 + w8 * 32 + d];
     (which ? x.qpart : p.kpart)[(int64_t)blockIdx.x * 32 + d] = tsum;
   }
 }
@@ -497,14 +626,23 @@ __global__ __launch_bounds__(1024) void bwd1_scale_sum_kernel(const float* __res
     dst[o] += a;
   }
 }
-// dtpart[wph][H][ncls] -> dtab (ncls, H), overwritten; workgroup partials in index order
-__global__ __launch_bounds__(256) void bwd1_dtab_sum_kernel(const float* __restrict__ part, int wph, float* __restrict__ dtab, int H, int ncls) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// dtpart[nblk][H][ncls] -> dtab (ncls, H), overwritten; the partials in index order (eight at a time in flight, summed left to right)
+__global__ __launch_bounds__(256) void bwd1_dtab_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dtab, int H, int ncls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;                 // i = h * ncls + cls: neighbours read neighbouring addresses
   if (i >= ncls * H) return;
-  const int cls = i / H, h = i % H;
+  const int h = i / ncls, cls = i - h * ncls;
+  const int64_t stride = (int64_t)H * ncls;
   float t = 0.f;
-  for (int b = 0; b < wph; ++b) t += part[((int64_t)b * H + h) * ncls + cls];
-  dtab[i] = t;
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)(b + k) * stride + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += v[k];
+  }
+  for (; b < nblk; ++b) t += part[(int64_t)b * stride + i];
+  dtab[(int64_t)cls * H + h] = t;
 }
 
 int ncus1() {
@@ -528,7 +666,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     pl.ncls = (2 * gh - 1) * S;
     pl.g = G1{gw, S, (gh - 1) * S + (gw - 1), (65536 + gw - 1) / gw, pl.ncls, gh};
   }
-  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256;
+  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4;
   if (pl.shm > 160 * 1024) return false;
   int P = (NT + NW1 - 1) / NW1;
   if (P < nkb) P = nkb;
@@ -554,8 +692,8 @@ extern "C" int ctclip_attn2_bwd_fused_supported(int nseq, int H, int L, int D_, 
 extern "C" int64_t ctclip_attn2_bwd_fused_workspace(int nseq, int H, int L, int bias_gh, int bias_gw) {
   Plan1 pl;
   if (!plan1(nseq, H, L, bias_gh, bias_gw, bias_gh > 0, pl)) return 0;
-  return a256((int64_t)H * pl.ncls * 4) + a256(H * 2 * 4) + a256((int64_t)pl.wph * H * pl.ncls * 4) + 2 * a256((int64_t)pl.nwg * 32 * 4) +
-         a256((int64_t)pl.nwg * (L / 32) * 2 * 32 * 64 * 4) + a256((int64_t)pl.nwg * 32 * NTH1 * 4) + 4096;
+  return a256((int64_t)H * pl.ncls * 4) + a256(H * 2 * 4) + a256((int64_t)nseq * H * pl.ncls * 4) + 2 * a256((int64_t)pl.nwg * 32 * 4) +
+         a256((int64_t)pl.nwg * NW1 * 64 * 32 * 4) + 4096;
 }
 
 // Backward of ctclip_attn2_fwd in ONE pass over the score tiles (attention.py:145-178 differentiated; the l2norm / learned-scale backward of
@@ -584,13 +722,12 @@ extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void
   char* w = (char*)workspace;
   float* tabadj = (float*)w; w += a256((int64_t)H * pl.ncls * 4);
   float* hinfo = (float*)w; w += a256(H * 2 * 4);
-  float* dtpart = (float*)w; w += a256((int64_t)pl.wph * H * pl.ncls * 4);
+  float* dtpart = (float*)w; w += a256((int64_t)nseq * H * pl.ncls * 4);
   p.kpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
   float* qpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
-  float* park = (float*)w; w += a256((int64_t)pl.nwg * (L / 32) * 2 * 32 * 64 * 4);
-  float* sacc = (float*)w; w += a256((int64_t)pl.nwg * 32 * NTH1 * 4);
+  float* park = (float*)w; w += a256((int64_t)pl.nwg * NW1 * 64 * 32 * 4);
   static const bool stamp = getenv("CTCLIP_BWD1_STAMPS") != nullptr;          // the last 4 KB of the workspace: phase clocks of workgroup 0
-  X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, hinfo, dtab ? dtpart : nullptr, park, sacc, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
+  X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, hinfo, dtab ? dtpart : nullptr, park, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
   hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, hinfo, pl.ncls);
   int rc = ctclip_check_launch("attn2_bwd_fused (stage)");
   if (rc) return rc;
@@ -612,6 +749,6 @@ extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void
   hipLaunchKernelGGL(bwd1_scale_sum_kernel, dim3(2), dim3(1024), 0, stream, (const float*)p.kpart, (const float*)qpart, pl.nwg, dk_scale, dq_scale);
   rc = ctclip_check_launch("attn2_bwd_fused (scale sums)");
   if (rc || !dtab) return rc;
-  hipLaunchKernelGGL(bwd1_dtab_sum_kernel, dim3((unsigned)cdiv((int64_t)pl.ncls * H, 256)), dim3(256), 0, stream, (const float*)dtpart, pl.wph, dtab, H, pl.ncls);
+  hipLaunchKernelGGL(bwd1_dtab_sum_kernel, dim3((unsigned)cdiv((int64_t)pl.ncls * H, 256)), dim3(256), 0, stream, (const float*)dtpart, nseq, dtab, H, pl.ncls);
   return ctclip_check_launch("attn2_bwd_fused (table sum)");
 }
