@@ -63,6 +63,21 @@ __device__ __forceinline__ void unpack8u(const u32x4& a, float* v) {
 }
 // every LDS operation of this wave has completed, then the workgroup barrier; global loads stay in flight
 __device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Global-memory accesses through pointers that arrived as FUNCTION arguments: the compiler cannot tell their address space and emits FLAT
+// instructions (counted on vmcnt AND lgkmcnt: every LDS wait then waits for them too) unless the access says "global"
+#define GPTR(T, ptr) ((__attribute__((address_space(1))) T*)(ptr))
+__device__ __forceinline__ Frag g_row(const bf16_t* row, int half) {
+  Frag f;
+  f.v[0] = *GPTR(const bf16x8, row + 8 * half);
+  f.v[1] = *GPTR(const bf16x8, row + 16 + 8 * half);
+  return f;
+}
+__device__ __forceinline__ void g_store8(bf16_t* ptr, const float (&v)[8]) {
+  u32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *GPTR(u32x4, ptr) = a;
+}
 // one dword of LDS, read now / written in program order (asm: a volatile generic pointer becomes a FLAT access that drains vmcnt)
 __device__ __forceinline__ int lds_peek(uint32_t addr) {
   int v;
@@ -159,15 +174,13 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   float* sred = misc + 64;
   const uint32_t tcnt_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 16);    // [32] tile counters
   const uint32_t pflag_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 48);   // [NW1] "wave w has parked its part"
+  const uint32_t etab_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(sred + 2 * NW1 * 32);   // [NW1][P] updates of the tile before (wave, step)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const TrOff tr = tr_offsets(lane);
   const int g0 = P * wave;                                       // first position of this wave
   if (g0 >= NT) return;
-  int pmod[NW1];
-#pragma unroll
-  for (int w8 = 0; w8 < NW1; ++w8) pmod[w8] = (P * w8) % nkb;
   const int last = (g0 + P < NT ? g0 + P : NT) - 1;              // last position of this wave
   int kb = g0 / nkb, t = g0 - kb * nkb;
   float ksacc[16];
@@ -175,19 +188,19 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   for (int i = 0; i < 16; ++i) ksacc[i] = 0.f;
   auto load_kv = [&](Frag& kk, Frag& vv, int jb) {
     const int64_t o2 = (int64_t)(jb * 32 + c) * D;
-    kk = global_row(a.k + o2, half); vv = global_row(a.v + o2, half);
+    kk = g_row(a.k + o2, half); vv = g_row(a.v + o2, half);
   };
   auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
   auto bias_req = [&](f32x16& cb, int tt, int uc) {
     if (TAB) {
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {
-        const float* b = a.tabh + class0(tt, gq, uc);
+        const __attribute__((address_space(1))) float* b = GPTR(const float, a.tabh + class0(tt, gq, uc));
 #pragma unroll
         for (int e = 0; e < 8; ++e) cb[8 * gq + e] = b[e];
       }
     } else {
-      const float tv = a.tabh[0];
+      const float tv = *GPTR(const float, a.tabh);
 #pragma unroll
       for (int r = 0; r < 16; ++r) cb[r] = tv;
     }
@@ -203,7 +216,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     if (ln >= 4 * hl) ad = reinterpret_cast<const char*>(a.ndout + (int64_t)(ln - 4 * hl) * a.lddo);
     if (ln >= 4 * hl + L) ad = reinterpret_cast<const char*>(a.no + (int64_t)(ln - 4 * hl - L) * a.ldo);
     if (ln >= 4 * hl + 2 * L) ad = reinterpret_cast<const char*>(a.nlse + ((ln - 4 * hl - 2 * L) * 32) % L);
-    return *reinterpret_cast<const uint32_t*>(ad);
+    return *GPTR(const uint32_t, ad);
   };
   f32x16 dkacc, dvacc;
   Frag kf, vf, ktf, kn, vn;
@@ -217,25 +230,6 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   for (int s = 0; s < P; ++s) {
     const int gpos = g0 + s;
     if (gpos > last) break;
-    int texp;
-    {   // wait until every earlier update of query tile t is complete: the steps of ALL waves order the updates of a tile (in one step the
-        // eight waves are on eight different tiles), so the number of updates before step s is a closed form -- no workgroup barrier
-      int expect = 0;
-#pragma unroll
-      for (int w8 = 0; w8 < NW1; ++w8) {
-        const int len = NT - P * w8 < P ? NT - P * w8 : P;                      // positions of wave w8 (may be <= 0)
-        const int lim = s < len ? s : len;
-        int f = t - pmod[w8]; f = f < 0 ? f + nkb : f;                            // its first step on tile t (pmod = P w8 mod nkb)
-        int d = lim - 1 - f, n = 0;                                               // (no integer division in here: ~25 instructions each on this chip)
-        if (d >= 0) { n = 1; while (d >= nkb) { d -= nkb; ++n; } }
-        expect += n;
-      }
-      const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
-      while (__builtin_amdgcn_readfirstlane(lds_peek(tcnt_a + 4 * t)) < expect) __builtin_amdgcn_s_sleep(1);
-      if (a.wstamp) tspin += wall_clock64() - tb0;
-      asm volatile("" ::: "memory");
-      texp = expect + 1;
-    }
     if (s == 0 || t == 0) {                                      // a new key block starts here
       kf = kn; vf = vn;
       ucol = g.u(kb * 32 + c);
@@ -244,11 +238,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
       for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
     }
     asm volatile("" :: "v"(tch));
-    float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
-    f32x16 dqc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
-    asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
+    // ---- part A: everything that does not touch dQ^T (no ownership of query tile t needed)
     f32x16 cb = cbn;
     const char* qtile = qs + t * TILE;
     const char* dotile = dos + t * TILE;
@@ -263,7 +253,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
       for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
     }
     if (!SAFE) {                                                 // slow path: the queries' lse2 from global memory
-      const float* sp = a.lse + t * 32 + 8 * half;
+      const __attribute__((address_space(1))) float* sp = GPTR(const float, a.lse + t * 32 + 8 * half);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { cb[e] -= sp[e]; cb[8 + e] -= sp[16 + e]; }
     }
@@ -295,7 +285,23 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
     dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
     dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
-    char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t in this step; its accumulators are in dqc
+    // ---- part B: the update of dQ^T[t] -- wait for the tile, then read-modify-write its accumulator block
+    // wait until every earlier update of query tile t is complete: the steps of ALL waves order the updates of a tile (in one step the eight
+    // waves are on eight different tiles), so the number of updates before step s is a closed form (tabulated by the kernel: etab) -- no
+    // workgroup barrier
+    const int texp = __builtin_amdgcn_readfirstlane(lds_peek(etab_a + 4 * (wave * P + s))) + 1;
+    {
+      const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
+      while (__builtin_amdgcn_readfirstlane(lds_peek(tcnt_a + 4 * t)) < texp - 1) __builtin_amdgcn_s_sleep(1);
+      if (a.wstamp) tspin += wall_clock64() - tb0;
+      asm volatile("" ::: "memory");
+    }
+    float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
+    f32x16 dqc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
+    asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
+    char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t now; its accumulators are in dqc
     if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
     put_rows(scratch, c, half, dsf);
     const Frag dstf = lds_cols(scratch, tr);
@@ -316,7 +322,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     if (t == nkb - 1 || gpos == last) {                          // this wave's tiles of key block kb are done
       float* pk = a.park + ((int64_t)wave * 64 + lane) * 32;
       if (kb * nkb < g0) {                                       // the block began in the previous wave's range: park this part for it
-        f32x4* pv = reinterpret_cast<f32x4*>(pk);
+        __attribute__((address_space(1))) f32x4* pv = GPTR(f32x4, pk);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           pv[j] = f32x4{dkacc[4 * j], dkacc[4 * j + 1], dkacc[4 * j + 2], dkacc[4 * j + 3]};
@@ -328,7 +334,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
         if ((kb + 1) * nkb - 1 > gpos) {                         // the rest of the block belongs to the next wave: add the part it parked (first
           while (__builtin_amdgcn_readfirstlane(lds_peek(pflag_a + 4 * (wave + 1))) == 0) __builtin_amdgcn_s_sleep(1);     // part + second part)
           asm volatile("" ::: "memory");
-          const f32x4* pv = reinterpret_cast<const f32x4*>(pk + 64 * 32);
+          const __attribute__((address_space(1))) f32x4* pv = GPTR(const f32x4, pk + 64 * 32);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x4 u = pv[j], w = pv[4 + j];
@@ -345,10 +351,10 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
           float b8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) b8[e] = dvacc[8 * gq + e] * a.invK;
-          store8(dV + 16 * gq + 8 * half, b8);
+          g_store8(dV + 16 * gq + 8 * half, b8);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float ik = a.kinv[(int64_t)row * a.H];
+        const float ik = *GPTR(const float, a.kinv + (int64_t)row * a.H);
         const float kmul = LN2 * a.invK;
         const u32x4 kw0 = __builtin_bit_cast(u32x4, kf.v[0]), kw1 = __builtin_bit_cast(u32x4, kf.v[1]);
         float part[2] = {0.f, 0.f};
@@ -359,7 +365,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
             const int i = 8 * gq + e;
             const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
             const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
-            const float ks = a.k_scale[16 * gq + 8 * half + e];
+            const float ks = *GPTR(const float, a.k_scale + 16 * gq + 8 * half + e);
             const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
             const float gk0 = bf2f(f2bf(dkacc[i] * kmul));
             const float uk = kx * rk;
@@ -377,17 +383,17 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
           for (int e = 0; e < 8; ++e) {
             const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
             const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
-            const float ks = a.k_scale[16 * gq + 8 * half + e];
+            const float ks = *GPTR(const float, a.k_scale + 16 * gq + 8 * half + e);
             const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
             a8[e] = ik * (dkacc[8 * gq + e] * ks - (kx * rk) * dot);
           }
-          store8(dK + 16 * gq + 8 * half, a8);
+          g_store8(dK + 16 * gq + 8 * half, a8);
         }
       }
     }
     if (++t == nkb) { t = 0; ++kb; }
   }
-  if (a.wstamp && wave == 0 && lane == 0) *a.wstamp = tspin;
+  if (a.wstamp && wave == 0 && lane == 0) *GPTR(unsigned long long, a.wstamp) = tspin;
   // this item's k_scale-gradient sums: the 32 lanes of a half by an xor tree, then added to the wave's row of the LDS accumulator
 #pragma unroll
   for (int i = 0; i < 16; ++i)
@@ -420,6 +426,48 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
   const float m2 = x.hinfo[2 * h];
   if (DTAB) { for (int i = tid; i < g.ncls; i += NTH1) dtab[i] = 0u; }
   if (tid < 2 * NW1 * 32) sred[tid] = 0.f;
+  {   // etab[w][s] = number of updates of query tile t(w, s) = (P w + s) mod nkb made in steps < s by all waves (see bwd1_steps)
+    int* etab = reinterpret_cast<int*>(sred + 2 * NW1 * 32);
+    const int NT = nkb * nkb;
+    for (int i = tid; i < NW1 * x.P; i += NTH1) {
+      const int w = i / x.P, sidx = i - w * x.P, tt = (x.P * w + sidx) % nkb;
+      int n = 0;
+      for (int w8 = 0; w8 < NW1; ++w8) {
+        const int len = NT - x.P * w8 < x.P ? NT - x.P * w8 : x.P;              // positions of wave w8 (may be <= 0)
+        const int lim = sidx < len ? sidx : len;
+        int f = (tt - x.P * w8) % nkb; f = f < 0 ? f + nkb : f;                  // its first step on tile tt
+        if (f < lim) n += (lim - 1 - f) / nkb + 1;
+      }
+      etab[i] = n;
+    }
+  }
+
+  // One item's load-phase operands (twenty 16-byte pieces per thread)
+  u32x4 oq[NPIECE], ov_[NPIECE], od[NPIECE], oo[NPIECE];
+  float ols[NPIECE];
+  auto issue_item = [&](int seq) {
+    const int64_t so = ((int64_t)h * p.M + (int64_t)seq * L) * D, tok0 = (int64_t)seq * L;
+    const bf16_t* qsl = p.qh + so;
+    const bf16_t* vsl = p.vh + so;
+    const bf16_t* dsl = p.dout + tok0 * p.lddo + h * D;
+    const bf16_t* osl = p.o + tok0 * p.ldo + h * D;
+    const float* lsl = p.lse2 + (int64_t)h * p.M + tok0;
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) {
+      const int pc = k * NTH1 + tid;
+      const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
+      oq[k] = *reinterpret_cast<const u32x4*>(qsl + row * D + ch * 8);
+      ov_[k] = *reinterpret_cast<const u32x4*>(vsl + row * D + ch * 8);
+      od[k] = *reinterpret_cast<const u32x4*>(dsl + (int64_t)row * p.lddo + ch * 8);
+      oo[k] = *reinterpret_cast<const u32x4*>(osl + (int64_t)row * p.ldo + ch * 8);
+      ols[k] = lsl[row];
+    }
+  };
+  float qsv[16];                                                 // q_scale of this lane's 16 head dims (un-prep of q)
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qsv[8 * gq + e] = p.q_scale[16 * gq + 8 * half + e];
 
 #define BWD1_STAMP(i) do { if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + (i)] = wall_clock64(); } while (0)
   for (int it = 0; it < x.ipw; ++it) {
@@ -431,12 +479,8 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     // Q~ slab, dO'' = K w dO (w = exp2(m2 - lse2): the factor between the bounded exponentials and the probabilities; K: the fixed-point scale),
     // -delta'' = -K w sum_d dO O, zeroed dQ^T accumulators, tile counters and park flags
     float K = 1.f, invK = 1.f;
+    issue_item(seq);      // (requesting these an item ahead, under the previous item's dQ un-prep, makes hipcc spill every piece as it lands: 20 serial HBM round trips)
     {
-      const bf16_t* qsl = p.qh + so;
-      const bf16_t* vsl = p.vh + so;
-      const bf16_t* dsl = p.dout + tok0 * p.lddo + h * D;
-      const bf16_t* osl = p.o + tok0 * p.ldo + h * D;
-      const float* lsl = p.lse2 + (int64_t)h * p.M + tok0;
       u32x4 dpc[NPIECE];
       float wrow[NPIECE], drow[NPIECE];
       float mxd = 0.f, mxv = 0.f;
@@ -444,11 +488,8 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
       for (int k = 0; k < NPIECE; ++k) {
         const int pc = k * NTH1 + tid;
         const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(qsl + row * D + ch * 8);
-        const u32x4 vv = *reinterpret_cast<const u32x4*>(vsl + row * D + ch * 8);
-        const u32x4 dv = *reinterpret_cast<const u32x4*>(dsl + (int64_t)row * p.lddo + ch * 8);
-        const u32x4 ov = *reinterpret_cast<const u32x4*>(osl + (int64_t)row * p.ldo + ch * 8);
-        const float ls = lsl[row];
+        const u32x4 qv = oq[k], vv = ov_[k], dv = od[k], ov = oo[k];
+        const float ls = ols[k];
         // (no branch in this loop: a branch would end the basic block and the next piece's loads would wait for this piece's -- five HBM
         // round trips instead of one; a clamped piece re-writes the last piece's bytes)
         *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = qv;
@@ -524,9 +565,10 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
 #pragma unroll
       for (int i = 0; i < 16; ++i) qsacc[i] = 0.f;
       const float scq = p.c * LN2 * invK;
-#pragma unroll
+#pragma nounroll                                                 // (one tile at a time: the next item's operands hold 85 registers through this loop)
       for (int j = 0; j < MAXB; ++j) {
         const int tq = wave + j * NW1;
+        const float iqj = j == 0 ? iq[0] : (j == 1 ? iq[1] : iq[2]);
         if (tq < nkb) {
           const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
           const int64_t tok = tok0 + tq * 32 + ar;               // lane n of the transposed product holds query pi32(n & 31)
@@ -539,13 +581,13 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int i = 8 * gq + e;
-              const float qsv = p.q_scale[16 * gq + 8 * half + e];
-              const float qc = qsv * p.c;
+              const float qsv_ = qsv[i];
+              const float qc = qsv_ * p.c;
               const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
               const float gq0 = bf2f(f2bf(dqt[i * 64 + lane] * scq));
               const float uq = qx[i] * rq;
               qsacc[i] += gq0 * uq;
-              const float gv = gq0 * qsv;
+              const float gv = gq0 * qsv_;
               part[gq] += uq * gv;
               qx[i] = uq; dq[i] = gv;
             }
@@ -555,7 +597,7 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
           for (int gq = 0; gq < 2; ++gq) {
             float a8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a8[e] = iq[j] * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
+            for (int e = 0; e < 8; ++e) a8[e] = iqj * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
             store8(dQ + 16 * gq + 8 * half, a8);
           }
         }
@@ -667,6 +709,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     pl.g = G1{gw, S, (gh - 1) * S + (gw - 1), (65536 + gw - 1) / gw, pl.ncls, gh};
   }
   pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4;
+  // (+ the step table, sized after P below)
   if (pl.shm > 160 * 1024) return false;
   int P = (NT + NW1 - 1) / NW1;
   if (P < nkb) P = nkb;
@@ -676,6 +719,8 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     if (ok) break;
   }
   pl.P = P;
+  pl.shm += (size_t)NW1 * P * 4;
+  if (pl.shm > 160 * 1024) return false;
   const int ncu = ncus1(), total = nseq * H;
   int ipw = (total + ncu - 1) / ncu;
   while (nseq % ipw) ++ipw;                                     // a workgroup stays inside one head
