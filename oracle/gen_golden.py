@@ -268,6 +268,71 @@ def run_full_case(name="full1", c=FULL_CASE, grad_limit=4000, inter_limit=50000,
           f"({os.path.getsize(path) / 1e6:.1f} MB)")
 
 
+# The shape bench.py TIMES: the 12+12 stack at B = 8 (110 592 image tokens, 3.4 rounds of 256-row GEMM tiles, the large-problem dispatch of several
+# kernels).  Forward only (train mode, no_grad: the backward of this size takes the CPU most of an hour); loss, both latents, the logits, every
+# VQ code id and the residual stream at four layer boundaries.  The VQ's EMA update runs (train mode) but nothing read here depends on it.
+FULL8_CASE = dict(FULL_CASE, seed=4, sdepth=12, tdepth=12, batch=8)
+
+
+def run_full8_fwd_case(name="full8_fwd", c=FULL8_CASE, inter_limit=60000):
+    import time
+    t0 = time.time()
+    clip, t, hw = build(c)
+    video, ids, mask = synth_inputs(c)
+    text = ref_shim.TextBatch(ids, mask)
+    sd0 = clip.state_dict()
+    unused = ("_extra.", "to_pixels", "to_patch_emb_first_frame", "pooler.")
+    prints = {k: fingerprint(v) for k, v in sd0.items() if not any(u in k for u in unused)}
+    from tests.helpers import build_model, perturb_1d
+    mine = build_model(c, None, torch.device("cpu"), torch.float32)
+    perturb_1d(mine, c["seed"])
+    sdm = mine.state_dict()
+    for k in prints:
+        if k.endswith("position_ids") or k.endswith("token_type_ids"):
+            continue
+        assert torch.equal(sdm[k], sd0[k]), f"seeded rebuild differs from the reference at {k}"
+    del mine, sdm
+    print(f"[{name}] reference built, seeded rebuild identical ({time.time() - t0:.0f} s)", flush=True)
+    inter, lat, vq_out = {}, {}, {}
+    vt = clip.visual_transformer
+
+    def pre(key):
+        def fn(_m, args):
+            inter[key] = subsample(args[0], inter_limit)
+        return fn
+
+    def keep(key):
+        def fn(_m, _i, o):
+            lat[key] = o.detach().clone()
+        return fn
+
+    def vq_hook(_m, _i, o):
+        vq_out["indices"] = o[1].detach().clone()
+    hs = [vt.enc_spatial_transformer.layers[0][0].register_forward_pre_hook(pre("s0_in")),
+          vt.enc_spatial_transformer.layers[c["sdepth"] // 2][0].register_forward_pre_hook(pre(f"s{c['sdepth'] // 2}_in")),
+          vt.enc_temporal_transformer.layers[0][0].register_forward_pre_hook(pre("t0_in")),
+          vt.enc_temporal_transformer.layers[c["tdepth"] // 2][0].register_forward_pre_hook(pre(f"t{c['tdepth'] // 2}_in")),
+          vt.vq.register_forward_hook(vq_hook),
+          clip.to_text_latent.register_forward_hook(keep("text")), clip.to_visual_latent.register_forward_hook(keep("image"))]
+    clip.train()
+    with torch.no_grad():
+        loss = clip(text, video, return_loss=True, device=torch.device("cpu"))
+    for h in hs:
+        h.remove()
+    print(f"[{name}] train-mode forward done, loss {float(loss):.6f} ({time.time() - t0:.0f} s)", flush=True)
+    # the logits of the loss (ct_clip.py:765-771, 805-811): l2-normalised latents, text rows x image columns, times exp(temperature)
+    tl = torch.nn.functional.normalize(lat["text"], dim=-1)
+    il = torch.nn.functional.normalize(lat["image"], dim=-1)
+    logits = (tl @ il.t()) * clip.temperature.exp()
+    out = dict(config=c, weight_fingerprints=prints, video_fingerprint=fingerprint(video), input_ids=ids, attention_mask=mask,
+               loss=loss.detach().clone(), intermediates=inter, vq_indices=vq_out["indices"].to(torch.int16),
+               text_latents_raw=lat["text"], image_latents_raw=lat["image"], logits=logits.detach().clone())
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: loss={float(loss):.6f} -> {path} ({os.path.getsize(path) / 1e6:.1f} MB, {time.time() - t0:.0f} s)")
+
+
 def run_finetune_case(name="finetune_tiny", base="tiny"):
     """Fixtures for the two fine-tuning loops on the REAL reference towers, tiny configuration
     (same seed / weights / volumes as tiny.pt, which the tests load next to this file).
@@ -410,6 +475,8 @@ if __name__ == "__main__":
             run_full_case()
         elif name == "full2":
             run_full_case("full2", FULL2_CASE, every_layer=True)
+        elif name == "full8_fwd":
+            run_full8_fwd_case()
         elif name == "finetune_tiny":
             run_finetune_case()
         else:

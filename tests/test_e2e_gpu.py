@@ -63,22 +63,23 @@ def test_f32_eval_modes_match_reference(golden, name):
 
 @pytest.mark.parametrize("name", ["tiny", "small"])
 def test_bf16_performance_mode_stays_close(golden, name):
-    """bf16 storage / MFMA inputs, f32 accumulate and statistics.  Tolerance: loss 3e-2 rel (the reference itself under bf16
-    autocast moves by ~1e-2 before the VQ); VQ code agreement reported and bounded."""
+    """bf16 storage / MFMA inputs, f32 accumulate and statistics.  Bounds <= 3x the deviations measured on MI355X (tiny: loss 1.33e-3, small:
+    8.2e-4; code agreement 1.000 at both): loss 4e-3 rel, gradient norm 3e-2 rel, VQ code agreement >= 0.99."""
     g = golden(name)
     clip, text, video = _run(g, torch.bfloat16)
     loss = clip(text, video, return_loss=True, device=DEV)
     rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
-    assert rel < 3e-2, (float(loss), float(g["loss"]))
+    assert rel < 4e-3, (float(loss), float(g["loss"]))
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
-    assert abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"]) < 0.15
+    gn_rel = abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"])
+    assert gn_rel < 3e-2, gn_rel
     clip.eval()
     with torch.no_grad():
         ids = clip.visual_transformer(video, return_only_codebook_ids=True)
     agree = (ids.reshape(g["vq_indices"].shape).cpu() == g["vq_indices"]).float().mean().item()
-    print(f"[{name}] bf16 loss rel err {rel:.2e}, VQ code agreement {agree:.3f}")
-    assert agree > 0.8
+    print(f"[{name}] bf16 loss rel err {rel:.2e}, gradient-norm rel err {gn_rel:.2e}, VQ code agreement {agree:.3f}")
+    assert agree >= 0.99
 
 
 class _SynthDS(torch.utils.data.Dataset):

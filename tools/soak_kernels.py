@@ -113,6 +113,11 @@ dqs2, dks2 = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
 soak("attn2_bwd_tok + unprep_q (round 3: key pass writes row-major dk / dv)",
      lambda: as_list(be.attn2_bwd_tok(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq_t, dkv_t[:, :256], dkv_t[:, 256:], dqs2.zero_(),
                                       dks2.zero_(), nseq, L, True))[:1] + [dq_t, dkv_t, dqs2, dks2])
+dq_f, dkv_f = torch.empty(nseq * L, 256, dtype=bf, device=dev), torch.empty(nseq * L, 512, dtype=bf, device=dev)
+dqs3, dks3 = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
+soak("attn2_bwd_fused (round 4: one pass, LDS tile counters, fixed-point table scatter)",
+     lambda: as_list(be.attn2_bwd_fused(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq_f, dkv_f[:, :256], dkv_f[:, 256:], dqs3.zero_(),
+                                        dks3.zero_(), nseq, L, True)) + [dq_f, dkv_f, dqs3, dks3])
 w_qn, w_kvn = rnd(256, 512, scale=0.05), rnd(512, 512, scale=0.05)
 soak("gemm_headnorm to_q (round 3: attention operands from the epilogue)", lambda: [t for pair in be.gemm_headnorm(x512, w_qn, [(qs, 8.0 * 1.4426950408889634)]) for t in pair])
 soak("gemm_headnorm to_kv", lambda: [t for pair in be.gemm_headnorm(x512, w_kvn, [(ks, 1.0), (None, 1.0)]) for t in pair])
