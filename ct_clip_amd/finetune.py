@@ -222,6 +222,7 @@ class VocabFineTrainer:
         # the quantiser per pathology, in the reference's order (its EMA update after every forward moves the codebook the next one reads);
         # the pooled vectors of all pathologies then go through the 151-M-parameter latent projection as ONE batch (one pass over the
         # 302-MB weight forward, one 604-MB weight-gradient write backward instead of one per pathology)
+        assert b == 1, "the fused VocabFine step pairs pathology j with row j of the stacked latents: one volume per step (ct_vocabfine_train.py batch_size=1); use fused=False for more"
         pooled = []
         for j in range(len(token_pairs)):
             q, _ = vt.vq(pre)

@@ -669,8 +669,18 @@ class PatchEmbedFn(Function):
             s_ = sink_of(param)
             return (s_, True) if s_ is not None else (torch.zeros_like(param, dtype=torch.float32), False)
         (dW, w_sunk), (dg1, g_sunk), (db1, b_sunk) = sink_or_zeros(W), sink_or_zeros(g1), sink_or_zeros(b1)
-        assert w_sunk == g_sunk == b_sunk, "the patch-embedding parameters are registered with the optimiser together or not at all"
-        be.patch_embed_param_bwd(G, W.detach().contiguous(), g1.detach(), b1.detach(), dbp, dW, dg1, db1, accumulate=w_sunk)
+        if w_sunk == g_sunk == b_sunk:
+            be.patch_embed_param_bwd(G, W.detach().contiguous(), g1.detach(), b1.detach(), dbp, dW, dg1, db1, accumulate=w_sunk)
+        else:
+            # a partially registered / partially frozen patch embedding: the kernel accumulates or overwrites all three together, so it runs
+            # into temporaries and the results are added to whichever flat-gradient views exist
+            tW, tg, tb = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(g1, dtype=torch.float32), torch.zeros_like(b1, dtype=torch.float32)
+            be.patch_embed_param_bwd(G, W.detach().contiguous(), g1.detach(), b1.detach(), dbp, tW, tg, tb, accumulate=False)
+            for dst, sunk, t in ((dW, w_sunk, tW), (dg1, g_sunk, tg), (db1, b_sunk, tb)):
+                if sunk:
+                    be.accumulate(dst, t)
+                else:
+                    dst.copy_(t)
         bls = sink_of(bl)
         if bls is not None:
             be.accumulate(bls, dbp)
@@ -698,7 +708,7 @@ class PegFn(Function):
         if comp is None:
             return y
         if e_out is None:      # grids the marching kernels do not serve: plain rounding at this add, the incoming residue travels on
-            e_out = comp.reshape(y.shape) if torch.is_tensor(comp) else torch.zeros_like(y)
+            e_out = comp.reshape(y.shape).clone() if torch.is_tensor(comp) else torch.zeros_like(y)      # (a tensor of its own, as LinearFn / FeedForwardFn)
         ctx.mark_non_differentiable(e_out)
         return y, e_out
 
@@ -958,6 +968,7 @@ def qkv_attention(xn, x_kv, wq, wkv, q_scale, k_scale, bias, nseq, L, H, D, scal
     M, HD = xn.shape[0], H * D
     table = bias is not None and bias_grid is not None
     fused = (xn.dtype == torch.bfloat16 and HD == 256 and D == 32 and M % 256 == 0 and (M // 256) >= 160 and xn.shape[1] % 64 == 0
+             and xn.shape[1] >= 128 and xn.data_ptr() % 16 == 0 and x_kv.data_ptr() % 16 == 0      # (ctclip_gemm_nt_headnorm_try: two k-steps at least, 16-byte rows)
              and (bias is None or table) and not (bias is None and B().attn_short_supported(xn.dtype, L, D))
              and B().attn2_supported(xn.dtype, H, L, D, bias_grid if table else None, table)
              and os.environ.get("CTCLIP_ATTN_FUSED_PREP", "1") != "0")

@@ -131,10 +131,10 @@ int ctclip_pair_softmax_mse(const float* sims, float* loss, float* dsims, int n,
 /* CTCLIP.forward without return_loss (ct_clip.py:771,796,805-807): sims[p] = <l2norm(text_p), l2norm(image_p)> * exp(temperature) with broadcasting (nt == ni, or one side has one row: two prompts against one volume).  dsims null: forward, sims (max(nt, ni)) f32.  dsims non-null: backward, dtext (nt, D), dimage (ni, D), dtemp (1) are overwritten. */
 int ctclip_latent_similarity(const float* text, const float* image, const float* temperature, const float* dsims, float* sims, float* dtext, float* dimage, float* dtemp, int nt, int ni, int D, hipStream_t s);
 
-/* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). */
+/* nn.Linear / F.linear forward, grad-input and grad-weight (attention.py:48,51,119,120,125; ctvit.py:173; ct_clip.py:549,762; HF BERT dense layers). C = alpha*op(A) op(B)^T + bias + residual (+C). With a split over K > 1 (split_k > 1, or auto on f32 output) a workspace of ctclip_gemm_workspace bytes is required (CTCLIP_EWORKSPACE otherwise). */
 int ctclip_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int in_dtype, int out_dtype, int res_dtype, int accumulate, int split_k, float alpha, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* bytes of optional workspace for ctclip_gemm (split-K partial slabs); split_k <= 0 = auto. [workspace query of ctclip_gemm (nn.Linear, attention.py:48,51,119,120,125)] */
+/* bytes of workspace ctclip_gemm needs (split-K partial slabs; 0 when the split is 1); split_k <= 0 = auto. REQUIRED whenever the split is > 1: ctclip_gemm then returns CTCLIP_EWORKSPACE without it (round 3 removed the float-atomic fallback: every reduction is deterministic). [workspace query of ctclip_gemm (nn.Linear, attention.py:48,51,119,120,125)] */
 int64_t ctclip_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int split_k);
 
 /* bytes of workspace ctclip_gemm_argmax needs. [workspace query of ctclip_gemm_argmax (the code search of vector-quantize-pytorch called at ctvit.py:403)] */
