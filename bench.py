@@ -27,6 +27,8 @@ Extra objects on the line:
                   4+4 layers when the time bound allows.
   reference_depth_4+4 -- the same train step with the reference scripts' own 4+4 transformer layers (run_train.py:17-27), timed after the
                   main configuration (--no-reference-depth skips it).
+  text_len_512 -- the same train step at the bench depth with reports padded to 512 tokens, as the reference trainer pads them
+                  (CTCLIPTrainer.py:251; BASELINE.json quotes T = 128); --no-text512 skips it.
 --workload lipro / vocabfine: BASELINE.json configs[4] / configs[3] (one CT-LiPro step at batch 16 with the frozen tower; one VocabFine step =
 one volume x 18 prompt pairs), same contract line with `roofline` and a bounded `cpu_baseline`.
 """
@@ -541,6 +543,10 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help=argparse.SUPPRESS)      # (default on since round 3; kept for old command lines)
     ap.add_argument("--no-reference-depth", action="store_true", help="skip the second timed configuration (reference scripts' 4+4 layers)")
+    ap.add_argument("--with-input-pipeline", action="store_true",
+                    help="feed every step through the device-side input pipeline (pinned int16 ring + copy stream + preprocess kernel, SURVEY 8(f)3); "
+                         "adds an `input_pipeline` object with that configuration's volumes/s (host decode of the NIfTI file excluded)")
+    ap.add_argument("--no-text512", action="store_true", help="skip the extra timed configuration with reports padded to 512 tokens (CTCLIPTrainer.py:251)")
     ap.add_argument("--input-dist", default="uniform", choices=["uniform", "normal"],
                     help="synthetic voxels: uniform [-1, 1] (default) or N(0, 0.3) clamped to [-1, 1] (SURVEY.md 8d: a second distribution, for DVFS honesty)")
     ap.add_argument("--workload", default="train", choices=["train", "lipro", "vocabfine"],
@@ -550,6 +556,8 @@ def main():
                                                                        "instead of one pass of each tower per volume")
     ap.add_argument("--finetune-cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.with_input_pipeline:      # one configuration only: the pipeline's pinned ring and batch buffers are built per run_config
+        args.no_reference_depth = args.no_text512 = True
     if args.workload != "train":      # the fine-tuning scripts build the towers with 4+4 layers (ct_lipro_train.py:47-51, ct_vocabfine_train.py:29-33)
         if "--spatial-depth" not in sys.argv:
             args.spatial_depth = 4
@@ -613,10 +621,45 @@ def main():
         ids, mask = synth_text(args.batch, args.text_len, g, device)
         text = Text(ids, mask)
 
+        pipe = None
+        if getattr(args, "with_input_pipeline", False):
+            # every step's volumes come through the device-side input pipeline -- int16 voxels (512 x 512 x 300 as stored: 157 MB) in
+            # PINNED host memory -> two-slot ring -> H2D on a copy stream -> preprocess kernel writing the (1, 240, 480, 480) f32 model input straight
+            # into the next step's batch buffer, all under the current step.  The host decode of the gz NIfTI file is NOT included (synthetic voxels
+            # are staged once); scripts/data.py:92-162 is the CPU path this replaces.
+            from ct_clip_amd import preprocess as PP
+            shape = (512, 512, 300)
+            up = PP.VolumeUploader(device, max_voxels=shape[0] * shape[1] * shape[2], slots=2, target_shape=(args.image, args.image, args.frames))
+            gh = torch.Generator().manual_seed(77 + rank)
+            for sl in range(2):
+                up.host_buffer(sl).copy_(torch.randint(-1000, 1000, (up.max_voxels,), generator=gh, dtype=torch.int16))
+            bufs = [torch.empty_like(video), torch.empty_like(video)]
+            used = [None, None]                                   # event: the main stream is done with this batch buffer
+
+            def fill(which):
+                if used[which] is not None:
+                    up.stream.wait_event(used[which])
+                # (source spacing chosen so that the 512 x 512 x 300 voxels resample to exactly image x image x frames at 0.75 / 0.75 / 1.5 mm)
+                return [up.submit(None, 1.0, 0.0, 0.75 * args.image / shape[0], 1.5 * args.frames / shape[2], out=bufs[which][b], staged=shape)
+                        for b in range(args.batch)]
+            pipe = {"k": 0, "tickets": fill(0)}
+
         def step():
-            loss = trainer.forward_backward(video, text)
+            vid = video
+            if pipe is not None:
+                cur = pipe["k"] & 1
+                for t_ in pipe["tickets"]:
+                    up.result(t_)
+                vid = bufs[cur]
+                pipe["tickets"] = fill(cur ^ 1)                  # the NEXT step's batch goes up under this step
+            loss = trainer.forward_backward(vid, text)
             trainer.optim.step(trainer.max_grad_norm)
             trainer.optim.zero_grad()
+            if pipe is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                used[pipe["k"] & 1] = ev
+                pipe["k"] += 1
             return loss
 
         for _ in range(warmup):
@@ -712,6 +755,28 @@ def main():
         out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps_ref / dt2, 3), "unit": "volumes/s", "steps": args.steps_ref,
                                       "ms_per_step": round(dt2 / args.steps_ref * 1e3, 3), "loss": round(loss2, 5),
                                       "workload": "the same train step with the reference scripts' 4+4 transformer layers (run_train.py:17-27)"}
+    if args.with_input_pipeline:
+        out["input_pipeline"] = {"value": out["value"], "unit": "volumes/s", "ms_per_step": out["ms_per_step"],
+                                 "note": "THIS line's steps took their volumes through the input pipeline: 8 x 157 MB of int16 voxels (512 x 512 x 300) per step "
+                                         "from pinned host memory through a two-slot ring, H2D + preprocess kernel (rescale, trilinear resample to 0.75 / 0.75 / 1.5 mm, "
+                                         "clip, crop / pad) on a copy stream under the previous step; the gz-NIfTI decode on the host is NOT included "
+                                         "(scripts/data.py:92-162 is the CPU path replaced)"}
+    if not args.no_text512 and args.text_len != 512:
+        # the reference trainer pads every report to 512 tokens (scripts/CTCLIPTrainer.py:251: max_length=512); BASELINE.json quotes T = 128.
+        # The same step (bench depth) with T = 512, fewer timed steps.
+        keep = args.text_len
+        args.text_len = 512
+        try:
+            n3 = max(5, args.steps // 3)
+            dt3, loss3, _, _ = run_config(sdepth, tdepth, n3, max(1, args.warmup), False)
+            out["text_len_512"] = {"value": round(world * args.batch * n3 / dt3, 3), "unit": "volumes/s", "steps": n3,
+                                   "ms_per_step": round(dt3 / n3 * 1e3, 3), "loss": round(loss3, 5),
+                                   "workload": f"the same train step ({sdepth}+{tdepth} layers) with reports padded to 512 tokens as the reference trainer "
+                                               "pads them (CTCLIPTrainer.py:251)"}
+        except Exception as e:      # auxiliary measurement: never lose the headline line to it
+            out["text_len_512"] = {"error": repr(e)[:300]}
+        finally:
+            args.text_len = keep
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline_bounded(args, sdepth, tdepth)

@@ -333,13 +333,17 @@ class HipBackend:
 
     # ------------------------------------------------------------------ input pipeline (csrc/preprocess.hip)
     def preprocess_volume(self, vox, slope, intercept, xy_spacing, z_spacing, target_xy=0.75, target_z=1.5, out_shape=(480, 480, 240),
-                          hu_range=(-1000.0, 1000.0), hu_div=1000.0, pad_value=-1.0):
-        """vox: (H, W, D) int16 / f32 / f64 voxel array on the device -> (1, out_d, out_h, out_w) f32 model input."""
+                          hu_range=(-1000.0, 1000.0), hu_div=1000.0, pad_value=-1.0, out=None):
+        """vox: (H, W, D) int16 / f32 / f64 voxel array on the device -> (1, out_d, out_h, out_w) f32 model input (into `out` when given:
+        a contiguous f32 tensor of that shape, e.g. one volume of a batch buffer)."""
         code = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[vox.dtype]
         assert vox.dim() == 3 and vox.is_contiguous()
         H, W, D = vox.shape
         oh, ow, od = out_shape
-        out = torch.empty((1, od, oh, ow), dtype=torch.float32, device=vox.device)
+        if out is None:
+            out = torch.empty((1, od, oh, ow), dtype=torch.float32, device=vox.device)
+        else:
+            assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == od * oh * ow and out.device == vox.device
         rc = self.lib.ctclip_preprocess_volume(_p(vox), code, H, W, D, float(slope), float(intercept), float(xy_spacing), float(z_spacing),
                                                float(target_xy), float(target_z), _p(out), oh, ow, od, float(hu_range[0]), float(hu_range[1]),
                                                float(hu_div), float(pad_value), _stream())

@@ -45,3 +45,80 @@ def nii_img_to_tensor(path, df, device=None):
     slope, intercept = float(row["RescaleSlope"].iloc[0]), float(row["RescaleIntercept"].iloc[0])
     xy, z = parse_xy_spacing(row["XYSpacing"].iloc[0]), float(row["ZSpacing"].iloc[0])
     return volume_to_tensor(arr, slope, intercept, xy, z, device=device)
+
+
+class VolumeUploader:
+    """The host half of the device-side input pipeline: a ring of PINNED int16 staging buffers and a copy stream, so that the upload (157 MB per
+    512 x 512 x 300 volume: a quarter of the float32 bytes the reference ships, scripts/data.py:92-162) and the preprocessing kernel of volume
+    k + 1 run under whatever the caller's stream does with volume k.
+
+        up = VolumeUploader(device)
+        t = up.submit(voxels, slope, intercept, xy, z)      # returns at once: pinned copy, async H2D, kernel on the copy stream
+        ...                                                 # (the training step of the previous batch)
+        x = up.result(t)                                    # (1, 240, 480, 480) f32; the caller's stream waits for the kernel's event
+
+    Results are bit-identical to `volume_to_tensor` (same kernel, same arguments).  Only int16 voxel arrays take the ring (the stored format of
+    CT-RATE); anything else goes through `volume_to_tensor` synchronously."""
+
+    class Ticket:
+        __slots__ = ("out", "done")
+
+        def __init__(self, out, done):
+            self.out, self.done = out, done
+
+    def __init__(self, device=None, max_voxels=512 * 512 * 640, slots=2, target_shape=TARGET_SHAPE):
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(self.device)
+        self.target_shape = target_shape
+        self.max_voxels = int(max_voxels)
+        self._host = [torch.empty(self.max_voxels, dtype=torch.int16).pin_memory() for _ in range(slots)]
+        self._dev = [torch.empty(self.max_voxels, dtype=torch.int16, device=self.device) for _ in range(slots)]
+        self._copied = [None] * slots        # event: the slot's H2D copy has left the pinned buffer (the host may overwrite it)
+        self._k = 0
+
+    def host_buffer(self, slot):
+        """The pinned staging buffer of a slot (a decoder can write the voxels here directly and pass `staged=n_voxels` to submit)."""
+        return self._host[slot % len(self._host)]
+
+    def submit(self, voxels, slope, intercept, xy_spacing, z_spacing, out=None, staged=None):
+        """voxels: (H, W, D) int16 array (numpy / torch, host).  staged = (H, W, D): the voxels are ALREADY in this call's pinned slot
+        (`host_buffer(k)` of the k-th submit): no host copy.  out: optional (1, D', H', W') f32 destination on the device."""
+        if staged is None:
+            t = torch.as_tensor(voxels)
+            if t.dtype != torch.int16 or t.is_cuda or t.numel() > self.max_voxels:
+                y = volume_to_tensor(voxels, slope, intercept, xy_spacing, z_spacing, device=self.device, target_shape=self.target_shape)
+                if out is not None:
+                    out.copy_(y.view_as(out))
+                    y = out
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                return self.Ticket(y, ev)
+            shape = tuple(t.shape)
+        else:
+            shape = tuple(staged)
+        n = shape[0] * shape[1] * shape[2]
+        s = self._k % len(self._host)
+        self._k += 1
+        if staged is None:
+            if self._copied[s] is not None:
+                self._copied[s].synchronize()            # the previous upload from this pinned buffer has been read by the copy engine
+            self._host[s][:n].copy_(t.contiguous().view(-1))
+        be = _be.get()
+        with torch.cuda.stream(self.stream):
+            # (same stream as the previous kernel that read this slot's device buffer: ordered)
+            self._dev[s][:n].copy_(self._host[s][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._copied[s] = ev
+            y = be.preprocess_volume(self._dev[s][:n].view(shape), slope, intercept, xy_spacing, z_spacing, TARGET_SPACING[0], TARGET_SPACING[2],
+                                     self.target_shape, HU_RANGE, out=out)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return self.Ticket(y, done)
+
+    def result(self, ticket):
+        """The tensor of a submitted volume, ordered behind its kernel on the CALLER's current stream (no host synchronisation)."""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ticket.done)
+        ticket.out.record_stream(cur)
+        return ticket.out

@@ -273,36 +273,9 @@ class CTClipTrainer(nn.Module):
         return logs
 
     def run_validation(self, steps):
-        """The in-training zero-shot check of CTCLIPTrainer.py:266-326 (10 validation volumes x 18 pathologies)."""
-        import numpy as np
-        pathologies = ['Medical material', 'Arterial wall calcification', 'Cardiomegaly', 'Pericardial effusion',
-                       'Coronary artery wall calcification', 'Hiatal hernia', 'Lymphadenopathy', 'Emphysema', 'Atelectasis',
-                       'Lung nodule', 'Lung opacity', 'Pulmonary fibrotic sequela', 'Pleural effusion',
-                       'Mosaic attenuation pattern', 'Peribronchial thickening', 'Consolidation', 'Bronchiectasis',
-                       'Interlobular septal thickening']
-        model = self.CTClip
-        model.eval()
-        predictedall, realall = [], []
-        with torch.no_grad():
-            for _ in range(10):
-                valid_data, text, onehotlabels, name_acc = next(self.valid_dl_iter)
-                valid_data = valid_data.to(self.device)
-                predicted = []
-                for pathology in pathologies:
-                    tokens = self.tokenize([f"There is {pathology}.", f"There is no {pathology}."])
-                    out = torch.softmax(model(tokens, valid_data, device=self.device), dim=0)
-                    predicted.append(float(out[0]))
-                predictedall.append(predicted)
-                realall.append(onehotlabels.detach().cpu().numpy()[0])
-        model.train()
-        plotdir = str(self.results_folder / f"CTClip_{steps}") + "/"
-        Path(plotdir).mkdir(parents=True, exist_ok=True)
-        try:
-            from eval import evaluate_internal  # the reference's scripts/eval.py
-            evaluate_internal(np.array(predictedall), np.array(realall), pathologies, plotdir)
-        except ImportError:
-            np.save(plotdir + "predicted.npy", np.array(predictedall))
-            np.save(plotdir + "labels.npy", np.array(realall))
+        """Reference-compatibility glue, not part of the hot path: see ct_clip_amd/validation.py."""
+        from .validation import run_validation
+        return run_validation(self, steps)
 
     def train(self, log_fn=noop):
         while self.steps < self.num_train_steps:

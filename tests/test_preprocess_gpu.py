@@ -71,3 +71,39 @@ def test_nii_img_to_tensor_drop_in(monkeypatch):
         want = PO.volume_to_tensor(arr, slope, inter, xy, z)
         assert got.shape == (1, 240, 480, 480)
         torch.testing.assert_close(got, want, rtol=0, atol=2e-7)
+
+
+def test_pinned_ring_pipeline_equals_synchronous_path():
+    """The host half of the input pipeline (ct_clip_amd.preprocess.VolumeUploader: pinned two-slot int16 ring + copy stream): volume k + 1 is
+    uploaded and preprocessed under the main stream's work on volume k; every output equals the synchronous `volume_to_tensor` bit for bit,
+    also when the ring wraps (5 volumes through 2 slots), with a pre-staged pinned buffer, into a caller-provided batch slot, and for a
+    non-int16 source (synchronous fallback)."""
+    from oracle import preprocess_oracle as PO
+    from ct_clip_amd import preprocess as PP
+    target = (48, 40, 24)
+    up = PP.VolumeUploader(DEV, max_voxels=64 * 64 * 40, slots=2, target_shape=target)
+    cases = [(PO.synthetic_volume(30 + i, sh), 0.8 + 0.1 * i, -500.0 + 7 * i, xy, z)
+             for i, (sh, xy, z) in enumerate([((40, 30, 50), 0.75, 1.5), ((37, 41, 23), 1.3, 2.2), ((64, 64, 30), 0.5, 1.0), ((9, 7, 5), 2.0, 5.0),
+                                              ((50, 33, 40), 0.9, 1.1)])]
+    want = [PP.volume_to_tensor(v, s, i, xy, z, device=DEV, target_shape=target) for v, s, i, xy, z in cases]
+    a, b = torch.randn(2048, 2048, device=DEV), torch.randn(2048, 2048, device=DEV)
+    batch = torch.empty((len(cases), 1, target[2], target[0], target[1]), dtype=torch.float32, device=DEV)
+    tick = up.submit(*cases[0], out=batch[0])
+    for k in range(len(cases)):
+        nxt = up.submit(*cases[k + 1], out=batch[k + 1]) if k + 1 < len(cases) else None      # volume k + 1 goes up ...
+        for _ in range(3):
+            a = (a @ b) * 1e-3                                                                  # ... under the "step" of volume k
+        got = up.result(tick)
+        assert got.data_ptr() == batch[k].data_ptr()
+        assert torch.equal(got.view_as(want[k]), want[k]), k
+        tick = nxt
+    # a decoder that writes straight into the pinned slot
+    v, s, i, xy, z = cases[2]
+    slot = up._k
+    up.host_buffer(slot)[:v.size].copy_(torch.as_tensor(v).view(-1))
+    got = up.result(up.submit(None, s, i, xy, z, staged=v.shape))
+    assert torch.equal(got, want[2])
+    # float sources take the synchronous path with the same result
+    vf = (cases[1][0].astype(np.float64) * 0.61)
+    got = up.result(up.submit(vf, *cases[1][1:]))
+    assert torch.equal(got, PP.volume_to_tensor(vf, *cases[1][1:], device=DEV, target_shape=target))

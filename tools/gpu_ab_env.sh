@@ -7,7 +7,7 @@ A="$1"; B="$2"; N=${3:-20}
 for r in 1 2; do
   for side in A B; do
     E="${!side}"
-    env $E timeout 600 python bench.py --steps $N --warmup 3 --no-cpu-baseline --no-pmc --no-reference-depth --profile-steps 0 > $O/${side}${r}.json 2> $O/${side}${r}.err
+    env $E timeout 600 python bench.py --steps $N --warmup 3 --no-cpu-baseline --no-pmc --no-reference-depth --no-text512 --profile-steps 0 > $O/${side}${r}.json 2> $O/${side}${r}.err
     python - <<PY
 import json
 try:

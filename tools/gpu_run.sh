@@ -26,7 +26,7 @@ print("  ms/step", b["ms_per_step"], "value", b["value"], "| roofline", r.get("k
 PY
       ;;
     prof)   # per-kernel durations with the weight-gradient stream off (one kernel per duration)
-      (cd /tmp && CTCLIP_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-attn-block --no-reference-depth > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err)
+      (cd /tmp && CTCLIP_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-attn-block --no-reference-depth --no-text512 > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err)
       python - <<'PY' > $O/prof_stats.md 2>&1
 import csv, glob, re, collections
 rows = collections.defaultdict(list)
