@@ -543,6 +543,9 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help=argparse.SUPPRESS)      # (default on since round 3; kept for old command lines)
     ap.add_argument("--no-reference-depth", action="store_true", help="skip the second timed configuration (reference scripts' 4+4 layers)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the optimisation step into a hipGraph after the warm-up steps and time replays (N = 1 only; falls back to eager "
+                         "launches if the capture fails); the line says which in config.launch")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="feed every step through the device-side input pipeline (pinned int16 ring + copy stream + preprocess kernel, SURVEY 8(f)3); "
                          "adds an `input_pipeline` object with that configuration's volumes/s (host decode of the NIfTI file excluded)")
@@ -664,6 +667,20 @@ def main():
 
         for _ in range(warmup):
             loss = step()
+        graphed = None
+        if getattr(args, "graph", False) and world == 1 and pipe is None:
+            # the whole optimisation step captured once into a hipGraph and replayed (ct_clip_amd.trainer.GraphedStep): the device work is
+            # the same kernels in the same order; what changes is the host's share (~1 900 launches through Python + ctypes per step)
+            from ct_clip_amd.trainer import GraphedStep
+            try:
+                graphed = GraphedStep(trainer).capture(video, text)
+                step = lambda: graphed.run()      # noqa: E731
+                step()
+            except Exception as e:                # never lose the measurement to the capture: eager steps are always valid
+                print(f"bench: hipGraph capture failed, staying eager: {e!r}", file=sys.stderr)
+                if graphed is not None:
+                    graphed.close()
+                graphed = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -676,6 +693,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        run_config.graphed = graphed is not None
+        if graphed is not None:
+            graphed.close()
+            args.profile_steps = 0                # (the per-launch GEMM timing needs eager launches)
         timing = None
         if profile_gemm and args.profile_steps > 0:
             # Per-launch durations for `roofline`: the timed steps run the weight-gradient GEMMs on a side stream UNDER the grad-input
@@ -708,6 +729,7 @@ def main():
         return float(t[0]), lossv, timing, peak_mem
 
     dt, lossv, timing, peak_mem = run_config(args.spatial_depth, args.temporal_depth, args.steps, args.warmup, True)
+    main_graphed = getattr(run_config, "graphed", False)
     sdepth, tdepth = args.spatial_depth, args.temporal_depth
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
@@ -723,7 +745,8 @@ def main():
                                f"{sdepth}+{tdepth} layers + BERT-base T={args.text_len}, batch {args.batch}/GPU, global batch {world * args.batch}, "
                                "gathered-negatives InfoNCE, grad clip 0.5, Adam",
                    "global_batch": world * args.batch, "text_len": args.text_len, "parallelism": f"dp{world}",
-                   "layers": f"{sdepth}+{tdepth}"},
+                   "layers": f"{sdepth}+{tdepth}",
+                   "launch": "hipGraph replay of the captured step (ct_clip_amd.trainer.GraphedStep)" if main_graphed else "eager launches (Python + ctypes per kernel)"},
         "loss": round(lossv, 5),
         "model_tflops_per_step_per_gpu": round(train_flops * args.batch / 1e12, 2),
         "model_tflops_per_s_per_gpu": round(train_flops * args.batch / 1e12 / (ms / 1e3), 1),
@@ -754,7 +777,8 @@ def main():
         args.steps_ref = max(5, args.steps // 3)
         out["reference_depth_4+4"] = {"value": round(world * args.batch * args.steps_ref / dt2, 3), "unit": "volumes/s", "steps": args.steps_ref,
                                       "ms_per_step": round(dt2 / args.steps_ref * 1e3, 3), "loss": round(loss2, 5),
-                                      "workload": "the same train step with the reference scripts' 4+4 transformer layers (run_train.py:17-27)"}
+                                      "workload": "the same train step with the reference scripts' 4+4 transformer layers (run_train.py:17-27)",
+                                      "launch": "hipGraph replay" if getattr(run_config, "graphed", False) else "eager"}
     if args.with_input_pipeline:
         out["input_pipeline"] = {"value": out["value"], "unit": "volumes/s", "ms_per_step": out["ms_per_step"],
                                  "note": "THIS line's steps took their volumes through the input pipeline: 8 x 157 MB of int16 voxels (512 x 512 x 300) per step "

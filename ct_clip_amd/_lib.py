@@ -46,6 +46,8 @@ SIGNATURES = {
     "ctclip_gemm_dgeglu": (_I, [_P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_gemm_residual_comp": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_attn2_bwd_tok_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "ctclip_set_step_state": (_I, [_P]),
+    "ctclip_advance_step_state": (_I, [_P, _P]),
     "ctclip_attn2_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "ctclip_attn2_bwd_fused_workspace": (_L, [_I, _I, _I, _I, _I]),
     "ctclip_attn2_bwd_fused": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P]),

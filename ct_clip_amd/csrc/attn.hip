@@ -92,7 +92,7 @@ struct AttnParams {
   const void *q, *k, *v, *qt, *kt, *vt, *o, *dout, *dot;
   const float *bias, *keymask, *lse, *delta;
   float drop_p, drop_inv_keep;   // attention-probability dropout (HF BertSelfAttention, train mode); 0 = off
-  uint64_t drop_seed;
+  uint64_t drop_seed; const unsigned long long* drop_state;      // (drop_state: device-resident seed offset, ctclip_set_step_state)
   const float* bias_tab;   // relative-position form of the bias: (nclass, H) table, class(i, j) below; replaces `bias`
   int gh, gw;              // token grid of the sequence (L = gh * gw) when bias_tab is set
   void *out, *dq, *dk, *dv;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void rel_stage(RelLds& rel, const AttnParams& p, int 
 // (ctclip_attn_dropout_mask materialises the same values), so forward, dQ and dK/dV regenerate identical masks
 __device__ __forceinline__ float attn_drop(const AttnParams& p, int seq, int h, int qi, int kj) {
   const uint64_t lin = (((uint64_t)seq * p.H + h) * p.L + qi) * p.L + kj;
-  return dropout_mult(philox4x32(p.drop_seed, lin, 0u)[0], p.drop_p, p.drop_inv_keep);
+  return dropout_mult(philox4x32(p.drop_seed + (p.drop_state ? p.drop_state[0] : 0ull), lin, 0u)[0], p.drop_p, p.drop_inv_keep);
 }
 
 // scores of one 32x32 tile in "lane = column c, regs = rows slot_index(r, half)" layout -> logits
@@ -1308,7 +1308,7 @@ static int set_bias(AttnParams& p, const float* bias, int bias_gh, int bias_gw, 
 // (dropout_p, dropout_seed) must be passed to ctclip_attn_bwd.
 static int set_dropout(AttnParams& p, float dropout_p, uint64_t dropout_seed) {
   if (dropout_p < 0.f || dropout_p >= 1.f) { ctclip_set_error("attention: 0 <= dropout_p < 1"); return CTCLIP_EBADARG; }
-  p.drop_p = dropout_p; p.drop_inv_keep = 1.f / (1.f - dropout_p); p.drop_seed = dropout_seed;
+  p.drop_p = dropout_p; p.drop_inv_keep = 1.f / (1.f - dropout_p); p.drop_seed = dropout_seed; p.drop_state = ctclip_step_state();
   return 0;
 }
 

@@ -21,6 +21,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 extern "C" void ctclip_set_error(const char* msg);
 int ctclip_check_launch(const char* what);
+// Device-resident step state (capi.hip: ctclip_set_step_state): null, or two 64-bit words { seed offset, optimiser step } that the dropout /
+// attention-dropout / Adam kernels read AT RUN TIME -- what lets a captured hipGraph of the training step draw fresh dropout masks and use the
+// right bias correction on every replay (scalars passed by value are frozen into the graph).
+const unsigned long long* ctclip_step_state(void);
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // f32 -> bf16 through the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving).  The integer

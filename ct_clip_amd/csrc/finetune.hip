@@ -10,7 +10,8 @@ namespace {
 
 // y = relu(x) * dropout_mask ; the mask is philox(seed, element group, stream) as in ctclip_dropout
 __global__ void relu_dropout_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int64_t n4, float p,
-                                    float inv_keep, uint64_t seed, uint32_t stream) {
+                                    float inv_keep, uint64_t seed, uint32_t stream, const unsigned long long* __restrict__ st) {
+  if (st) seed += st[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const u32x4 w = philox4x32(seed, (uint64_t)i, stream);
     const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void latent_similarity_kernel(const float* __r
 extern "C" int ctclip_relu_dropout(const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed, uint32_t stream_id, hipStream_t s) {
   if (!x || !out || n % 4 || p < 0.f || p >= 1.f) { ctclip_set_error("relu_dropout: n % 4 == 0, 0 <= p < 1"); return CTCLIP_EBADARG; }
   int64_t nb = cdiv(n / 4, 256); if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(relu_dropout_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, out, n / 4, p, 1.f / (1.f - p), seed, stream_id);
+  hipLaunchKernelGGL(relu_dropout_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, out, n / 4, p, 1.f / (1.f - p), seed, stream_id, ctclip_step_state());
   return ctclip_check_launch("relu_dropout");
 }
 

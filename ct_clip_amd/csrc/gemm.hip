@@ -312,7 +312,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const int64_t n = M * N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float t = 0.f;
-    for (int s = 0; s < nsplit; ++s) t += slab[(int64_t)s * n + i];
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {                        // four slabs in flight, added in slab order
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = slab[(int64_t)(s + k) * n + i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t += v[k];
+    }
+    for (; s < nsplit; ++s) t += slab[(int64_t)s * n + i];
     float* c = C + (i / N) * ldc + i % N;
     *c = accumulate ? *c + t : t;
   }

@@ -69,7 +69,10 @@ __global__ void leaky_bwd_kernel(const float* __restrict__ dy, const float* __re
 }
 
 // ---- out[n] += sum_m x[m][n]   (bias gradients).  block: 32 column-groups of 8 x 8 row lanes; 512 rows per block
-template <typename T>
+// ROWS rows per workgroup (eight row lanes x ROWS / 8 steps).  Small M (the text tower: M = B T = 1024, 73 bias gradients per step) takes
+// ROWS = 64: sixteen row blocks instead of two, and a thread's eight loads are all in flight (round 3: 512 rows = 64 dependent-latency
+// iterations on 6-24 workgroups, 40 us per launch for a 3-MB read).
+template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ part, int64_t M, int N, int64_t ld) {
   __shared__ float red[8][256];
   const int cgp = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -78,12 +81,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (c < N) {
-    const int64_t r0 = (int64_t)blockIdx.x * 512;
-    for (int64_t r = r0 + rl; r < r0 + 512 && r < M; r += 8) {
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+#pragma unroll 8
+    for (int i = 0; i < ROWS / 8; ++i) {
+      int64_t r = r0 + rl + 8 * i;
+      const bool ok = r < M;
+      r = ok ? r : M - 1;                                  // (clamped, masked below: never branch around a load)
       float v[8];
       load8(x + r * ld + c, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += ok ? v[e] : 0.f;
     }
   }
 #pragma unroll
@@ -102,7 +109,15 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= N) return;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * N + col];
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {                            // eight partials in flight, added in block order
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)(b + k) * N + col];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += v[k];
+  }
+  for (; b < nblk; ++b) t += part[(int64_t)b * N + col];
   out[col] += t;
 }
 
@@ -231,7 +246,8 @@ __global__ void cpb_reduce_kernel(const float* __restrict__ dbias, float* __rest
 //      The same call with dy in place of x is the backward.
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n4, float p, float inv_keep,
-                               uint64_t seed, uint32_t stream) {
+                               uint64_t seed, uint32_t stream, const unsigned long long* __restrict__ st) {
+  if (st) seed += st[0];                                     // (device-resident step state: see ctclip_set_step_state)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const u32x4 w = philox4x32(seed, (uint64_t)i, stream);
     float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
@@ -334,7 +350,8 @@ extern "C" int ctclip_leaky_relu_bwd(const float* dy, const float* x, float* dx,
   return ctclip_check_launch("leaky_relu_bwd");
 }
 // out (f32, N) += column sums of x (M, N)
-extern "C" int64_t ctclip_colsum_workspace(int64_t M, int N) { return cdiv(M, 512) * (int64_t)N * 4; }
+static inline int colsum_rows(int64_t M) { return M <= 16384 ? 64 : 512; }
+extern "C" int64_t ctclip_colsum_workspace(int64_t M, int N) { return cdiv(M, colsum_rows(M)) * (int64_t)N * 4; }
 // out[0:N] += column sums of x (M, N) -- bias gradients of the Linear layers.  Two stages with a fixed summation order (the first
 // version added per-block partial sums with f32 atomics); workspace >= ctclip_colsum_workspace(M, N) bytes.
 extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* workspace, int64_t workspace_bytes,
@@ -348,9 +365,11 @@ extern "C" int ctclip_colsum(const void* x, float* out, int64_t M, int N, int64_
     dim3 gridg((unsigned)nblk, (unsigned)cdiv(N, 64));
     BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_generic_kernel<T>, gridg, dim3(256), 0, s, (const T*)x, part, M, N, ld));
   } else {
-    nblk = (int)cdiv(M, 512);
+    const int rows = colsum_rows(M);
+    nblk = (int)cdiv(M, rows);
     dim3 grid((unsigned)nblk, (unsigned)cdiv(N, 256));
-    BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, part, M, N, ld));
+    if (rows == 64) { BY_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T, 64>), grid, dim3(256), 0, s, (const T*)x, part, M, N, ld)); }
+    else { BY_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T, 512>), grid, dim3(256), 0, s, (const T*)x, part, M, N, ld)); }
   }
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, (const float*)part, nblk, N, out);
   return ctclip_check_launch("colsum");
@@ -405,7 +424,7 @@ extern "C" int ctclip_dropout(const void* x, const void* residual, void* y, int6
                               int dtype, hipStream_t s) {
   if (!x || !y || n % 4 || p < 0.f || p >= 1.f) { ctclip_set_error("dropout: n % 4 == 0, 0 <= p < 1"); return CTCLIP_EBADARG; }
   const float inv_keep = 1.f / (1.f - p);
-  BY_DTYPE(dtype, hipLaunchKernelGGL(dropout_kernel<T>, grid_for(n / 4), dim3(256), 0, s, (const T*)x, (const T*)residual, (T*)y, n / 4, p, inv_keep, seed, stream_id));
+  BY_DTYPE(dtype, hipLaunchKernelGGL(dropout_kernel<T>, grid_for(n / 4), dim3(256), 0, s, (const T*)x, (const T*)residual, (T*)y, n / 4, p, inv_keep, seed, stream_id, ctclip_step_state()));
   return ctclip_check_launch("dropout");
 }
 // mask[(seq, h, i, j)] = the multiplier ctclip_attn_fwd/bwd apply to attention probability (seq, h, i, j) for (p, seed): 0 or 1/(1-p)

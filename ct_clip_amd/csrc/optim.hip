@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
                                                    float bc1, float bc2_sqrt, float weight_decay, const float* __restrict__ clip,
-                                                   const uint8_t* __restrict__ decay_mask4) {
+                                                   const uint8_t* __restrict__ decay_mask4, const unsigned long long* __restrict__ st) {
+  if (st) {                                                  // the step count lives on the device (a replayed hipGraph): bias corrections from it
+    const float t = (float)st[1];
+    bc1 = 1.f - powf(beta1, t);
+    bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+  }
   const float cs = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   const int64_t n4 = n / 4;
@@ -108,6 +113,6 @@ extern "C" int ctclip_adam_step(float* p, const float* g, float* m, float* v, in
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   int64_t nb = cdiv(n / 4 + 1, 256); if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, weight_decay, clip, decay_mask4);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, weight_decay, clip, decay_mask4, ctclip_step_state());
   return ctclip_check_launch("adam_step");
 }

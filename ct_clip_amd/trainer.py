@@ -127,6 +127,59 @@ class FusedAdam:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+class GraphedStep:
+    """One optimisation step (forward, backward, gradient clip, Adam, weight-shadow refresh, zero_grad) captured ONCE into a hipGraph and
+    replayed: the ~1 900 kernel launches of a step cost the host 42 ms to enqueue through Python + ctypes, a graph launch costs microseconds
+    (the reference is eager PyTorch, scripts/CTCLIPTrainer.py:249-264: it has no counterpart).  What varies from step to step and would be
+    frozen by the capture lives on the device: the dropout seed offset and the optimiser step (ctclip_set_step_state), advanced by the first
+    kernel of the graph; the batch is copied into static input tensors.  Single process only (collectives are not captured).
+
+        gs = GraphedStep(trainer); gs.capture(video, text)        # after >= 3 eager warm-up steps
+        loss = gs.run(video, text)                                  # every later step
+
+    While a GraphedStep is live every Adam launch of the PROCESS reads the device step: do not mix eager optimiser steps in; `close()`."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+        self.graph = None
+
+    def capture(self, video, text):
+        be = _be.get()
+        t = self.t
+        dev = video.device
+        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.state[1] = t.optim.step_count
+        _be._lib.check(be.lib.ctclip_set_step_state(self.state.data_ptr()), "ctclip_set_step_state")
+        self.video = video.clone()
+        self.ids, self.mask = text.input_ids.clone(), text.attention_mask.clone()
+        self.text = type(text)(self.ids, self.mask) if not hasattr(text, "_replace") else text._replace(input_ids=self.ids, attention_mask=self.mask)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            _be._lib.check(be.lib.ctclip_advance_step_state(self.state.data_ptr(), _be._stream()), "ctclip_advance_step_state")
+            self.loss = t.forward_backward(self.video, self.text)
+            t.optim.step(t.max_grad_norm)
+            t.optim.zero_grad()
+        torch.cuda.synchronize(dev)
+        # the capture only RECORDED the step (nothing ran): state and step counter are where the first replay expects them
+        t.optim.step_count -= 1
+        return self
+
+    def run(self, video=None, text=None):
+        if video is not None and video.data_ptr() != self.video.data_ptr():
+            self.video.copy_(video, non_blocking=True)
+        if text is not None and text.input_ids.data_ptr() != self.ids.data_ptr():
+            self.ids.copy_(text.input_ids, non_blocking=True)
+            self.mask.copy_(text.attention_mask, non_blocking=True)
+        self.graph.replay()
+        self.t.optim.step_count += 1
+        return self.loss
+
+    def close(self):
+        _be.get().lib.ctclip_set_step_state(None)
+        self.graph = None
+
+
 class CTClipTrainer(nn.Module):
     def __init__(self, CTClip, *, num_train_steps, batch_size, data_train="train", data_valid="valid",
                  reports_file_train="data_reports.xslx", reports_file_valid="data_reports.xslx",

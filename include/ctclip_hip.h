@@ -107,6 +107,12 @@ int ctclip_abi_version(void);
 /* "gfx950".  [C-ABI plumbing, no reference counterpart] */
 const char* ctclip_target_arch(void);
 
+/* state: two 64-bit words in DEVICE memory { dropout seed offset, optimiser step } or NULL (off, the default). While set, ctclip_dropout / ctclip_relu_dropout / ctclip_attn_fwd / ctclip_attn_bwd add state[0] to the seed they are given and ctclip_adam_step takes its step count from state[1], read when the kernels RUN: a captured hipGraph of the training step replays with fresh dropout masks and the right bias correction. Process-wide; the caller keeps the memory alive. [no reference counterpart: the reference is eager PyTorch (CTCLIPTrainer.py:249-264), its RNG and step counters live on the host] */
+int ctclip_set_step_state(const void* state);
+
+/* state[0] += an odd 64-bit constant, state[1] += 1 in one launch (put it first in the captured step). [no reference counterpart: see ctclip_set_step_state] */
+int ctclip_advance_step_state(void* state, hipStream_t s);
+
 /* x + PEG(x): causal-padded depthwise Conv3d 3x3x3 (attention.py:56-84,324). */
 int ctclip_peg_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int D1, int D2, int D3, int C, int dtype, hipStream_t stream);
 

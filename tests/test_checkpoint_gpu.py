@@ -96,3 +96,50 @@ def test_ctclip_load_accepts_the_ddp_prefixed_checkpoint(golden, tmp_path):
         with torch.no_grad():
             got = other(text, g["video"].to(DEV), device=DEV, return_latents=True)[1]
         assert torch.equal(got, want), path
+
+
+def test_graphed_step_replays_the_eager_step_bit_for_bit(golden, tmp_path):
+    """ct_clip_amd.trainer.GraphedStep: the optimisation step captured once into a hipGraph.  With dropout off the step is a pure function of
+    (weights, moments, step count, batch): three replays after three eager warm-up steps leave the flat f32 parameters, both Adam moments and the
+    VQ buffers BIT-IDENTICAL to six eager steps (the step count that feeds Adam's bias correction lives on the device and advances inside the
+    graph).  With dropout on, consecutive replays draw different masks (the seed offset advances too): the losses differ."""
+    import ct_clip_amd
+    from ct_clip_amd.trainer import GraphedStep
+    g = golden("tiny")
+    c = g["config"]
+    text = TextBatch(g["input_ids"].to(DEV), g["attention_mask"].to(DEV))
+    video = g["video"].to(DEV)
+
+    def run(n_eager, n_graph, dropout, lr=1e-3):
+        clip = build_model(c, g["state_dict"], DEV, torch.bfloat16)
+        clip.text_transformer.config.hidden_dropout_prob = dropout
+        clip.text_transformer.config.attention_probs_dropout_prob = dropout
+        clip.train()
+        tr = ct_clip_amd.CTClipTrainer(clip, num_train_steps=10, batch_size=2, tokenizer=object(), lr=lr, train_dataset=[0], evaluate=False,
+                                       checkpoint=False, results_folder=str(tmp_path / f"res{n_graph}{dropout}"), num_workers=0)
+        torch.manual_seed(11)
+        losses = []
+        for _ in range(n_eager):
+            loss = tr.forward_backward(video, text)
+            tr.optim.step(tr.max_grad_norm)
+            tr.optim.zero_grad()
+            losses.append(float(loss))
+        if n_graph:
+            gs = GraphedStep(tr).capture(video, text)
+            try:
+                for _ in range(n_graph):
+                    losses.append(float(gs.run()))
+            finally:
+                gs.close()
+        torch.cuda.synchronize()
+        sd = clip.state_dict()
+        return (losses, tr.optim.flat_param.clone(), tr.optim.exp_avg.clone(), tr.optim.exp_avg_sq.clone(),
+                {k: v.clone() for k, v in sd.items() if "_codebook" in k}, tr.optim.step_count)
+    la, pa, ma, va, qa, na = run(6, 0, 0.0)
+    lb, pb, mb, vb, qb, nb = run(3, 3, 0.0)
+    assert na == nb == 6
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert all(torch.equal(qa[k], qb[k]) for k in qa)
+    lc = run(3, 3, 0.1)[0]
+    assert len(set(lc[3:])) == 3, lc          # fresh dropout masks per replay (and a moving model)
