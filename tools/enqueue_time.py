@@ -39,4 +39,19 @@ for _ in range(steps):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
-print(f"enqueue {sum(enq) / len(enq):.1f} ms (min {min(enq):.1f}) of {sum(tot) / len(tot):.1f} ms per step, synchronised after every step")
+print(f"eager: enqueue {sum(enq) / len(enq):.1f} ms (min {min(enq):.1f}) of {sum(tot) / len(tot):.1f} ms per step, synchronised after every step")
+# the same step captured into a hipGraph (ct_clip_amd.trainer.GraphedStep): what the host pays per step then
+from ct_clip_amd.trainer import GraphedStep  # noqa: E402
+gs = GraphedStep(trainer).capture(video, text)
+gs.run()
+torch.cuda.synchronize()
+enq, tot = [], []
+for _ in range(steps):
+    t0 = time.perf_counter()
+    gs.run()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+gs.close()
+print(f"hipGraph replay: enqueue {sum(enq) / len(enq):.2f} ms (min {min(enq):.2f}) of {sum(tot) / len(tot):.1f} ms per step, synchronised after every step")
