@@ -444,3 +444,84 @@ def test_short_attention_lane_maps():
     for lane in range(64):
         assert np.allclose(dKt[lane], [(dS.T @ Q)[lane & 31, d] for d in M.dims(lane >> 5)])
         assert np.allclose(dVt[lane], [(P.T @ dO)[lane & 31, d] for d in M.dims(lane >> 5)])
+
+
+# ---------------------------------------------------------------------------------------------------------------- attn2_bwd1.hip (round 4)
+def _bwd1_plan(nkb, nw=8):
+    """plan1() of csrc/attn2_bwd1.hip: positions per wave = the smallest P >= max(ceil(nkb^2 / 8), nkb) with P d != 0 (mod nkb) for d = 1..7"""
+    nt = nkb * nkb
+    p = max((nt + nw - 1) // nw, nkb)
+    while any((p * d) % nkb == 0 for d in range(1, nw)):
+        p += 1
+    return nt, p
+
+
+def test_bwd1_tile_schedule_properties():
+    """The one-pass attention backward walks the nkb x nkb score tiles row-major (key block, query tile); wave w owns positions [P w, P w + P).
+    For every supported nkb (L = 256 .. 576): every tile exactly once; in every step the eight waves are on eight DIFFERENT query tiles (so the
+    read-modify-write of dQ^T[t] never collides); a key block is shared by at most two waves; and the tabulated number of earlier updates of a
+    tile (etab, bwd1_body) equals a brute-force count -- the tile counters then admit the updates of a tile in step order."""
+    for nkb in range(8, 19):
+        nt, p = _bwd1_plan(nkb)
+        pos = lambda w, s: p * w + s
+        seen = {}
+        for w in range(8):
+            for s in range(p):
+                g = pos(w, s)
+                if g < nt:
+                    assert g not in seen
+                    seen[g] = (w, s)
+        assert sorted(seen) == list(range(nt)), nkb
+        for s in range(p):
+            tiles = [pos(w, s) % nkb for w in range(8) if pos(w, s) < nt]
+            assert len(set(tiles)) == len(tiles), (nkb, s, tiles)
+        for kb in range(nkb):
+            owners = {seen[kb * nkb + t][0] for t in range(nkb)}
+            assert len(owners) <= 2 and (len(owners) == 1 or max(owners) - min(owners) == 1), (nkb, kb, owners)
+        # etab[w][s]: closed form of the kernel vs brute force
+        for w in range(8):
+            for s in range(p):
+                if pos(w, s) >= nt:
+                    continue
+                tt = pos(w, s) % nkb
+                brute = sum(1 for w8 in range(8) for s8 in range(s) if pos(w8, s8) < nt and pos(w8, s8) % nkb == tt)
+                n = 0
+                for w8 in range(8):
+                    ln = min(max(nt - p * w8, -10 ** 9), p)
+                    lim = min(s, ln)
+                    f = (tt - p * w8) % nkb
+                    if f < lim:
+                        n += (lim - 1 - f) // nkb + 1
+                assert n == brute, (nkb, w, s, n, brute)
+
+
+def test_bwd1_fixed_point_rounding_and_class_counts():
+    """The table gradient is scattered as integers: round(x) = the low mantissa bits of float32(x + 1.5 * 2^23) for |x| < 2^22 (round to nearest
+    even, like the FMA that produces it), 576 addends of magnitude < 2^21 stay below 2^31, and the number of (query, key) pairs of an offset class
+    -- subtracted as count x bits(1.5 * 2^23) when the table is flushed -- is (gh - |dy|)(gw - |dx|)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-2 ** 21, 2 ** 21, 200000), rng.uniform(-4, 4, 50000), np.array([0.5, 1.5, 2.5, -0.5, -1.5, 0.0, 2 ** 21 - 1.0])])
+    x = x.astype(np.float32)
+    bits = (x + np.float32(12582912.0)).astype(np.float32).view(np.uint32)
+    got = (bits - np.uint32(0x4B400000)).view(np.int32)
+    want = np.rint(x.astype(np.float64)).astype(np.int64)          # numpy rounds half to even
+    assert np.array_equal(got.astype(np.int64), want)
+    assert 576 * 2 ** 21 * 1.05 < 2 ** 31
+    gh, gw = 24, 24
+    counts = {}
+    for q in range(gh * gw):
+        for k in range(gh * gw):
+            c = ((q // gw - k // gw + gh - 1), (q % gw - k % gw + gw - 1))
+            counts[c] = counts.get(c, 0) + 1
+    for (dyi, dxi), n in counts.items():
+        assert n == (gh - abs(dyi - (gh - 1))) * (gw - abs(dxi - (gw - 1)))
+    assert len(counts) == (2 * gh - 1) * (2 * gw - 1)
+    # modular arithmetic of the flush: u32 sum of (bits) minus count * MAGIC_BITS = the signed integer sum, whatever the wrap-arounds
+    vals = rng.integers(-2 ** 21, 2 ** 21, 576)
+    acc = np.uint32(0)
+    with np.errstate(over="ignore"):
+        for v in vals:
+            acc = np.uint32(acc + (np.float32(v) + np.float32(12582912.0)).view(np.uint32))
+        back = np.uint32(acc - np.uint32(576) * np.uint32(0x4B400000)).view(np.int32)
+    assert int(back) == int(vals.sum())
