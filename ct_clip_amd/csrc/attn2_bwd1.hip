@@ -6,7 +6,7 @@
 //
 // Work decomposition.  One persistent workgroup of eight waves per CU walks a run of (sequence, head) items of ONE head.  Per item the
 // LDS holds the head-planar Q~ slab, the dO'' = K w dO slab (both L x 64 B, the swizzled 32-row tiles of attn2_common.h), -delta'' per
-// query, the f32 accumulators of dQ^T (L x 128 B, stored in MFMA accumulator order: [tile][register][lane]) and an integer class table
+// query, the f32 accumulators of dQ^T (L x 128 B, stored by accumulator register: [tile][register / 4][lane][register % 4], 16-byte accesses) and an integer class table
 // for the bias gradient.  The L/32 x L/32 score tiles are enumerated row-major, g = kb * nkb + t (key block kb, query tile t), and wave
 // w owns the contiguous positions [P w, P w + P): it keeps dK^T / dV^T of the current key block in registers and, per tile, computes
 //     S^T-oriented  s = Q~ K^^T + bias,  dp = dO'' V^T - delta''      (rows = queries in registers, lane = key)
@@ -37,6 +37,7 @@ namespace {
 
 constexpr int NW1 = 8, NTH1 = NW1 * 64;
 constexpr int NPIECE = 5;                    // 16-byte pieces per thread and slab: 4 L <= NPIECE * NTH1
+constexpr int NTOUCH = 5;                    // L2 touches per thread and item: 3 L / 2 + 2 L + L / 32 lines <= NTOUCH * NTH1
 constexpr float MAGIC = 12582912.f;          // 1.5 * 2^23: fma(x, y, MAGIC) has round(x y) in its low mantissa bits for |x y| < 2^22
 constexpr uint32_t MAGIC_BITS = 0x4B400000u;
 constexpr int FIX_BITS = 21;
@@ -136,6 +137,12 @@ __device__ __forceinline__ int64_t uni(int64_t v) {
 }
 __device__ __forceinline__ float uni(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 
+// Compile-time ablation mask (tools/build_variant.py; never set in the product build -- results are WRONG, timing only): 1 = no class-table
+// atomics, 2 = no dQ^T update at all (no wait, no read-modify-write), 4 = no exponential, 8 = no L2 touches, 16 = no dV / dK products and no
+// transposing reads of Q~ / dO'', 32 = no bias loads, 64 = dQ^T update without the tile-counter wait
+#ifndef BWD1_ABL
+#define BWD1_ABL 0
+#endif
 struct StepArgs {
   const bf16_t *k, *v;                       // the item's K^ / V slabs (head-planar)
   const float* lse;                          // its lse2 at this head (only read on the unbounded-logit path)
@@ -143,8 +150,6 @@ struct StepArgs {
   const float *kinv, *k_scale;               // inverse norms at (row 0, this head); learned scale
   bf16_t *dk, *dv; int64_t ldk, ldv;         // row 0 at this head of the two outputs
   float* park;                               // this workgroup's parked accumulators [NW1][64][32]
-  const bf16_t *nq, *nv, *nk, *ndout, *no;   // the NEXT item's load-phase operands (touched line by line; this item's when there is none)
-  const float* nlse; int64_t lddo, ldo;
   float invK; int H, L, P;
   G1 g;
   unsigned long long* wstamp;                // profiling aid: spin time of wave 0 (100-MHz ticks), or null
@@ -159,8 +164,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   StepArgs a = a_;
   a.k = uni(a.k); a.v = uni(a.v); a.lse = uni(a.lse); a.tabh = uni(a.tabh); a.kinv = uni(a.kinv); a.k_scale = uni(a.k_scale);
   a.dk = uni(a.dk); a.dv = uni(a.dv); a.ldk = uni(a.ldk); a.ldv = uni(a.ldv); a.park = uni(a.park);
-  a.nq = uni(a.nq); a.nv = uni(a.nv); a.nk = uni(a.nk); a.ndout = uni(a.ndout); a.no = uni(a.no); a.nlse = uni(a.nlse);
-  a.lddo = uni(a.lddo); a.ldo = uni(a.ldo); a.invK = uni(a.invK); a.H = uni(a.H); a.L = uni(a.L); a.P = uni(a.P);
+  a.invK = uni(a.invK); a.H = uni(a.H); a.L = uni(a.L); a.P = uni(a.P);
   a.g.gw = uni(a.g.gw); a.g.S = uni(a.g.S); a.g.c0 = uni(a.g.c0); a.g.magic = uni(a.g.magic); a.g.ncls = uni(a.g.ncls); a.g.gh = uni(a.g.gh);
   a.wstamp = uni(a.wstamp);
   const G1& g = a.g;
@@ -192,7 +196,10 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   };
   auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
   auto bias_req = [&](f32x16& cb, int tt, int uc) {
-    if (TAB) {
+    if (BWD1_ABL & 32) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[r] = 0.f;
+    } else if (TAB) {
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {
         const __attribute__((address_space(1))) float* b = GPTR(const float, a.tabh + class0(tt, gq, uc));
@@ -205,19 +212,6 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
       for (int r = 0; r < 16; ++r) cb[r] = tv;
     }
   };
-  // touch j covers lines [64 j, 64 j + 64) of: K^ of this item (L / 2 lines), then Q~, V, K^ of the next item, then its dout and o rows (one
-  // line per row) and lse2
-  auto touch_line = [&](int j) -> uint32_t {
-    const int ln = j * 64 + lane, hl = L / 2;
-    const char* ad = reinterpret_cast<const char*>(a.k) + (ln < hl ? ln : 0) * 128;
-    if (ln >= hl) ad = reinterpret_cast<const char*>(a.nq) + (ln - hl) * 128;
-    if (ln >= 2 * hl) ad = reinterpret_cast<const char*>(a.nv) + (ln - 2 * hl) * 128;
-    if (ln >= 3 * hl) ad = reinterpret_cast<const char*>(a.nk) + (ln - 3 * hl) * 128;
-    if (ln >= 4 * hl) ad = reinterpret_cast<const char*>(a.ndout + (int64_t)(ln - 4 * hl) * a.lddo);
-    if (ln >= 4 * hl + L) ad = reinterpret_cast<const char*>(a.no + (int64_t)(ln - 4 * hl - L) * a.ldo);
-    if (ln >= 4 * hl + 2 * L) ad = reinterpret_cast<const char*>(a.nlse + ((ln - 4 * hl - 2 * L) * 32) % L);
-    return *GPTR(const uint32_t, ad);
-  };
   f32x16 dkacc, dvacc;
   Frag kf, vf, ktf, kn, vn;
   load_kv(kn, vn, kb);
@@ -225,7 +219,6 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   bool need_ktf = false, newblk = false;
   f32x16 cbn;
   bias_req(cbn, t, g.u(kb * 32 + c));
-  uint32_t tch = 0u;
   unsigned long long tspin = 0;
   for (int s = 0; s < P; ++s) {
     const int gpos = g0 + s;
@@ -237,7 +230,6 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
     }
-    asm volatile("" :: "v"(tch));
     // ---- part A: everything that does not touch dQ^T (no ownership of query tile t needed)
     f32x16 cb = cbn;
     const char* qtile = qs + t * TILE;
@@ -261,16 +253,12 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[0], vf.v[0], cdel, 0, 0, 0);
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[1], kf.v[1], sc, 0, 0, 0);
     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[1], vf.v[1], dp, 0, 0, 0);
-    // L2 prefetch, trickled: vmcnt retires in order, so an HBM miss anywhere in this loop holds up the next step's bias -- the operands the
-    // loop reads from global memory (K^ / V rows of THIS item) and the whole load phase of the NEXT item are therefore touched line by line
-    // (one dword per 128 bytes), one wave instruction every fourth step, issued here and consumed at the top of the next step
-    if ((s & 3) == 1) tch = touch_line((s >> 2) * NW1 + wave);
-    const Frag dotf = lds_cols(dotile, tr);
-    const Frag qtf = lds_cols(qtile, tr);
+    Frag dotf, qtf;
+    if (!(BWD1_ABL & 16)) { dotf = lds_cols(dotile, tr); qtf = lds_cols(qtile, tr); }
     float pr[16], ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(sc[r]); ds[r] = pr[r] * dp[r]; }
-    if (DTAB) {
+    for (int r = 0; r < 16; ++r) { pr[r] = (BWD1_ABL & 4) ? sc[r] : __builtin_amdgcn_exp2f(sc[r]); ds[r] = pr[r] * dp[r]; }
+    if (DTAB && !(BWD1_ABL & 1)) {
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {
         uint32_t* b = dtab + class0(t, gq, ucol);
@@ -281,25 +269,35 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
       }
     }
     const Frag pf = pack(pr), dsf = pack(ds);
-    dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);
-    dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
-    dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
-    dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
+    if (!(BWD1_ABL & 16)) {
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[1], pf.v[1], dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[1], dsf.v[1], dkacc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dvacc[r] += pr[r]; dkacc[r] += ds[r]; }
+    }
     // ---- part B: the update of dQ^T[t] -- wait for the tile, then read-modify-write its accumulator block
     // wait until every earlier update of query tile t is complete: the steps of ALL waves order the updates of a tile (in one step the eight
     // waves are on eight different tiles), so the number of updates before step s is a closed form (tabulated by the kernel: etab) -- no
     // workgroup barrier
     const int texp = __builtin_amdgcn_readfirstlane(lds_peek(etab_a + 4 * (wave * P + s))) + 1;
-    {
+    if (!(BWD1_ABL & 2)) {
+    if (!(BWD1_ABL & 64)) {
       const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
       while (__builtin_amdgcn_readfirstlane(lds_peek(tcnt_a + 4 * t)) < texp - 1) __builtin_amdgcn_s_sleep(1);
       if (a.wstamp) tspin += wall_clock64() - tb0;
       asm volatile("" ::: "memory");
     }
     float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
-    f32x16 dqc;
+    f32x16 dqc;                                                  // block layout [4][64 lanes][4]: four 16-byte accesses per lane each way
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dqc[r] = dqt[r * 64 + lane];
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqt + j * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dqc[4 * j + e] = q4[e];
+    }
     asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
     char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t now; its accumulators are in dqc
     if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
@@ -307,9 +305,14 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     const Frag dstf = lds_cols(scratch, tr);
     dqc = mma(dqc, ktf, dstf);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dqt[r * 64 + lane] = dqc[r];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dqt + j * 256 + lane * 4) = f32x4{dqc[4 * j], dqc[4 * j + 1], dqc[4 * j + 2], dqc[4 * j + 3]};
     asm volatile("" ::: "memory");
     if (lane == 0) lds_poke(tcnt_a + 4 * t, texp);               // (LDS executes a wave's operations in order: the accumulators are written when this is seen)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dkacc[r] += __builtin_bit_cast(float, (uint32_t)dsf.v[r >> 3][(r & 7)] << 16);
+      need_ktf = false;
+    }
     {                                                            // the next tile's bias (L1-resident table): requested at the END of the tile, when
       int tn = t + 1, kbn = kb;                                  // the tile's temporaries are dead, consumed at the start of the next step
       if (tn == nkb) { tn = 0; kbn = kb + 1; }
@@ -407,12 +410,128 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   }
 }
 
+struct UnprepArgs {
+  const float* qinv;                         // inverse norms at (row 0 of the item, this head); row stride H
+  bf16_t* dq; int64_t lddq;                  // row 0 of the item at this head
+  const float* q_scale; float c, invK;
+  int H, L, ncls;
+  const bf16_t *nq, *nv, *nk, *ndout, *no;   // the NEXT item's load-phase operands (touched line by line)
+  const float* nlse; int64_t lddo, ldo;
+};
+
+// dQ of one item: un-prep of q in place (attn_unprep_kernel of attn2.hip: u = q~ / (q_scale c), g = dq^ q_scale, dq = qinv (g - u (u . g)),
+// dscale += dq^ u on the bf16-rounded dq^) from the finished LDS accumulators, and the L2 prefetch of the NEXT item's operands (Q~, V, K^
+// slabs, its dout / o rows, lse2): one dword per 128-byte line, requested behind this function's own loads and consumed at its end.  A call for the
+// same reason as the steps: inlined, the kernel's long-lived values sit in scratch here, every reload is a VMEM operation and -- loads retire in
+// order -- waits for the touches in front of it (15 us per item instead of 8).  (Inside the tile steps the touches cost more than they saved:
+// every step waits for its bias behind them.)
+__device__ __noinline__ void bwd1_unprep_q(UnprepArgs a_) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  UnprepArgs a = a_;
+  a.qinv = uni(a.qinv); a.dq = uni(a.dq); a.lddq = uni(a.lddq); a.q_scale = uni(a.q_scale); a.c = uni(a.c); a.invK = uni(a.invK);
+  a.H = uni(a.H); a.L = uni(a.L); a.ncls = uni(a.ncls); a.nq = uni(a.nq); a.nv = uni(a.nv); a.nk = uni(a.nk); a.ndout = uni(a.ndout);
+  a.no = uni(a.no); a.nlse = uni(a.nlse); a.lddo = uni(a.lddo); a.ldo = uni(a.ldo);
+  const int L = a.L, nkb = L / 32;
+  const char* qs = dyn;
+  const char* dqa = dyn + L * 128;
+  float* sred = reinterpret_cast<float*>(dyn + L * 260 + ((a.ncls * 4 + 15) & ~15)) + 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  constexpr int MAXB = 3;                                        // query tiles per wave: ceil(18 / 8)
+  float iq[MAXB], qsv[16];
+#pragma unroll
+  for (int j = 0; j < MAXB; ++j) {
+    const int tq = wave + j * NW1 < nkb ? wave + j * NW1 : nkb - 1;
+    iq[j] = *GPTR(const float, a.qinv + (int64_t)(tq * 32 + ar) * a.H);
+  }
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qsv[8 * gq + e] = *GPTR(const float, a.q_scale + 16 * gq + 8 * half + e);
+  // the touches, after this function's own loads (loads retire in order: the waits for those are counted ones that leave the touches in flight).
+  // Wave-uniform chunks of 64 lines: chunk j * 8 + wave walks the segments Q~ | V | K^ (L / 2 lines each, 128 B apart), dout | o (L rows, one
+  // line per row), lse2 (L / 32 lines), each padded to whole chunks: segment, base and stride are scalar selects, the lane part one clamped multiply
+  uint32_t tch[NTOUCH];
+#pragma unroll
+  for (int j = 0; j < NTOUCH; ++j) tch[j] = 0u;
+  if (!(BWD1_ABL & 8)) {
+    const int hl = L / 2, cq = (hl + 63) >> 6, cr = (L + 63) >> 6;
+#pragma unroll
+    for (int j = 0; j < NTOUCH; ++j) {
+      int r = j * NW1 + wave, sg = 0;
+      if (r >= cq) { r -= cq; sg = 1; }
+      if (sg == 1 && r >= cq) { r -= cq; sg = 2; }
+      if (sg == 2 && r >= cq) { r -= cq; sg = 3; }
+      if (sg == 3 && r >= cr) { r -= cr; sg = 4; }
+      if (sg == 4 && r >= cr) { r -= cr; sg = 5; }
+      const char* base = reinterpret_cast<const char*>(sg == 0 ? a.nq : (sg == 1 ? a.nv : (sg == 2 ? a.nk : (sg == 3 ? a.ndout : a.no))));
+      if (sg == 5) base = reinterpret_cast<const char*>(a.nlse);
+      const uint32_t stride = sg == 3 ? (uint32_t)a.lddo * 2u : (sg == 4 ? (uint32_t)a.ldo * 2u : 128u);
+      const int nl = sg < 3 ? hl : (sg < 5 ? L : L / 32);
+      int ln = r * 64 + lane;
+      ln = ln < nl ? ln : nl - 1;
+      tch[j] = *GPTR(const uint32_t, base + (uint32_t)ln * stride);
+    }
+  }
+  float qsacc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) qsacc[i] = 0.f;
+  const float scq = a.c * LN2 * a.invK;
+#pragma unroll
+  for (int j = 0; j < MAXB; ++j) {
+    const int tq = wave + j * NW1;
+    if (tq < nkb) {                                              // (wave-uniform)
+      const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
+      const Frag qrow = lds_rows(qs + tq * TILE, ar, half);      // lane n of the transposed product holds query pi32(n & 31)
+      float qx[16], dq[16];
+      unpack8u(__builtin_bit_cast(u32x4, qrow.v[0]), qx); unpack8u(__builtin_bit_cast(u32x4, qrow.v[1]), qx + 8);
+      float part[2] = {0.f, 0.f};
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = 8 * gq + e;
+          const float qc = qsv[i] * a.c;
+          const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
+          const float gq0 = bf2f(f2bf(dqt[(i >> 2) * 256 + lane * 4 + (i & 3)] * scq));
+          const float uq = qx[i] * rq;
+          qsacc[i] += gq0 * uq;
+          const float gv = gq0 * qsv[i];
+          part[gq] += uq * gv;
+          qx[i] = uq; dq[i] = gv;
+        }
+      const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+      bf16_t* dQ = a.dq + (int64_t)(tq * 32 + ar) * a.lddq;
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[e] = iq[j] * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
+        g_store8(dQ + 16 * gq + 8 * half, a8);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) qsacc[i] += __shfl_xor(qsacc[i], o, 64);
+  if (c == 0) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sred[NW1 * 32 + wave * 32 + 16 * gq + 8 * half + e] += qsacc[8 * gq + e];
+  }
+#pragma unroll
+  for (int j = 0; j < NTOUCH; ++j) asm volatile("" :: "v"(tch[j]));
+}
+
 template <bool TAB, bool DTAB, bool SAFE>
 __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1& g, char* dyn) {
   const int L = p.L, nkb = L / 32;
   char* qs = dyn;                                               // Q~ slab
   char* dos = dyn + L * 64;                                     // dO'' slab
-  char* dqa = dyn + L * 128;                                    // dQ^T accumulators [tile][16][64] f32
+  char* dqa = dyn + L * 128;                                    // dQ^T accumulators [tile][4][64 lanes][4] f32 (register r of lane l at (r >> 2, l, r & 3))
   float* nd = reinterpret_cast<float*>(dyn + L * 256);          // -delta''
   uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);  // class table (fixed point)
   float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));       // [0,16) reductions, [16,48) tile counters, [48,56) park flags
@@ -463,11 +582,6 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
       ols[k] = lsl[row];
     }
   };
-  float qsv[16];                                                 // q_scale of this lane's 16 head dims (un-prep of q)
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qsv[8 * gq + e] = p.q_scale[16 * gq + 8 * half + e];
 
 #define BWD1_STAMP(i) do { if (x.stamps && blockIdx.x == 0 && tid == 0) x.stamps[it * 16 + (i)] = wall_clock64(); } while (0)
   for (int it = 0; it < x.ipw; ++it) {
@@ -540,79 +654,20 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     BWD1_STAMP(2);
     // ------------------------------------------------------------------------------------------------ tile steps (+ dK / dV un-prep inside)
     {
-      const bool more = it + 1 < x.ipw;
-      const int64_t so2 = more ? so + (int64_t)L * D : so, tok2 = more ? tok0 + L : tok0;
       bwd1_steps<TAB, DTAB, SAFE>(StepArgs{p.kh + so, p.vh + so, p.lse2 + (int64_t)h * p.M + tok0, x.tabadj + (int64_t)h * g.ncls, p.kinv + tok0 * p.H + h,
                                            p.k_scale, p.dk_tok + tok0 * p.ldk_tok + h * D, p.dv_tok + tok0 * p.ldv_tok + h * D, p.ldk_tok, p.ldv_tok,
-                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, p.qh + so2, p.vh + so2, p.kh + so2,
-                                           p.dout + tok2 * p.lddo + h * D, p.o + tok2 * p.ldo + h * D, p.lse2 + (int64_t)h * p.M + tok2, p.lddo, p.ldo,
-                                           invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr});
+                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr});
     }
     BWD1_STAMP(3);
     __syncthreads();
     BWD1_STAMP(4);
-    // ------------------------------------------------------------------------------------------------ dQ: un-prep of q in place
-    // (attn_unprep_kernel of attn2.hip: u = q~ / (q_scale c), g = dq^ q_scale, dq = qinv (g - u (u . g)), dscale += dq^ u on the bf16-rounded dq^)
+    // ------------------------------------------------------------------------------------------------ dQ: un-prep of q in place + L2 touches of the next item
     {
-      constexpr int MAXB = 3;                                    // query tiles per wave: ceil(18 / 8)
-      float iq[MAXB];
-#pragma unroll
-      for (int j = 0; j < MAXB; ++j) {
-        const int tq = wave + j * NW1 < nkb ? wave + j * NW1 : nkb - 1;
-        iq[j] = x.qinv[(tok0 + tq * 32 + ar) * p.H + h];
-      }
-      float qsacc[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) qsacc[i] = 0.f;
-      const float scq = p.c * LN2 * invK;
-#pragma nounroll                                                 // (one tile at a time: the next item's operands hold 85 registers through this loop)
-      for (int j = 0; j < MAXB; ++j) {
-        const int tq = wave + j * NW1;
-        const float iqj = j == 0 ? iq[0] : (j == 1 ? iq[1] : iq[2]);
-        if (tq < nkb) {
-          const float* dqt = reinterpret_cast<const float*>(dqa + tq * 4096);
-          const int64_t tok = tok0 + tq * 32 + ar;               // lane n of the transposed product holds query pi32(n & 31)
-          const Frag qrow = lds_rows(qs + tq * TILE, ar, half);
-          float qx[16], dq[16];
-          unpack8u(__builtin_bit_cast(u32x4, qrow.v[0]), qx); unpack8u(__builtin_bit_cast(u32x4, qrow.v[1]), qx + 8);
-          float part[2] = {0.f, 0.f};
-#pragma unroll
-          for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int i = 8 * gq + e;
-              const float qsv_ = qsv[i];
-              const float qc = qsv_ * p.c;
-              const float rq = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
-              const float gq0 = bf2f(f2bf(dqt[i * 64 + lane] * scq));
-              const float uq = qx[i] * rq;
-              qsacc[i] += gq0 * uq;
-              const float gv = gq0 * qsv_;
-              part[gq] += uq * gv;
-              qx[i] = uq; dq[i] = gv;
-            }
-          const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
-          bf16_t* dQ = x.dq_tok + tok * x.lddq + h * D;
-#pragma unroll
-          for (int gq = 0; gq < 2; ++gq) {
-            float a8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a8[e] = iqj * (dq[8 * gq + e] - qx[8 * gq + e] * dot);
-            store8(dQ + 16 * gq + 8 * half, a8);
-          }
-        }
-      }
-      BWD1_STAMP(5);
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) qsacc[i] += __shfl_xor(qsacc[i], o, 64);
-      if (c == 0) {
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sred[NW1 * 32 + wave * 32 + 16 * gq + 8 * half + e] += qsacc[8 * gq + e];
-      }
+      const bool more = it + 1 < x.ipw;
+      const int64_t so2 = more ? so + (int64_t)L * D : so, tok2 = more ? tok0 + L : tok0;      // (no next item: this item's lines again, no branch)
+      bwd1_unprep_q(UnprepArgs{x.qinv + tok0 * p.H + h, x.dq_tok + tok0 * x.lddq + h * D, x.lddq, p.q_scale, p.c, invK, p.H, L, g.ncls,
+                               p.qh + so2, p.vh + so2, p.kh + so2, p.dout + tok2 * p.lddo + h * D, p.o + tok2 * p.ldo + h * D,
+                               p.lse2 + (int64_t)h * p.M + tok2, p.lddo, p.ldo});
     }
     BWD1_STAMP(7);
     // ------------------------------------------------------------------------------------------------ flush the class table (stores only)

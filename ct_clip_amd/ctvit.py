@@ -173,6 +173,9 @@ class Transformer(nn.Module):
                 x, e = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x, comp=e)
             else:
                 x = Fn.feed_forward(y, ff[1].weight, ff[4].weight, residual=x)
+        # norm_out reads x alone: the last residue e (|e| <= half a bf16 ulp of x) is dropped, i.e. the stream takes ONE plain bf16 rounding here
+        # instead of 72 along the way.  The compensated stream is an inference-time refinement (auto = only without autograd): a training forward
+        # and a no_grad forward of the same bf16 weights differ by that rounding noise (INTEGRATION.md CTCLIP_RESIDUAL_COMP).
         return Fn.layer_norm(x, self.norm_out.gamma, None)
 
 

@@ -56,12 +56,12 @@ def main():
     if stamps:      # phase clocks (100 MHz) of workgroup 0, wave 0: see BWD1_STAMP in csrc/attn2_bwd1.hip
         n = be.lib.ctclip_attn2_bwd_fused_workspace(nseq, H, L, gh, gw)
         st = be.workspace(dev, n)[n - 4096:n].view(torch.int64).cpu().reshape(-1, 16)
-        names = ["loads issued+consumed", "dO'' written (load phase end)", "tile steps", "parked stores drained + barrier", "dq un-prep", "dk/dv un-prep",
-                 "scale partials", "table flush + barrier"]
+        spans = [("loads issued+consumed", 0, 1), ("dO'' written (load phase end)", 1, 2), ("tile steps", 2, 3), ("parked stores drained + barrier", 3, 4),
+                 ("dq un-prep + next item's L2 touches", 4, 7), ("table flush + barrier", 7, 8)]
         rows = []
         for it in range(6):
             t = st[it].tolist()
-            rows.append({names[i]: round((t[i + 1] - t[i]) / 100.0, 2) for i in range(8)} | {"barrier wait in steps (wave 0)": round(t[9] / 100.0, 2)})
+            rows.append({nm: round((t[b] - t[a]) / 100.0, 2) for nm, a, b in spans} | {"tile-counter wait in steps (wave 0)": round(t[9] / 100.0, 2)})
         out["phases_us_per_item"] = rows
     flops = 2.0 * nseq * H * L * L * D * 5          # five matrix products per score tile
     if out.get("one_pass_us"):
