@@ -143,6 +143,9 @@ __device__ __forceinline__ float uni(float v) { return __uint_as_float((uint32_t
 #ifndef BWD1_ABL
 #define BWD1_ABL 0
 #endif
+#ifndef BWD1_DELTA_MFMA
+#define BWD1_DELTA_MFMA 1
+#endif
 struct StepArgs {
   const bf16_t *k, *v;                       // the item's K^ / V slabs (head-planar)
   const float* lse;                          // its lse2 at this head (only read on the unbounded-logit path)
@@ -153,6 +156,7 @@ struct StepArgs {
   float invK; int H, L, P;
   G1 g;
   unsigned long long* wstamp;                // profiling aid: spin time of wave 0 (100-MHz ticks), or null
+  unsigned long long* sstamp;                // profiling aid: per-step sums [wave < 7][48] of the tile wait, then [48] step durations of wave 0; or null
 };
 
 // The tile steps of one item (see the file header): a call, so that the loop has the whole register file to itself -- inlined into the kernel
@@ -166,7 +170,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   a.dk = uni(a.dk); a.dv = uni(a.dv); a.ldk = uni(a.ldk); a.ldv = uni(a.ldv); a.park = uni(a.park);
   a.invK = uni(a.invK); a.H = uni(a.H); a.L = uni(a.L); a.P = uni(a.P);
   a.g.gw = uni(a.g.gw); a.g.S = uni(a.g.S); a.g.c0 = uni(a.g.c0); a.g.magic = uni(a.g.magic); a.g.ncls = uni(a.g.ncls); a.g.gh = uni(a.g.gh);
-  a.wstamp = uni(a.wstamp);
+  a.wstamp = uni(a.wstamp); a.sstamp = uni(a.sstamp);
   const G1& g = a.g;
   const int L = a.L, nkb = L / 32, NT = nkb * nkb, P = a.P;
   char* qs = dyn;
@@ -178,21 +182,26 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   float* sred = misc + 64;
   const uint32_t tcnt_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 16);    // [32] tile counters
   const uint32_t pflag_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 48);   // [NW1] "wave w has parked its part"
-  const uint32_t etab_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(sred + 2 * NW1 * 32);   // [NW1][P] updates of the tile before (wave, step)
+  const float* ksr = sred + 2 * NW1 * 32;                        // [2][32]: k_scale and its guarded reciprocal (staged once per workgroup)
+  const uint32_t etab_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(sred + 2 * NW1 * 32 + 64);   // [NW1][P] updates of the tile before (wave, step)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const TrOff tr = tr_offsets(lane);
   const int g0 = P * wave;                                       // first position of this wave
   if (g0 >= NT) return;
+  // this wave's row of the step table (updates of the step's query tile made before that step, see the kernel): lane = step
+  const int etrow = lds_peek(etab_a + 4 * (wave * P + (lane < P ? lane : 0)));
   const int last = (g0 + P < NT ? g0 + P : NT) - 1;              // last position of this wave
   int kb = g0 / nkb, t = g0 - kb * nkb;
   float ksacc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) ksacc[i] = 0.f;
+  float ik = 0.f, ikn;                                           // inverse norm of this lane's key row: current block, next block
   auto load_kv = [&](Frag& kk, Frag& vv, int jb) {
     const int64_t o2 = (int64_t)(jb * 32 + c) * D;
     kk = g_row(a.k + o2, half); vv = g_row(a.v + o2, half);
+    ikn = *GPTR(const float, a.kinv + (int64_t)(jb * 32 + c) * a.H);
   };
   auto class0 = [&](int tt, int gq, int uc) { return g.u(tt * 32 + 16 * gq + 8 * half) - uc + g.c0; };
   auto bias_req = [&](f32x16& cb, int tt, int uc) {
@@ -220,11 +229,17 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   f32x16 cbn;
   bias_req(cbn, t, g.u(kb * 32 + c));
   unsigned long long tspin = 0;
+  unsigned long long tstep = a.sstamp ? wall_clock64() : 0ull;
   for (int s = 0; s < P; ++s) {
     const int gpos = g0 + s;
     if (gpos > last) break;
+    if (a.sstamp && s > 0 && wave == 0 && lane == 0) {
+      const unsigned long long now = wall_clock64();
+      *GPTR(unsigned long long, a.sstamp + 7 * 48 + s - 1) += now - tstep;
+      tstep = now;
+    }
     if (s == 0 || t == 0) {                                      // a new key block starts here
-      kf = kn; vf = vn;
+      kf = kn; vf = vn; ik = ikn;
       ucol = g.u(kb * 32 + c);
       need_ktf = true; newblk = true;
 #pragma unroll
@@ -236,6 +251,25 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     const char* dotile = dos + t * TILE;
     const Frag qf = lds_rows(qtile, ar, half);
     const Frag dof = lds_rows(dotile, ar, half);
+#if BWD1_DELTA_MFMA
+    // -delta'' enters dp as a THIRD matrix product instead of as the C operand: row q of the A operand is the f32 value split into three bf16
+    // terms (hi + lo + lolo: 24 mantissa bits), the B operand is ones in those three contraction slots.  One 4-byte LDS read per lane instead of
+    // four 16-byte broadcast reads (the LDS pipe is this loop's bottleneck; the matrix pipe is 90 % idle)
+    bf16x8 dlt;
+    {
+      const float dl = nd[t * 32 + ar];
+      const uint32_t hi = pack2bf(dl, 0.f) & 0xffffu;
+      const float r1 = dl - __uint_as_float(hi << 16);
+      const uint32_t lo = pack2bf(r1, 0.f) & 0xffffu;
+      const float r2 = r1 - __uint_as_float(lo << 16);
+      const uint32_t ll = pack2bf(r2, 0.f) & 0xffffu;
+      const u32x4 w4 = half ? u32x4{0u, 0u, 0u, 0u} : u32x4{hi | (lo << 16), ll, 0u, 0u};
+      dlt = __builtin_bit_cast(bf16x8, w4);
+    }
+    const bf16x8 ones3 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x00003F80u, 0u, 0u});
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x16 cdel = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dlt, ones3, zero16, 0, 0, 0);
+#else
     f32x16 cdel;
     {
       const float* sp = nd + t * 32 + 8 * half;
@@ -244,6 +278,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
     }
+#endif
     if (!SAFE) {                                                 // slow path: the queries' lse2 from global memory
       const __attribute__((address_space(1))) float* sp = GPTR(const float, a.lse + t * 32 + 8 * half);
 #pragma unroll
@@ -282,32 +317,44 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     // wait until every earlier update of query tile t is complete: the steps of ALL waves order the updates of a tile (in one step the eight
     // waves are on eight different tiles), so the number of updates before step s is a closed form (tabulated by the kernel: etab) -- no
     // workgroup barrier
-    const int texp = __builtin_amdgcn_readfirstlane(lds_peek(etab_a + 4 * (wave * P + s))) + 1;
+    const int texp = __builtin_amdgcn_readlane(etrow, s) + 1;
     if (!(BWD1_ABL & 2)) {
-    if (!(BWD1_ABL & 64)) {
-      const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
-      while (__builtin_amdgcn_readfirstlane(lds_peek(tcnt_a + 4 * t)) < texp - 1) __builtin_amdgcn_s_sleep(1);
-      if (a.wstamp) tspin += wall_clock64() - tb0;
+      float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
+      f32x16 dqc;                                                  // block layout [4][64 lanes][4]: four 16-byte accesses per lane each way
+      {
+        // ONE LDS round trip for "is the tile mine yet" and its accumulators: the counter is read FIRST and the LDS executes a wave's operations in
+        // order (and the updater's poke after its writes), so accumulators read behind a counter that shows texp - 1 updates are complete; if it
+        // does not, the reads are repeated
+        const unsigned long long tb0 = a.wstamp ? wall_clock64() : 0ull;
+        const uint32_t ca = tcnt_a + 4 * t, da = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)dqt + lane * 16;
+        f32x4 q0, q1, q2, q3;
+        for (;;) {
+          int cnt;
+          asm volatile("ds_read_b32 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:1024\n\tds_read_b128 %3, %6 offset:2048\n\t"
+                       "ds_read_b128 %4, %6 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(cnt), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(ca), "v"(da) : "memory");
+          if ((BWD1_ABL & 64) || __builtin_amdgcn_readfirstlane(cnt) >= texp - 1) break;
+          // not yet: poll the counter alone (4 bytes instead of 4 KB per look), then read the block again
+          do { __builtin_amdgcn_s_sleep(1); } while (__builtin_amdgcn_readfirstlane(lds_peek(ca)) < texp - 1);
+        }
+        if (a.wstamp) {
+          const unsigned long long dt = wall_clock64() - tb0;
+          tspin += dt;
+          if (a.sstamp && wave < 7 && lane == 0) *GPTR(unsigned long long, a.sstamp + wave * 48 + s) += dt;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dqc[e] = q0[e]; dqc[4 + e] = q1[e]; dqc[8 + e] = q2[e]; dqc[12 + e] = q3[e]; }
+      }
+      asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
+      char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t now; its accumulators are in dqc
+      if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
+      put_rows(scratch, c, half, dsf);
+      const Frag dstf = lds_cols(scratch, tr);
+      dqc = mma(dqc, ktf, dstf);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dqt + j * 256 + lane * 4) = f32x4{dqc[4 * j], dqc[4 * j + 1], dqc[4 * j + 2], dqc[4 * j + 3]};
       asm volatile("" ::: "memory");
-    }
-    float* dqt = reinterpret_cast<float*>(dqa + t * 4096);
-    f32x16 dqc;                                                  // block layout [4][64 lanes][4]: four 16-byte accesses per lane each way
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqt + j * 256 + lane * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dqc[4 * j + e] = q4[e];
-    }
-    asm volatile("" ::: "memory");                               // (the block is re-used as bf16 scratch below: keep these reads in front of those stores)
-    char* scratch = reinterpret_cast<char*>(dqt);                // this wave owns query tile t now; its accumulators are in dqc
-    if (need_ktf) { put_rows(scratch, c, half, kf); ktf = lds_cols(scratch, tr); need_ktf = false; }
-    put_rows(scratch, c, half, dsf);
-    const Frag dstf = lds_cols(scratch, tr);
-    dqc = mma(dqc, ktf, dstf);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dqt + j * 256 + lane * 4) = f32x4{dqc[4 * j], dqc[4 * j + 1], dqc[4 * j + 2], dqc[4 * j + 3]};
-    asm volatile("" ::: "memory");
-    if (lane == 0) lds_poke(tcnt_a + 4 * t, texp);               // (LDS executes a wave's operations in order: the accumulators are written when this is seen)
+      if (lane == 0) lds_poke(tcnt_a + 4 * t, texp);               // (LDS executes a wave's operations in order: the accumulators are written when this is seen)
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dkacc[r] += __builtin_bit_cast(float, (uint32_t)dsf.v[r >> 3][(r & 7)] << 16);
@@ -357,37 +404,41 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
           g_store8(dV + 16 * gq + 8 * half, b8);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float ik = *GPTR(const float, a.kinv + (int64_t)row * a.H);
         const float kmul = LN2 * a.invK;
         const u32x4 kw0 = __builtin_bit_cast(u32x4, kf.v[0]), kw1 = __builtin_bit_cast(u32x4, kf.v[1]);
         float part[2] = {0.f, 0.f};
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
+        for (int gq = 0; gq < 2; ++gq) {
+          const float* sp = ksr + 16 * gq + 8 * half;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(sp + 32), r1 = *reinterpret_cast<const f32x4*>(sp + 36);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int i = 8 * gq + e;
             const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
             const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
-            const float ks = *GPTR(const float, a.k_scale + 16 * gq + 8 * half + e);
-            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+            const float ks = e < 4 ? s0[e & 3] : s1[e & 3], rk = e < 4 ? r0[e & 3] : r1[e & 3];
             const float gk0 = bf2f(f2bf(dkacc[i] * kmul));
             const float uk = kx * rk;
             ksacc[i] += gk0 * uk;
             part[gq] += uk * (gk0 * ks);
             dkacc[i] = gk0;
           }
+        }
         const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
         __builtin_amdgcn_sched_barrier(0);
         bf16_t* dK = a.dk + (int64_t)row * a.ldk;
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) {
+          const float* sp = ksr + 16 * gq + 8 * half;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(sp + 32), r1 = *reinterpret_cast<const f32x4*>(sp + 36);
           float a8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const uint32_t kwd = gq ? kw1[e >> 1] : kw0[e >> 1];
             const float kx = (e & 1) ? __uint_as_float(kwd & 0xffff0000u) : __uint_as_float(kwd << 16);
-            const float ks = *GPTR(const float, a.k_scale + 16 * gq + 8 * half + e);
-            const float rk = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f;
+            const float ks = e < 4 ? s0[e & 3] : s1[e & 3], rk = e < 4 ? r0[e & 3] : r1[e & 3];
             a8[e] = ik * (dkacc[8 * gq + e] * ks - (kx * rk) * dot);
           }
           g_store8(dK + 16 * gq + 8 * half, a8);
@@ -546,7 +597,9 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
   if (DTAB) { for (int i = tid; i < g.ncls; i += NTH1) dtab[i] = 0u; }
   if (tid < 2 * NW1 * 32) sred[tid] = 0.f;
   {   // etab[w][s] = number of updates of query tile t(w, s) = (P w + s) mod nkb made in steps < s by all waves (see bwd1_steps)
-    int* etab = reinterpret_cast<int*>(sred + 2 * NW1 * 32);
+    float* ksr = sred + 2 * NW1 * 32;                           // k_scale and 1 / k_scale for the in-loop un-prep of dK (no division, no global load there)
+    if (tid < 32) { const float ks = p.k_scale[tid]; ksr[tid] = ks; ksr[32 + tid] = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f; }
+    int* etab = reinterpret_cast<int*>(sred + 2 * NW1 * 32 + 64);
     const int NT = nkb * nkb;
     for (int i = tid; i < NW1 * x.P; i += NTH1) {
       const int w = i / x.P, sidx = i - w * x.P, tt = (x.P * w + sidx) % nkb;
@@ -656,7 +709,8 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     {
       bwd1_steps<TAB, DTAB, SAFE>(StepArgs{p.kh + so, p.vh + so, p.lse2 + (int64_t)h * p.M + tok0, x.tabadj + (int64_t)h * g.ncls, p.kinv + tok0 * p.H + h,
                                            p.k_scale, p.dk_tok + tok0 * p.ldk_tok + h * D, p.dv_tok + tok0 * p.ldv_tok + h * D, p.ldk_tok, p.ldv_tok,
-                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr});
+                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr,
+                                           (x.stamps && blockIdx.x == 0) ? x.stamps + 128 : nullptr});
     }
     BWD1_STAMP(3);
     __syncthreads();
@@ -763,7 +817,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     pl.ncls = (2 * gh - 1) * S;
     pl.g = G1{gw, S, (gh - 1) * S + (gw - 1), (65536 + gw - 1) / gw, pl.ncls, gh};
   }
-  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4;
+  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4 + 64 * 4;
   // (+ the step table, sized after P below)
   if (pl.shm > 160 * 1024) return false;
   int P = (NT + NW1 - 1) / NW1;
@@ -773,6 +827,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     for (int d = 1; d < NW1; ++d) ok = ok && (P * d) % nkb != 0;
     if (ok) break;
   }
+  if (P > 64) return false;                                     // (a wave keeps its row of the step table in ONE register, lane = step)
   pl.P = P;
   pl.shm += (size_t)NW1 * P * 4;
   if (pl.shm > 160 * 1024) return false;

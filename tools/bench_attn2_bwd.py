@@ -40,6 +40,9 @@ def main():
 
     out = {}
     for name, fn in (("three_pass_us", old), ("one_pass_us", new)):
+        if stamps and name == "one_pass_us":       # the per-step sums accumulate: start from zero
+            nws = be.lib.ctclip_attn2_bwd_fused_workspace(nseq, H, L, gh, gw)
+            be.workspace(dev, nws)[nws - 4096:nws].zero_()
         for _ in range(3):
             r = fn()
         if r is None:
@@ -63,6 +66,10 @@ def main():
             t = st[it].tolist()
             rows.append({nm: round((t[b] - t[a]) / 100.0, 2) for nm, a, b in spans} | {"tile-counter wait in steps (wave 0)": round(t[9] / 100.0, 2)})
         out["phases_us_per_item"] = rows
+        flat = be.workspace(dev, n)[n - 4096:n].view(torch.int64).cpu()
+        per = flat[128:128 + 8 * 48].reshape(8, 48).double() / 100.0 / (reps + 3) / 6       # us per item (sums over every launch since the buffer was zeroed)
+        out["tile_wait_us_per_step"] = {f"wave{w}": [round(float(v), 2) for v in per[w][:41]] for w in range(7)}
+        out["step_us_wave0"] = [round(float(v), 2) for v in per[7][:41]]
     flops = 2.0 * nseq * H * L * L * D * 5          # five matrix products per score tile
     if out.get("one_pass_us"):
         out["one_pass_mfma_frac"] = round(flops / (out["one_pass_us"] * 1e-6) / 2.5e15, 4)
