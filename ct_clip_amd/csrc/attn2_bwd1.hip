@@ -5,32 +5,37 @@
 // S, P = exp2(S), dP and dS three times per tile.
 //
 // Work decomposition.  One persistent workgroup of eight waves per CU walks a run of (sequence, head) items of ONE head.  Per item the
-// LDS holds the head-planar Q~ slab, the dO'' = K w dO slab (both L x 64 B, the swizzled 32-row tiles of attn2_common.h), -delta'' per
-// query, the f32 accumulators of dQ^T (L x 128 B, stored by accumulator register: [tile][register / 4][lane][register % 4], 16-byte accesses) and an integer class table
-// for the bias gradient.  The L/32 x L/32 score tiles are enumerated row-major, g = kb * nkb + t (key block kb, query tile t), and wave
-// w owns the contiguous positions [P w, P w + P): it keeps dK^T / dV^T of the current key block in registers and, per tile, computes
-//     S^T-oriented  s = Q~ K^^T + bias,  dp = dO'' V^T - delta''      (rows = queries in registers, lane = key)
-//     p = exp2(s), ds = p dp;   dV^T += dO''^T p,  dK^T += Q~^T ds   (transposing LDS reads, as the key pass did)
+// LDS holds the head-planar Q~ slab and a plain copy of the item's dO rows (both L x 64 B, the swizzled 32-row tiles of attn2_common.h),
+// two f32 values per query (-delta_q = -sum_d dO O and log2 K - lse2_q), the f32 accumulators of dQ^T (L x 128 B, stored by accumulator
+// register: [tile][register / 4][lane][register % 4], 16-byte accesses) and an integer class table for the bias gradient.  The
+// L/32 x L/32 score tiles are enumerated row-major, g = kb * nkb + t (key block kb, query tile t), and wave w owns the contiguous
+// positions [P w, P w + P): it keeps dK^T / dV^T of the current key block in registers and, per tile, computes
+//     s = Q~ K^^T + bias + (log2 K - lse2_q),  dp = dO V^T - delta_q   (rows = queries in registers, lane = key; the two per-query terms
+//                                                                      are matrix products of their own: three bf16 terms x ones)
+//     p = exp2(s) = K x probability, ds = p dp;   dV^T += dO^T p,  dK^T += Q~^T ds   (transposing LDS reads, as the key pass did)
 //     dQ^T[t] += K^^T ds^T                                            (ds transposed through LDS: written row-major, read with
 //                                                                      ds_read_b64_tr_b16; the tile's own accumulator block is the scratch)
 //     table[class(q, k)] += round(ds)                                  (ds_add_u32, see below)
-// dQ^T[t] is a read-modify-write of LDS by whichever wave works on query tile t.  All waves advance one tile per STEP with one barrier
-// per step, and P is chosen so that P (w - w') != 0 (mod nkb): in every step the eight waves are on eight different query tiles, so the
-// updates never collide and every tile sees its addends in a FIXED order (deterministic; no floating-point atomic anywhere).  A key block
-// whose positions straddle two waves (7 of 18 at L = 576) has two partial dK^T / dV^T.  A wave PARKS its accumulators in global scratch
-// (L2) when it leaves a key block; after the last step the waves add the parts in a fixed order and apply the l2norm backward -- inside
-// the tile loop that epilogue cost 140 registers on top of a loop that needs all 256.
+// dQ^T[t] is a read-modify-write of LDS by whichever wave works on query tile t.  P is chosen so that P (w - w') != 0 (mod nkb): in every
+// step the eight waves are on eight different query tiles, and the updates of one tile are ordered by a per-tile LDS counter whose expected
+// value per (wave, step) is tabulated at kernel start (each wave keeps its row in ONE register, lane = step): no workgroup barrier in the
+// tile loop, every tile sees its addends in a FIXED order (deterministic; no floating-point atomic anywhere).  A key block whose positions
+// straddle two waves (7 of 18 at L = 576) has two partial dK^T / dV^T: the holder of the second part PARKS its accumulators in global
+// scratch (L2) and raises an LDS flag, the holder of the first part adds them and applies the l2norm backward in the loop (k_scale and its
+// reciprocal staged in LDS, the rows' inverse norms prefetched with the K^ / V rows: no division and no global load there).
 //
 // Bias-table gradient.  ds_add_f32 costs 161 cycles per wave instruction on gfx950 (tools/ubench/lds_atomic_rates.hip), ds_add_u32 4 --
 // the same as a plain store.  So the scatter is done in FIXED POINT: per item a power of two K is chosen from the rigorous bound
-// |dS| <= 2 max_q |dO_q| max_k |v_k| such that |K dS| < 2^21, folded into dO'' (exact: every product of the item is scaled by K and
-// un-scaled by 1/K in the epilogues), and round(K dS) is obtained as the low bits of fma(p, dp, 1.5 * 2^23).  Integer addition is
-// associative: the table is bit-identical from run to run whatever the order in which the waves' atomics retire.  576 addends per class
-// and item stay below 2^31; the table is flushed (x 1/K, f32) into a per-workgroup partial after every item.
+// |dS| <= 2 max_q |dO_q| max_k |v_k| such that |K dS| < 2^21.  K enters through the LOGITS (log2 K is an integer: exact): p is K times the
+// true probability, every product of the item is scaled by K and un-scaled by 1/K in the epilogues, and round(K dS) is obtained as the low
+// bits of fma(p, dp, 1.5 * 2^23).  Integer addition is associative: the table is bit-identical from run to run whatever the order in which
+// the waves' atomics retire.  576 addends per class and item stay below 2^31; the table is flushed (x 1/K, f32) into a per-(workgroup,
+// item) partial after every item.  Because the row's lse2 is subtracted inside the exponent, p <= K whatever the logit span: one code path
+// (the slab kernels' bounded-logit / row-maximum distinction does not exist here) and dO is never re-rounded.
 //
-// The bias itself comes from a per-head f32 table in GLOBAL memory (8.8 KB: L1-resident), log2 e applied and the logit bound subtracted
-// by a one-workgroup-per-head stage kernel; a tile's 16 values per lane are requested one step ahead.  The LDS budget (160 KiB to the
-// byte in the slab kernels) has no room for a second table.
+// The bias itself comes from a per-head f32 table in GLOBAL memory (8.8 KB: L1-resident), log2 e applied by a one-workgroup-per-head
+// stage kernel; a tile's 16 values per lane are requested at the end of the previous tile.  The LDS budget (160 KiB nearly to the byte)
+// has no room for a second table.
 #include "attn2_common.h"
 
 namespace {
@@ -50,8 +55,7 @@ struct G1 {                                  // token -> class arithmetic (table
 struct X1 {                                  // arguments of the fused backward beyond ctclip_attn2::Params
   const float* qinv; bf16_t* dq_tok; int64_t lddq;
   float* qpart;                              // [nwg][32] q_scale gradient partials (kpart: Params)
-  const float* tabadj;                       // [H][ncls] staged table (log2 domain, bound subtracted when safe)
-  const float* hinfo;                        // [H][2]: m2, safe
+  const float* tabadj;                       // [H][ncls] staged table (log2 domain)
   float* dtpart;                             // [nseq][H][ncls] table-gradient partials, one per (workgroup, item), or null
   float* park;                               // [nwg][NW1][64][32] a wave's parked dK^T / dV^T accumulators (second part of a split key block)
   int P, ipw, wph;                           // positions per wave, items per workgroup, workgroups per head
@@ -92,38 +96,12 @@ __device__ __forceinline__ void put_rows(char* tile, int row, int half, const Fr
   *reinterpret_cast<bf16x8*>(tile + swz(row, 2 + half)) = f.v[1];
 }
 
-// per head: log2-domain table, the logit bound m2 and whether the bounded-logit softmax is safe (stage_srel of attn2_slab.hip)
-__global__ __launch_bounds__(256) void bwd1_stage_kernel(Params p, float* __restrict__ tabadj, float* __restrict__ hinfo, int ncls) {
-  __shared__ float red[2][4];
-  __shared__ float bc[2];
-  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float mx = -INFINITY, mn = INFINITY;
+// per head: the position-bias table in the log2 domain, contiguous ([H][ncls]; the model's table is [ncls][H])
+__global__ __launch_bounds__(256) void bwd1_stage_kernel(Params p, float* __restrict__ tabadj, int ncls) {
+  const int h = blockIdx.x, tid = threadIdx.x;
   if (p.tab) {
-    for (int i = tid; i < ncls; i += 256) { const float t = p.tab[(int64_t)i * p.H + h] * LOG2E; mx = fmaxf(mx, t); mn = fminf(mn, t); }
-  } else { mx = 0.f; mn = 0.f; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
-  if (lane == 0) { red[0][wave] = mx; red[1][wave] = mn; }
-  __syncthreads();
-  if (wave == 0) {
-    float a = lane < 32 ? fabsf(p.q_scale[lane]) : fabsf(p.k_scale[lane - 32]);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
-    const float qk = a * __shfl_xor(a, 32, 64) * p.c;
-    float tmx = -INFINITY, tmn = INFINITY;
-    for (int w = 0; w < 4; ++w) { tmx = fmaxf(tmx, red[0][w]); tmn = fminf(tmn, red[1][w]); }
-    if (lane == 0) {
-      const float span = 2.f * qk + (tmx - tmn);
-      const int safe = (span <= SAFE_SPAN && span == span) ? 1 : 0;
-      bc[0] = qk + tmx; bc[1] = (float)safe;
-      hinfo[2 * h] = qk + tmx; hinfo[2 * h + 1] = (float)safe;
-    }
-  }
-  __syncthreads();
-  const float sub = bc[1] != 0.f ? bc[0] : 0.f;
-  if (p.tab) {
-    for (int i = tid; i < ncls; i += 256) tabadj[(int64_t)h * ncls + i] = p.tab[(int64_t)i * p.H + h] * LOG2E - sub;
-  } else if (tid == 0) tabadj[(int64_t)h * ncls] = -sub;
+    for (int i = tid; i < ncls; i += 256) tabadj[(int64_t)h * ncls + i] = p.tab[(int64_t)i * p.H + h] * LOG2E;
+  } else if (tid == 0) tabadj[(int64_t)h * ncls] = 0.f;
 }
 
 template <class T>
@@ -143,18 +121,15 @@ __device__ __forceinline__ float uni(float v) { return __uint_as_float((uint32_t
 #ifndef BWD1_ABL
 #define BWD1_ABL 0
 #endif
-#ifndef BWD1_DELTA_MFMA
-#define BWD1_DELTA_MFMA 1
-#endif
 struct StepArgs {
   const bf16_t *k, *v;                       // the item's K^ / V slabs (head-planar)
-  const float* lse;                          // its lse2 at this head (only read on the unbounded-logit path)
   const float* tabh;                         // the head's staged table
   const float *kinv, *k_scale;               // inverse norms at (row 0, this head); learned scale
   bf16_t *dk, *dv; int64_t ldk, ldv;         // row 0 at this head of the two outputs
   float* park;                               // this workgroup's parked accumulators [NW1][64][32]
   float invK; int H, L, P;
   G1 g;
+  int etrow;                                 // PER LANE: this wave's row of the step table (lane = step): updates of the step's query tile made before it
   unsigned long long* wstamp;                // profiling aid: spin time of wave 0 (100-MHz ticks), or null
   unsigned long long* sstamp;                // profiling aid: per-step sums [wave < 7][48] of the tile wait, then [48] step durations of wave 0; or null
 };
@@ -162,11 +137,11 @@ struct StepArgs {
 // The tile steps of one item (see the file header): a call, so that the loop has the whole register file to itself -- inlined into the kernel
 // it shared an allocation with the load phase (twenty 16-byte loads in flight per thread) and the un-prep arithmetic, and one side or the other
 // spilled.  Ends with this item's k_scale-gradient sums in the waves' LDS rows; the caller's barrier publishes the dQ^T accumulators.
-template <bool TAB, bool DTAB, bool SAFE>
+template <bool TAB, bool DTAB>
 __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   StepArgs a = a_;
-  a.k = uni(a.k); a.v = uni(a.v); a.lse = uni(a.lse); a.tabh = uni(a.tabh); a.kinv = uni(a.kinv); a.k_scale = uni(a.k_scale);
+  a.k = uni(a.k); a.v = uni(a.v); a.tabh = uni(a.tabh); a.kinv = uni(a.kinv); a.k_scale = uni(a.k_scale);
   a.dk = uni(a.dk); a.dv = uni(a.dv); a.ldk = uni(a.ldk); a.ldv = uni(a.ldv); a.park = uni(a.park);
   a.invK = uni(a.invK); a.H = uni(a.H); a.L = uni(a.L); a.P = uni(a.P);
   a.g.gw = uni(a.g.gw); a.g.S = uni(a.g.S); a.g.c0 = uni(a.g.c0); a.g.magic = uni(a.g.magic); a.g.ncls = uni(a.g.ncls); a.g.gh = uni(a.g.gh);
@@ -176,22 +151,21 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   char* qs = dyn;
   char* dos = dyn + L * 64;
   char* dqa = dyn + L * 128;
-  float* nd = reinterpret_cast<float*>(dyn + L * 256);
-  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);
-  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));
+  float* nd = reinterpret_cast<float*>(dyn + L * 256);           // -delta per query
+  float* nl = reinterpret_cast<float*>(dyn + L * 260);           // log2 K - lse2 per query
+  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 264);
+  float* misc = reinterpret_cast<float*>(dyn + L * 264 + ((g.ncls * 4 + 15) & ~15));
   float* sred = misc + 64;
   const uint32_t tcnt_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 16);    // [32] tile counters
   const uint32_t pflag_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(misc + 48);   // [NW1] "wave w has parked its part"
   const float* ksr = sred + 2 * NW1 * 32;                        // [2][32]: k_scale and its guarded reciprocal (staged once per workgroup)
-  const uint32_t etab_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(sred + 2 * NW1 * 32 + 64);   // [NW1][P] updates of the tile before (wave, step)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (scalar: every position / key-block decision below is wave-uniform)
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const TrOff tr = tr_offsets(lane);
   const int g0 = P * wave;                                       // first position of this wave
   if (g0 >= NT) return;
-  // this wave's row of the step table (updates of the step's query tile made before that step, see the kernel): lane = step
-  const int etrow = lds_peek(etab_a + 4 * (wave * P + (lane < P ? lane : 0)));
+  const int etrow = a.etrow;                                     // (a per-lane argument: lane = step)
   const int last = (g0 + P < NT ? g0 + P : NT) - 1;              // last position of this wave
   int kb = g0 / nkb, t = g0 - kb * nkb;
   float ksacc[16];
@@ -251,39 +225,26 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
     const char* dotile = dos + t * TILE;
     const Frag qf = lds_rows(qtile, ar, half);
     const Frag dof = lds_rows(dotile, ar, half);
-#if BWD1_DELTA_MFMA
-    // -delta'' enters dp as a THIRD matrix product instead of as the C operand: row q of the A operand is the f32 value split into three bf16
-    // terms (hi + lo + lolo: 24 mantissa bits), the B operand is ones in those three contraction slots.  One 4-byte LDS read per lane instead of
-    // four 16-byte broadcast reads (the LDS pipe is this loop's bottleneck; the matrix pipe is 90 % idle)
-    bf16x8 dlt;
-    {
-      const float dl = nd[t * 32 + ar];
-      const uint32_t hi = pack2bf(dl, 0.f) & 0xffffu;
-      const float r1 = dl - __uint_as_float(hi << 16);
+    // The two per-QUERY terms of a tile enter as matrix products of their own instead of as C operands: row q of the A operand is the f32 value
+    // split into three bf16 terms (hi + lo + lolo: 24 mantissa bits), the B operand is ones in those three contraction slots.
+    //   * log2 K - lse2_q on the logits: p = exp2(s) is then K times the TRUE probability (<= K whatever the logit span: no bounded-logit
+    //     special case, no per-row factor folded into dO, K never touches dO: the dO slab is a plain copy);
+    //   * -delta_q on dP.
+    // One 4-byte LDS read per lane each instead of 16-byte broadcast reads: the LDS pipe is this loop's bottleneck, the matrix pipe is 90 % idle.
+    auto split3 = [&](float v) -> bf16x8 {
+      const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
+      const float r1 = v - __uint_as_float(hi << 16);
       const uint32_t lo = pack2bf(r1, 0.f) & 0xffffu;
       const float r2 = r1 - __uint_as_float(lo << 16);
       const uint32_t ll = pack2bf(r2, 0.f) & 0xffffu;
       const u32x4 w4 = half ? u32x4{0u, 0u, 0u, 0u} : u32x4{hi | (lo << 16), ll, 0u, 0u};
-      dlt = __builtin_bit_cast(bf16x8, w4);
-    }
+      return __builtin_bit_cast(bf16x8, w4);
+    };
+    const bf16x8 dlt = split3(nd[t * 32 + ar]), lgt = split3(nl[t * 32 + ar]);
     const bf16x8 ones3 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x00003F80u, 0u, 0u});
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const f32x16 cdel = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dlt, ones3, zero16, 0, 0, 0);
-#else
-    f32x16 cdel;
-    {
-      const float* sp = nd + t * 32 + 8 * half;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sp + 16), b1 = *reinterpret_cast<const f32x4*>(sp + 20);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { cdel[e] = a0[e]; cdel[4 + e] = a1[e]; cdel[8 + e] = b0[e]; cdel[12 + e] = b1[e]; }
-    }
-#endif
-    if (!SAFE) {                                                 // slow path: the queries' lse2 from global memory
-      const __attribute__((address_space(1))) float* sp = GPTR(const float, a.lse + t * 32 + 8 * half);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { cb[e] -= sp[e]; cb[8 + e] -= sp[16 + e]; }
-    }
+    cb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lgt, ones3, cb, 0, 0, 0);
     f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[0], kf.v[0], cb, 0, 0, 0);
     f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof.v[0], vf.v[0], cdel, 0, 0, 0);
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf.v[1], kf.v[1], sc, 0, 0, 0);
@@ -485,7 +446,7 @@ __device__ __noinline__ void bwd1_unprep_q(UnprepArgs a_) {
   const int L = a.L, nkb = L / 32;
   const char* qs = dyn;
   const char* dqa = dyn + L * 128;
-  float* sred = reinterpret_cast<float*>(dyn + L * 260 + ((a.ncls * 4 + 15) & ~15)) + 64;
+  float* sred = reinterpret_cast<float*>(dyn + L * 264 + ((a.ncls * 4 + 15) & ~15)) + 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
@@ -577,15 +538,16 @@ __device__ __noinline__ void bwd1_unprep_q(UnprepArgs a_) {
   for (int j = 0; j < NTOUCH; ++j) asm volatile("" :: "v"(tch[j]));
 }
 
-template <bool TAB, bool DTAB, bool SAFE>
+template <bool TAB, bool DTAB>
 __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1& g, char* dyn) {
   const int L = p.L, nkb = L / 32;
   char* qs = dyn;                                               // Q~ slab
-  char* dos = dyn + L * 64;                                     // dO'' slab
+  char* dos = dyn + L * 64;                                     // dO slab (a plain copy)
   char* dqa = dyn + L * 128;                                    // dQ^T accumulators [tile][4][64 lanes][4] f32 (register r of lane l at (r >> 2, l, r & 3))
-  float* nd = reinterpret_cast<float*>(dyn + L * 256);          // -delta''
-  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 260);  // class table (fixed point)
-  float* misc = reinterpret_cast<float*>(dyn + L * 260 + ((g.ncls * 4 + 15) & ~15));       // [0,16) reductions, [16,48) tile counters, [48,56) park flags
+  float* nd = reinterpret_cast<float*>(dyn + L * 256);          // -delta per query
+  float* nl = reinterpret_cast<float*>(dyn + L * 260);          // log2 K - lse2 per query (before the first item: the step table, see below)
+  uint32_t* dtab = reinterpret_cast<uint32_t*>(dyn + L * 264);  // class table (fixed point)
+  float* misc = reinterpret_cast<float*>(dyn + L * 264 + ((g.ncls * 4 + 15) & ~15));       // [0,16) reductions, [16,48) tile counters, [48,56) park flags
   float* sred = misc + 64;                                      // [2][NW1][32] scale-gradient sums of the waves (k, q) over the items
   int* cnts = reinterpret_cast<int*>(misc + 16);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -593,13 +555,12 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
   const int c = lane & 31, half = lane >> 5, ar = pi32(c);
   const int h = (int)blockIdx.x / x.wph, wgh = (int)blockIdx.x % x.wph;
   const int seq0 = wgh * x.ipw;
-  const float m2 = x.hinfo[2 * h];
   if (DTAB) { for (int i = tid; i < g.ncls; i += NTH1) dtab[i] = 0u; }
   if (tid < 2 * NW1 * 32) sred[tid] = 0.f;
   {   // etab[w][s] = number of updates of query tile t(w, s) = (P w + s) mod nkb made in steps < s by all waves (see bwd1_steps)
     float* ksr = sred + 2 * NW1 * 32;                           // k_scale and 1 / k_scale for the in-loop un-prep of dK (no division, no global load there)
     if (tid < 32) { const float ks = p.k_scale[tid]; ksr[tid] = ks; ksr[32 + tid] = fabsf(ks) > 1e-30f ? 1.f / ks : 0.f; }
-    int* etab = reinterpret_cast<int*>(sred + 2 * NW1 * 32 + 64);
+    int* etab = reinterpret_cast<int*>(nl);                     // (lives where log2 K - lse2 will: every wave takes its row into a register below, before the first item writes there)
     const int NT = nkb * nkb;
     for (int i = tid; i < NW1 * x.P; i += NTH1) {
       const int w = i / x.P, sidx = i - w * x.P, tt = (x.P * w + sidx) % nkb;
@@ -613,6 +574,8 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
       etab[i] = n;
     }
   }
+  __syncthreads();
+  const int etrow = reinterpret_cast<const int*>(nl)[wave * x.P + (lane < x.P ? lane : 0)];      // lane = step (P <= 64); nl is first written behind the load phase's barrier
 
   // One item's load-phase operands (twenty 16-byte pieces per thread)
   u32x4 oq[NPIECE], ov_[NPIECE], od[NPIECE], oo[NPIECE];
@@ -643,23 +606,23 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
     const int64_t so = ((int64_t)h * p.M + (int64_t)seq * L) * D;
     const int64_t tok0 = (int64_t)seq * L;
     // ------------------------------------------------------------------------------------------------ load phase: the item's operands -> LDS
-    // Q~ slab, dO'' = K w dO (w = exp2(m2 - lse2): the factor between the bounded exponentials and the probabilities; K: the fixed-point scale),
-    // -delta'' = -K w sum_d dO O, zeroed dQ^T accumulators, tile counters and park flags
-    float K = 1.f, invK = 1.f;
+    // Q~ slab and dO slab (plain copies), -delta = -sum_d dO O, log2 K - lse2 (K: the fixed-point scale of the item, a power of two), zeroed dQ^T
+    // accumulators, tile counters and park flags
+    float invK = 1.f;
     issue_item(seq);      // (requesting these an item ahead, under the previous item's dQ un-prep, makes hipcc spill every piece as it lands: 20 serial HBM round trips)
     {
-      u32x4 dpc[NPIECE];
-      float wrow[NPIECE], drow[NPIECE];
+      float lsr[NPIECE];
       float mxd = 0.f, mxv = 0.f;
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
         const int pc = k * NTH1 + tid;
         const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
         const u32x4 qv = oq[k], vv = ov_[k], dv = od[k], ov = oo[k];
-        const float ls = ols[k];
+        lsr[k] = ols[k];
         // (no branch in this loop: a branch would end the basic block and the next piece's loads would wait for this piece's -- five HBM
         // round trips instead of one; a clamped piece re-writes the last piece's bytes)
         *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = qv;
+        *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = dv;
         float x8[8], b[8], v8[8];
         unpack8u(dv, x8); unpack8u(ov, b); unpack8u(vv, v8);
         float ds = 0.f, dn = 0.f, vnn = 0.f;
@@ -668,9 +631,8 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
         ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
         dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
         vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
-        const float w = SAFE ? __builtin_amdgcn_exp2f(m2 - ls) : 1.f;
-        wrow[k] = w; drow[k] = ds * w; dpc[k] = dv;
-        mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);                  // |dS| <= P 2 |dO_q| |v_k| with the TRUE probability P <= 1: no w here
+        nd[row] = -ds;                                                // (the four chunk threads of a row hold the same value)
+        mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);                  // |dS| <= P 2 |dO_q| |v_k| with the probability P <= 1
       }
       BWD1_STAMP(1);
       mxd = wave_max(mxd); mxv = wave_max(mxv);
@@ -682,34 +644,27 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
 #pragma unroll
       for (int w8 = 0; w8 < NW1; ++w8) { bd = fmaxf(bd, misc[w8]); bv = fmaxf(bv, misc[8 + w8]); }
       const float B = 2.f * sqrtf(bd) * sqrtf(bv);
+      int kk = 0;
       if (B > 0.f && B < 3.0e38f) {
         int e; (void)frexpf(B, &e);                              // B < 2^e
-        int kk = FIX_BITS - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
-        K = ldexpf(1.f, kk); invK = ldexpf(1.f, -kk);
+        kk = FIX_BITS - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
+        invK = ldexpf(1.f, -kk);
       }
+      const float lgK = (float)kk;                               // K = 2^kk enters through the logits: exp2(s + kk - lse2) = K x probability
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
         const int pc = k * NTH1 + tid;
-        const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2, ch = pcc & 3;      // (clamped: the last row's four chunks, as a quad)
-        float x8[8];
-        unpack8u(dpc[k], x8);
-        const float f = wrow[k] * K;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x8[e] *= f;
-        u32x4 o4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = pack2bf(x8[2 * e], x8[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = o4;
-        nd[row] = -(drow[k] * K);                                // (the four chunk threads of a row hold the same value)
+        const int pcc = pc < 4 * L ? pc : 4 * L - 4 + (pc & 3), row = pcc >> 2;
+        nl[row] = lgK - lsr[k];
       }
     }
     __syncthreads();
     BWD1_STAMP(2);
     // ------------------------------------------------------------------------------------------------ tile steps (+ dK / dV un-prep inside)
     {
-      bwd1_steps<TAB, DTAB, SAFE>(StepArgs{p.kh + so, p.vh + so, p.lse2 + (int64_t)h * p.M + tok0, x.tabadj + (int64_t)h * g.ncls, p.kinv + tok0 * p.H + h,
+      bwd1_steps<TAB, DTAB>(StepArgs{p.kh + so, p.vh + so, x.tabadj + (int64_t)h * g.ncls, p.kinv + tok0 * p.H + h,
                                            p.k_scale, p.dk_tok + tok0 * p.ldk_tok + h * D, p.dv_tok + tok0 * p.ldv_tok + h * D, p.ldk_tok, p.ldv_tok,
-                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, invK, p.H, L, x.P, g, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr,
+                                           x.park + (int64_t)blockIdx.x * NW1 * 64 * 32, invK, p.H, L, x.P, g, etrow, (x.stamps && blockIdx.x == 0) ? x.stamps + it * 16 + 9 : nullptr,
                                            (x.stamps && blockIdx.x == 0) ? x.stamps + 128 : nullptr});
     }
     BWD1_STAMP(3);
@@ -755,8 +710,7 @@ template <bool TAB, bool DTAB>
 __global__ __launch_bounds__(NTH1) void bwd1_kernel(Params p, X1 x, G1 g) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   // the bounded-logit softmax (no row maximum) when the head's logit span allows it, else the classical form: a workgroup-uniform choice
-  if (x.hinfo[2 * ((int)blockIdx.x / x.wph) + 1] != 0.f) bwd1_body<TAB, DTAB, true>(p, x, g, dyn);
-  else bwd1_body<TAB, DTAB, false>(p, x, g, dyn);
+  bwd1_body<TAB, DTAB>(p, x, g, dyn);
 }
 
 // part[nblk][32] -> dst (+=), two vectors per launch (blockIdx.x: 0 = k, 1 = q): 32 interleaved slices, then the slices in a fixed order
@@ -817,7 +771,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
     pl.ncls = (2 * gh - 1) * S;
     pl.g = G1{gw, S, (gh - 1) * S + (gw - 1), (65536 + gw - 1) / gw, pl.ncls, gh};
   }
-  pl.shm = (size_t)L * 260 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4 + 64 * 4;
+  pl.shm = (size_t)L * 264 + (size_t)((pl.ncls * 4 + 15) & ~15) + 256 + 2 * NW1 * 32 * 4 + 64 * 4;
   // (+ the step table, sized after P below)
   if (pl.shm > 160 * 1024) return false;
   int P = (NT + NW1 - 1) / NW1;
@@ -829,8 +783,7 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
   }
   if (P > 64) return false;                                     // (a wave keeps its row of the step table in ONE register, lane = step)
   pl.P = P;
-  pl.shm += (size_t)NW1 * P * 4;
-  if (pl.shm > 160 * 1024) return false;
+  if (NW1 * P > L) return false;                                // (the step table is built where the L per-query floats log2 K - lse2 live later)
   const int ncu = ncus1(), total = nseq * H;
   int ipw = (total + ncu - 1) / ncu;
   while (nseq % ipw) ++ipw;                                     // a workgroup stays inside one head
@@ -847,7 +800,7 @@ extern "C" int ctclip_attn2_bwd_fused_supported(int nseq, int H, int L, int D_, 
 extern "C" int64_t ctclip_attn2_bwd_fused_workspace(int nseq, int H, int L, int bias_gh, int bias_gw) {
   Plan1 pl;
   if (!plan1(nseq, H, L, bias_gh, bias_gw, bias_gh > 0, pl)) return 0;
-  return a256((int64_t)H * pl.ncls * 4) + a256(H * 2 * 4) + a256((int64_t)nseq * H * pl.ncls * 4) + 2 * a256((int64_t)pl.nwg * 32 * 4) +
+  return a256((int64_t)H * pl.ncls * 4) + a256((int64_t)nseq * H * pl.ncls * 4) + 2 * a256((int64_t)pl.nwg * 32 * 4) +
          a256((int64_t)pl.nwg * NW1 * 64 * 32 * 4) + 4096;
 }
 
@@ -876,14 +829,13 @@ extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void
   p.dk_tok = (bf16_t*)dk; p.dv_tok = (bf16_t*)dv; p.ldk_tok = lddk; p.ldv_tok = lddv; p.kinv = kinv;
   char* w = (char*)workspace;
   float* tabadj = (float*)w; w += a256((int64_t)H * pl.ncls * 4);
-  float* hinfo = (float*)w; w += a256(H * 2 * 4);
   float* dtpart = (float*)w; w += a256((int64_t)nseq * H * pl.ncls * 4);
   p.kpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
   float* qpart = (float*)w; w += a256((int64_t)pl.nwg * 32 * 4);
   float* park = (float*)w; w += a256((int64_t)pl.nwg * NW1 * 64 * 32 * 4);
   static const bool stamp = getenv("CTCLIP_BWD1_STAMPS") != nullptr;          // the last 4 KB of the workspace: phase clocks of workgroup 0
-  X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, hinfo, dtab ? dtpart : nullptr, park, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
-  hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, hinfo, pl.ncls);
+  X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, dtab ? dtpart : nullptr, park, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
+  hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, pl.ncls);
   int rc = ctclip_check_launch("attn2_bwd_fused (stage)");
   if (rc) return rc;
   static bool raised = false;

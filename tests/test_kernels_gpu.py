@@ -677,7 +677,8 @@ def test_attn2_bwd_fused_one_pass(hip, ref, nseq, H, gh, gw, gain, with_tab, wan
     tiles) against (a) the f32 checker and (b) the three-pass path it replaces (ctclip_attn2_bwd + ctclip_attn2_unprep).  dv is the same sum in
     the same order -> bit for bit when the key block is not split between two waves; dq / dk are f32 sums in another order -> one bf16 ulp on few
     elements; the table gradient is a fixed-point sum (2^-21 of the item's bound per addend).  Twice: bit-reproducible.  Cases: 70 x 8 items on
-    256 CUs (persistent runs of 3 items), the unbounded-logit path (gain 4), no table (16 x 16), L = 384 (nkb = 12) and L = 512 (nkb = 16: the
+    256 CUs (persistent runs of 3 items), a 4 x logit gain (the three-pass kernels leave their bounded-logit form there; the one pass has a single form:
+    the row's lse2 is subtracted inside the exponent), no table (16 x 16), L = 384 (nkb = 12) and L = 512 (nkb = 16: the
     position stride P is not the plain quotient), no table gradient wanted."""
     L, D, M, q, kv, qs, ks, tab = _attn2_case(nseq, H, gh, gw, gain, with_tab, seed=70)
     HD, bf = H * D, torch.bfloat16
@@ -708,13 +709,20 @@ def test_attn2_bwd_fused_one_pass(hip, ref, nseq, H, gh, gw, gain, with_tab, wan
     dq0, dkv0 = torch.empty(M, HD, dtype=bf, device=DEV), torch.empty(M, 2 * HD, dtype=bf, device=DEV)
     dqs0, dks0 = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
     hip.attn2_unprep(dqh, dkh, dvh, qh, kh, qinv, kinv, qs, ks, 8.0, dq0, dkv0[:, :HD], dkv0[:, HD:], dqs0, dks0)
-    for name, a, b in (("dq", dq, dq0), ("dk", dkv[:, :HD], dkv0[:, :HD]), ("dv", dkv[:, HD:], dkv0[:, HD:])):
-        close(a, b, rtol=2 ** -6, atol=2e-3 * float(b.float().abs().max()) + 1e-30)
-        assert float((a != b).float().mean()) < 0.08, name                          # another summation order: a bf16 ulp here and there
+    # The one-pass kernel rounds to bf16 at other points than the three passes (K x probability and the RAW dO slab, against bounded exponentials and
+    # the row factor folded into a re-rounded dO): element-wise the two agree to a few bf16 ulps, and against the f32 checker the one pass must not
+    # be the worse of the two.
+    for name, a, b, r in (("dq", dq, dq0, rq), ("dk", dkv[:, :HD], dkv0[:, :HD], rkv[:, :HD]), ("dv", dkv[:, HD:], dkv0[:, HD:], rkv[:, HD:])):
+        close(a, b, rtol=2 ** -5, atol=4e-3 * float(b.float().abs().max()) + 1e-30)
+        e1 = float((a.float() - r.float()).norm() / r.float().norm()); e3 = float((b.float() - r.float()).norm() / r.float().norm())
+        print(f"[attn2_bwd_fused {nseq}x{H} {gh}x{gw}] {name}: one pass {e1:.3e}, three passes {e3:.3e} against the f32 checker; {float((a != b).float().mean()):.3f} of the elements differ")
+        assert e1 <= 1.1 * e3 + 1e-6, (name, e1, e3)
     close(dqs, dqs0, rtol=1e-3, atol=1e-3 * float((dqs0 - 1).abs().max())); close(dks, dks0, rtol=1e-3, atol=1e-3 * float((dks0 - 1).abs().max()))
     if want_dtab:
         err = (dtab - dtab0).norm() / dtab0.norm()
-        assert err < 2e-3, float(err)
+        e1, e3 = float((dtab - rtab).norm() / rtab.norm()), float((dtab0 - rtab).norm() / rtab.norm())
+        print(f"[attn2_bwd_fused {nseq}x{H} {gh}x{gw}] table gradient: one pass {e1:.3e}, three passes {e3:.3e} against the f32 checker, {float(err):.3e} between them")
+        assert err < 4e-3 and e1 <= max(1.1 * e3, 2e-4), (float(err), e1, e3)      # (2e-4: the fixed-point grid, 2^-21 of the item's bound per addend)
     # bit-reproducible (integer scatter, fixed summation orders)
     dq2, dkv2, dqs2, dks2 = torch.empty_like(dq), torch.empty_like(dkv), torch.ones(D, device=DEV), torch.ones(D, device=DEV)
     res2 = hip.attn2_bwd_fused(qh, kh, vh, tab, grid, qs, ks, 8.0, o, do, lse2, qinv, kinv, dq2, dkv2[:, :HD], dkv2[:, HD:], dqs2, dks2, nseq, L, want_dtab)
