@@ -92,11 +92,7 @@ class CTCLIP(nn.Module):
         import os
         if device.type != "cuda" or os.environ.get("CTCLIP_TEXT_STREAM", "1") == "0":
             return None
-        st = self.__dict__.get("_side_stream")
-        if st is None:
-            st = Fn.register_side_stream(torch.cuda.Stream(device=device))      # (the fused optimiser joins it before reading gradients)
-            self.__dict__["_side_stream"] = st
-        return st
+        return Fn.shared_side_stream(device, "text")      # one per device and process (the fused optimiser joins it before reading gradients)
 
     def tokenize(self, prompt):
         if self.tokenizer is None:

@@ -190,6 +190,22 @@ def register_side_stream(st):
     return st
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_side_stream(device, name):
+    """ONE side stream per (device, purpose) for the whole process, registered for the optimiser's join.  Every model instance used to create its
+    own text-tower stream; the third model of a process (bench.py's T = 512 configuration after the 12+12 and 4+4 ones) then ran 4 ... 19 ms per
+    step slower than the same configuration in a fresh process (box-dependent; consistent with HIP multiplexing streams onto a handful of hardware
+    queues in creation order: a text stream that shares its queue with the main stream runs serialised behind the image tower).  With one stream per
+    process a configuration no longer depends on what ran before it (tools/probe_config_sequence.py)."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), name)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = register_side_stream(torch.cuda.Stream(device=device))
+    return st
+
+
 def join_side_streams():
     """The current stream of each device waits for every registered side stream of that device."""
     for st in _SIDE_STREAMS:
