@@ -525,3 +525,67 @@ def test_bwd1_fixed_point_rounding_and_class_counts():
             acc = np.uint32(acc + (np.float32(v) + np.float32(12582912.0)).view(np.uint32))
         back = np.uint32(acc - np.uint32(576) * np.uint32(0x4B400000)).view(np.int32)
     assert int(back) == int(vals.sum())
+
+
+def test_bwd1_step_table_fits_its_register_and_its_lds_alias():
+    """Round 4, second form: a wave keeps its row of the step table in ONE register (lane = step: P <= 64) and the table is built where the L
+    per-query floats log2 K - lse2 live later (8 P <= L); plan1() declines a shape that breaks either."""
+    for nkb in range(8, 21):                                     # L = 256 .. 640 (4 L <= NPIECE * 512)
+        _, p = _bwd1_plan(nkb)
+        assert p <= 64 and 8 * p <= 32 * nkb, (nkb, p)
+
+
+def test_bwd1_three_term_bf16_split_carries_an_f32():
+    """The per-query terms (-delta_q, log2 K - lse2_q) enter the score / dP tiles as a matrix product: A row = the f32 value split into three bf16
+    terms (hi = bf16(v), lo = bf16(v - hi), lolo = bf16(v - hi - lo)), B = ones.  The f32 sum of the three products must return the value to
+    f32 rounding (24 mantissa bits in three 8-bit pieces), for magnitudes from 1e-28 to 1e+30 (below ~1e-33 the third term is subnormal and flushed:
+    2^-20 relative there, on values that are zero for every purpose of the kernel) and for exact integers (log2 K)."""
+    import numpy as np
+
+    def bf16(x):                                                  # round-to-nearest-even on the upper 16 bits, as v_cvt_pk_bf16_f32
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    rng = np.random.default_rng(1)
+    v = np.concatenate([(1.0 + np.abs(rng.standard_normal(100000))) * rng.choice([-1.0, 1.0], 100000) * 10.0 ** rng.uniform(-28, 30, 100000), np.arange(-100, 101, dtype=np.float64),
+                        -rng.uniform(0, 40, 50000)]).astype(np.float32)
+    hi = bf16(v)
+    r1 = (v - hi).astype(np.float32)
+    lo = bf16(r1)
+    r2 = (r1 - lo).astype(np.float32)
+    ll = bf16(r2)
+    back = ((hi.astype(np.float32) + lo) + ll).astype(np.float32)     # the MFMA adds the three products in f32
+    err = np.abs(back.astype(np.float64) - v.astype(np.float64))
+    assert np.all(err <= np.abs(v.astype(np.float64)) * 2.0 ** -23), float((err / np.maximum(np.abs(v), 1e-38)).max())
+    ints = np.arange(-100, 101, dtype=np.float32)
+    assert np.array_equal(bf16(ints), ints)                       # log2 K is an integer in [-100, 100]: ONE term already exact
+
+
+def test_bwd1_touch_chunks_cover_every_line_of_the_next_item():
+    """bwd1_unprep_q touches the next item's operands one dword per 128-byte line: wave-uniform chunks of 64 lines, chunk j * 8 + wave (j < NTOUCH = 5)
+    walking Q~ | V | K^ (L / 2 lines each) | dout | o (L rows, one line per row) | lse2 (L / 32 lines), every segment padded to whole chunks and
+    lines past a segment clamped to its last one.  Every line of every segment must be touched, for every supported L."""
+    NTOUCH, NW = 5, 8
+    for L in range(256, 641, 32):
+        hl, cq, cr = L // 2, (L // 2 + 63) >> 6, (L + 63) >> 6
+        assert 3 * cq + 2 * cr + 1 <= NTOUCH * NW, L
+        seen = {sg: set() for sg in range(6)}
+        for j in range(NTOUCH):
+            for wave in range(NW):
+                r, sg = j * NW + wave, 0
+                if r >= cq:
+                    r -= cq; sg = 1
+                if sg == 1 and r >= cq:
+                    r -= cq; sg = 2
+                if sg == 2 and r >= cq:
+                    r -= cq; sg = 3
+                if sg == 3 and r >= cr:
+                    r -= cr; sg = 4
+                if sg == 4 and r >= cr:
+                    r -= cr; sg = 5
+                nl = hl if sg < 3 else (L if sg < 5 else L // 32)
+                for lane in range(64):
+                    seen[sg].add(min(r * 64 + lane, nl - 1))
+        for sg in range(6):
+            nl = hl if sg < 3 else (L if sg < 5 else L // 32)
+            assert seen[sg] == set(range(nl)), (L, sg)
