@@ -76,12 +76,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // add1 / add2: gradients that reach the same activation through its other consumers (the residual connection, the k/v projection
 // of the raw tokens): summed here instead of by two elementwise kernels over the 113-MB tensor.
 // Per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy are written to part[block][2][cols].
-template <typename T, int NV>
+template <typename T, int NV, int RU>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows, int cols,
                                                             const T* __restrict__ add1, const T* __restrict__ add2) {
+  // RU rows per wave in flight, and the add operands requested TOGETHER with dy / x (they used to be requested behind the two wave
+  // reductions: a second memory round trip per row).  tools/ubench/stream_rates.hip, cold operands: 109 -> 104 us with two adds.
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int cc[NV]; bool ok[NV];
@@ -92,43 +94,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[i][e] = gamma ? gamma[cc[i] + e] : 1.f; dg[i][e] = 0.f; db[i][e] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float a[NV][8], b[NV][8];
+  for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RU; row0 < rows; row0 += (int64_t)gridDim.x * 4 * RU) {
+    float a[RU][NV][8], b[RU][NV][8], r1[RU][NV][8], r2[RU][NV][8], mu[RU], rs[RU];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { load8(dy + row * cols + cc[i], a[i]); load8(x + row * cols + cc[i], b[i]); }
-    float s1 = 0.f, s2 = 0.f;
+    for (int u = 0; u < RU; ++u) {
+      const int64_t row = row0 + u < rows ? row0 + u : rows - 1;      // clamped, never branch around a load
+      mu[u] = mean[row]; rs[u] = rstd[row];
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = (b[i][e] - mu) * rs;
-        const float dyv = ok[i] ? a[i][e] : 0.f;
-        const float g = dyv * gm[i][e];
-        b[i][e] = xh; a[i][e] = g;
-        s1 += g; s2 += g * xh;
-        dg[i][e] += dyv * xh; db[i][e] += dyv;
+      for (int i = 0; i < NV; ++i) {
+        load8(dy + row * cols + cc[i], a[u][i]); load8(x + row * cols + cc[i], b[u][i]);
+        if (add1) load8(add1 + row * cols + cc[i], r1[u][i]);       // kernel-uniform
+        if (add2) load8(add2 + row * cols + cc[i], r2[u][i]);
       }
-    s1 = wave_sum(s1) / cols;
-    s2 = wave_sum(s2) / cols;
+    }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      float o[8];
+    for (int u = 0; u < RU; ++u) {
+      const bool live = row0 + u < rows;
+      const int64_t row = live ? row0 + u : rows - 1;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rs * (a[i][e] - s1 - b[i][e] * s2);
-      if (add1) {       // kernel-uniform
-        float r1[8];
-        load8(add1 + row * cols + cc[i], r1);
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r1[e];
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (b[u][i][e] - mu[u]) * rs[u];
+          const float dyv = (ok[i] && live) ? a[u][i][e] : 0.f;
+          const float g = dyv * gm[i][e];
+          b[u][i][e] = xh; a[u][i][e] = g;
+          s1 += g; s2 += g * xh;
+          dg[i][e] += dyv * xh; db[i][e] += dyv;
+        }
+      s1 = wave_sum(s1) / cols;
+      s2 = wave_sum(s2) / cols;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs[u] * (a[u][i][e] - s1 - b[u][i][e] * s2);
+        if (add1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r1[u][i][e];
+        }
+        if (add2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r2[u][i][e];
+        }
+        if (ok[i] && live) store8(dx + row * cols + cc[i], o);
       }
-      if (add2) {
-        float r2[8];
-        load8(add2 + row * cols + cc[i], r2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r2[e];
-      }
-      if (ok[i]) store8(dx + row * cols + cc[i], o);
     }
   }
   if (!part) return;
@@ -347,8 +358,9 @@ extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* 
   float* part = want ? (float*)workspace : nullptr;
   const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
   const int nv = (cols + 511) / 512;
-#define LNB(T, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols, (const T*)add1, (const T*)add2)
-#define LNB_NV(T) do { if (nv == 1) LNB(T, 1); else if (nv == 2) LNB(T, 2); else if (nv == 3) LNB(T, 3); else LNB(T, 4); } while (0)
+  const bool two = nv == 1 && rows >= 65536;        // two rows in flight per wave on the big token grids of the image tower
+#define LNB(T, NVV, RUU) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV, RUU>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols, (const T*)add1, (const T*)add2)
+#define LNB_NV(T) do { if (nv == 1) { if (two) LNB(T, 1, 2); else LNB(T, 1, 1); } else if (nv == 2) LNB(T, 2, 1); else if (nv == 3) LNB(T, 3, 1); else LNB(T, 4, 1); } while (0)
   if (dtype == DT_F32) LNB_NV(float);
   else if (dtype == DT_BF16) LNB_NV(bf16_t);
   else return CTCLIP_EUNSUPPORTED;
