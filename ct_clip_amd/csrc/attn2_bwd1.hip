@@ -117,7 +117,7 @@ __device__ __forceinline__ float uni(float v) { return __uint_as_float((uint32_t
 
 // Compile-time ablation mask (tools/build_variant.py; never set in the product build -- results are WRONG, timing only): 1 = no class-table
 // atomics, 2 = no dQ^T update at all (no wait, no read-modify-write), 4 = no exponential, 8 = no L2 touches, 16 = no dV / dK products and no
-// transposing reads of Q~ / dO'', 32 = no bias loads, 64 = dQ^T update without the tile-counter wait
+// transposing reads of Q~ / dO, 32 = no bias loads, 64 = dQ^T update without the tile-counter wait
 #ifndef BWD1_ABL
 #define BWD1_ABL 0
 #endif
@@ -709,7 +709,6 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
 template <bool TAB, bool DTAB>
 __global__ __launch_bounds__(NTH1) void bwd1_kernel(Params p, X1 x, G1 g) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
-  // the bounded-logit softmax (no row maximum) when the head's logit span allows it, else the classical form: a workgroup-uniform choice
   bwd1_body<TAB, DTAB>(p, x, g, dyn);
 }
 
