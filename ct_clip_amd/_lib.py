@@ -85,8 +85,8 @@ SIGNATURES = {
     "ctclip_patch_embed_param_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ctclip_permute0213": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "ctclip_transpose2d": (_I, [_P, _P, _I, _I, _L, _L, _I, _P]),
-    "ctclip_pool_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),
-    "ctclip_pool_bwd": (_I, [_P, _P, _L, _I, _L, _I, _P]),
+    "ctclip_pool_fwd": (_I, [_P, _P, _L, _I, _L, _I, _I, _P]),
+    "ctclip_pool_bwd": (_I, [_P, _P, _L, _I, _L, _I, _I, _P]),
     "ctclip_convert_pad": (_I, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _P]),
     "ctclip_cpb_expand": (_I, [_P, _P, _I, _I, _I, _P]),
     "ctclip_cpb_reduce": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -695,18 +695,18 @@ class HipBackend:
                    "ctclip_transpose2d")
         return y
 
-    def pool_fwd(self, x):
+    def pool_fwd(self, x, out_dtype=None):
         B, t, R = x.shape
         assert x.is_contiguous()
-        y = torch.empty((B, R), dtype=x.dtype, device=x.device)
-        _lib.check(self.lib.ctclip_pool_fwd(_p(x), _p(y), B, t, R, dcode(x.dtype), _stream()), "ctclip_pool_fwd")
+        y = torch.empty((B, R), dtype=out_dtype or x.dtype, device=x.device)
+        _lib.check(self.lib.ctclip_pool_fwd(_p(x), _p(y), B, t, R, dcode(x.dtype), dcode(y.dtype), _stream()), "ctclip_pool_fwd")
         return y
 
-    def pool_bwd(self, dy, t):
+    def pool_bwd(self, dy, t, out_dtype=None):
         B, R = dy.shape
         assert dy.is_contiguous()
-        dx = torch.empty((B, t, R), dtype=dy.dtype, device=dy.device)
-        _lib.check(self.lib.ctclip_pool_bwd(_p(dy), _p(dx), B, t, R, dcode(dy.dtype), _stream()), "ctclip_pool_bwd")
+        dx = torch.empty((B, t, R), dtype=out_dtype or dy.dtype, device=dy.device)
+        _lib.check(self.lib.ctclip_pool_bwd(_p(dy), _p(dx), B, t, R, dcode(dy.dtype), dcode(dx.dtype), _stream()), "ctclip_pool_bwd")
         return dx
 
     def convert_pad(self, src, rows_dst, cols_dst, dtype, colscale=None, out=None):

@@ -18,8 +18,14 @@ def is_hf_bert(module):
         and hasattr(module.embeddings, "word_embeddings")
 
 
-def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
-    """Returns last_hidden_state as a (B*T, hidden) activation in ``dtype``."""
+def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype=None):
+    """Returns last_hidden_state as a (B*T, hidden) activation in ``dtype``.
+
+    operand_dtype (mixed precision, the default of the bf16 mode: dtype = f32, operand_dtype = bf16): the residual stream, both
+    LayerNorms of a layer, bias / dropout / residual adds, GELU and every GEMM's accumulate-and-store are f32 -- what torch.autocast
+    keeps in f32 around an HF BertModel -- and bf16 appears only where the matrix cores read it: the GEMM operands (each f32 activation
+    rounded once on its way into a GEMM), q | k | v and the attention core.  M = B*T rows x 768: the f32 tensors are a few MB."""
+    od = operand_dtype if (operand_dtype is not None and operand_dtype != dtype) else None
     cfg = bert.config
     if getattr(cfg, "hidden_act", "gelu") != "gelu":
         raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU BERT is implemented")
@@ -56,17 +62,17 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype):
         x = Fn.grad_ready(x, layer)
         sa, so = layer.attention.self, layer.attention.output
         c = Fn.QkvSdpaFn.apply(x, sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias, keymask,
-                               Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None)
+                               Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None, od)
         if p_hid > 0:    # dense -> dropout -> + input -> LayerNorm
-            h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias), x, 1 + 2 * li)
+            h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias, out_dtype=dtype, operand_dtype=od), x, 1 + 2 * li)
         else:
-            h1 = Fn.linear(c, so.dense.weight, so.dense.bias, residual=x)
+            h1 = Fn.linear(c, so.dense.weight, so.dense.bias, residual=x, out_dtype=dtype, operand_dtype=od)
         x = Fn.layer_norm(h1, so.LayerNorm.weight, so.LayerNorm.bias, eps)
-        u = Fn.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias)
+        u = Fn.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, operand_dtype=od)
         m = Fn.GeluFn.apply(u)
         if p_hid > 0:
-            h2 = drop(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias), x, 2 + 2 * li)
+            h2 = drop(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, operand_dtype=od), x, 2 + 2 * li)
         else:
-            h2 = Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x)
+            h2 = Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x, operand_dtype=od)
         x = Fn.layer_norm(h2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
     return x

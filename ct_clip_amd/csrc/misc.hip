@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ 
 }
 
 // ---- mean over the depth-token axis (ct_clip.py:724): x (B, t, R) -> y (B, R); backward broadcasts dy / t
-template <typename T>
-__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t B, int t, int64_t R) {
+template <typename T, typename TO>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, TO* __restrict__ y, int64_t B, int t, int64_t R) {
   const int64_t G = R / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * G; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / G, c = (i % G) * 8;
@@ -188,8 +188,8 @@ __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int6
     store8(y + b * R + c, acc);
   }
 }
-template <typename T>
-__global__ void pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t B, int t, int64_t R) {
+template <typename T, typename TO>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, TO* __restrict__ dx, int64_t B, int t, int64_t R) {
   const int64_t G = R / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * t * G; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = (i % G) * 8; const int64_t bt = i / G; const int64_t b = bt / t;
@@ -385,16 +385,26 @@ extern "C" int ctclip_transpose2d(const void* x, void* y, int R, int C, int64_t 
   BY_DTYPE(dtype, hipLaunchKernelGGL(transpose2d_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (T*)y, R, C, ldx, ldy));
   return ctclip_check_launch("transpose2d");
 }
-extern "C" int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s) {
+// (dtype, out_dtype): the mixed-precision head pools bf16 tokens into an f32 vector and hands the f32 gradient back as bf16
+#define BY_DTYPE2(din, dout, KERNEL, GRID, ...)                                                                                        \
+  if (din == DT_F32 && dout == DT_F32) hipLaunchKernelGGL((KERNEL<float, float>), GRID, dim3(256), 0, s, (const float*)src_, (float*)dst_, __VA_ARGS__);          \
+  else if (din == DT_BF16 && dout == DT_BF16) hipLaunchKernelGGL((KERNEL<bf16_t, bf16_t>), GRID, dim3(256), 0, s, (const bf16_t*)src_, (bf16_t*)dst_, __VA_ARGS__); \
+  else if (din == DT_BF16 && dout == DT_F32) hipLaunchKernelGGL((KERNEL<bf16_t, float>), GRID, dim3(256), 0, s, (const bf16_t*)src_, (float*)dst_, __VA_ARGS__);   \
+  else if (din == DT_F32 && dout == DT_BF16) hipLaunchKernelGGL((KERNEL<float, bf16_t>), GRID, dim3(256), 0, s, (const float*)src_, (bf16_t*)dst_, __VA_ARGS__);   \
+  else { ctclip_set_error("unsupported dtype pair"); return CTCLIP_EUNSUPPORTED; }
+extern "C" int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, int out_dtype, hipStream_t s) {
   if (!x || !y || R % 8) { ctclip_set_error("pool_fwd: R must be a multiple of 8"); return CTCLIP_EBADARG; }
-  BY_DTYPE(dtype, hipLaunchKernelGGL(pool_fwd_kernel<T>, grid_for(B * R / 8), dim3(256), 0, s, (const T*)x, (T*)y, B, t, R));
+  const void* src_ = x; void* dst_ = y;
+  BY_DTYPE2(dtype, out_dtype, pool_fwd_kernel, grid_for(B * R / 8), B, t, R);
   return ctclip_check_launch("pool_fwd");
 }
-extern "C" int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, hipStream_t s) {
+extern "C" int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, int out_dtype, hipStream_t s) {
   if (!dy || !dx || R % 8) { ctclip_set_error("pool_bwd: bad args"); return CTCLIP_EBADARG; }
-  BY_DTYPE(dtype, hipLaunchKernelGGL(pool_bwd_kernel<T>, grid_for(B * t * R / 8), dim3(256), 0, s, (const T*)dy, (T*)dx, B, t, R));
+  const void* src_ = dy; void* dst_ = dx;
+  BY_DTYPE2(dtype, out_dtype, pool_bwd_kernel, grid_for(B * t * R / 8), B, t, R);
   return ctclip_check_launch("pool_bwd");
 }
+#undef BY_DTYPE2
 extern "C" int ctclip_convert_pad(const void* src, void* dst, const float* colscale, int64_t rows, int64_t cols, int64_t lds_,
                                   int64_t rows_dst, int64_t cols_dst, int64_t ldd, int src_dtype, int dst_dtype, hipStream_t s) {
   if (!src || !dst) return CTCLIP_EBADARG;

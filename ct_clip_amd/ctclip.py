@@ -67,14 +67,34 @@ class CTCLIP(nn.Module):
         if hasattr(image_encoder, "compute_dtype"):
             image_encoder.compute_dtype = self.compute_dtype
         self.gather_negatives = gather_negatives
-        # dtype of the text tower's activations / GEMM operands: None = the compute dtype; CTCLIP_TEXT_DTYPE=f32 (or the attribute) keeps BERT in
-        # f32 while the image tower runs in bf16 (M = B*T rows on a side stream: 1 % of the step's FLOPs, most of the teacher-forced loss error)
+        # Precision of the text tower when the image tower computes in bf16 (attribute, or CTCLIP_TEXT_DTYPE):
+        #   None / "mixed" (default)  f32 residual stream, LayerNorms, bias / dropout / residual adds and GELU; bf16 only where the matrix cores
+        #                             read it (GEMM operands, q | k | v, the attention core) -- torch.autocast's split for an HF BertModel.  The
+        #                             all-bf16 tower's 48 roundings of the post-LN stream were most of the teacher-forced loss error (1.0e-3 at
+        #                             12+12 layers against 1.9e-5 with an f32 tower); M = B*T rows x 768 in f32 is a few MB per tensor;
+        #   torch.float32 / "f32"     everything in f32, GEMMs included (16x the matrix-core time);
+        #   torch.bfloat16 / "bf16"   the all-bf16 tower of rounds 1-4.
         import os
         env = os.environ.get("CTCLIP_TEXT_DTYPE", "").lower()
-        self.text_compute_dtype = torch.float32 if env in ("f32", "fp32", "float32") else torch.bfloat16 if env in ("bf16", "bfloat16") else None
+        self.head_dtype = torch.bfloat16 if os.environ.get("CTCLIP_HEAD_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
+        self.text_compute_dtype = (torch.float32 if env in ("f32", "fp32", "float32") else torch.bfloat16 if env in ("bf16", "bfloat16")
+                                   else "mixed" if env == "mixed" else None)
 
-    def _text_dtype(self):
-        return self.text_compute_dtype or self.compute_dtype
+    def pool_tokens(self, enc_tokens):
+        """(Bi, t, h, w, d) quantised tokens -> (Bi, h*w*d) depth mean (ct_clip.py:724,740).  bf16 mode: the pooled vector is f32 and so is
+        everything behind it (to_visual_latent against the f32 master weight, l2norm, logits): the head of the image tower is a 151-M-weight
+        GEMV of B rows -- HBM-bound either way (+0.3 GB of weight reads per pass) -- and its bf16 operands were most of what the image side
+        contributed to the loss error with teacher-forced codes (tiny configuration: 6.0e-4 of 1.33e-3).  CTCLIP_HEAD_DTYPE=bf16 restores it."""
+        Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
+        out = torch.float32 if (enc_tokens.dtype == torch.bfloat16 and self.head_dtype != torch.bfloat16) else None
+        return Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1), out)
+
+    def _text_dtypes(self):
+        """-> (activation dtype, matrix-core operand dtype or None = the same)."""
+        t = self.text_compute_dtype
+        if t in (None, "mixed"):
+            return (torch.float32, torch.bfloat16) if self.compute_dtype == torch.bfloat16 else (self.compute_dtype, None)
+        return t, None
 
     def load(self, path):
         """ct_clip.py:593-597.  Additive: the trainer's periodic checkpoints are written from the DDP-wrapped model with
@@ -105,13 +125,13 @@ class CTCLIP(nn.Module):
     def encode_text(self, text):
         """HF BatchEncoding-like (.input_ids, .attention_mask) -> (Bt, dim_latent) l2-normalised f32 text latents (ct_clip.py:685-686,762,771)."""
         ids, mask = text.input_ids, text.attention_mask
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self._text_dtype())
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes())
         cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
         return Fn.l2norm_f32(Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32))
 
     def text_latents_raw(self, ids, mask):
         """(Bt, T) ids / mask -> (Bt, dim_latent) f32 text latents BEFORE l2norm (ct_clip.py:685-686,762,765), differentiable."""
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, self._text_dtype())
+        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes())
         cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
         cls = Fn.grad_ready(cls, self.to_text_latent)
         return Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)
@@ -119,8 +139,7 @@ class CTCLIP(nn.Module):
     def encode_image(self, image, return_tokens=False):
         """(Bi, 1, F, H, W) volume -> (Bi, dim_latent) l2-normalised f32 image latents (ct_clip.py:715-767,771) [, the token grid]."""
         enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)
-        Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
-        enc_image = Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1))
+        enc_image = self.pool_tokens(enc_tokens)
         lat = Fn.l2norm_f32(Fn.visual_latent(enc_image, self.to_visual_latent.weight))
         return (lat, enc_tokens) if return_tokens else lat
 
@@ -129,7 +148,7 @@ class CTCLIP(nn.Module):
         # freeze_* are accepted and ignored exactly as in the reference (ct_clip.py:709-715)
         if aug_text is not None or aug_image is not None:
             raise NotImplementedError("multiview augmentation is never used by CT-CLIP's entry scripts")
-        dt = self._text_dtype()
+        dt, od = self._text_dtypes()
         ids, mask = text.input_ids, text.attention_mask
         Bt, T = ids.shape
         # The text tower (M = B*T rows: far too small to fill 256 CUs) runs on a side stream underneath the image tower;
@@ -139,15 +158,15 @@ class CTCLIP(nn.Module):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)   # (Bt*T, dim_text)
+                enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od)   # (Bt*T, dim_text)
         else:
-            enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt)
+            enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od)
         enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)                 # (Bi, t, h, w, d)
         if side is not None:
             main.wait_stream(side)
             enc_text.record_stream(main)
-        Bi, t = enc_tokens.shape[0], enc_tokens.shape[1]
-        enc_image = Fn.PoolFn.apply(enc_tokens.reshape(Bi, t, -1))                               # ct_clip.py:724,740
+        Bi = enc_tokens.shape[0]
+        enc_image = self.pool_tokens(enc_tokens)                                                 # ct_clip.py:724,740
         if return_encodings:
             return enc_text.view(Bt, T, -1), enc_image
         cls = enc_text.view(Bt, -1)[:, :self.dim_text]                                          # enc_text[:, 0, :] (ct_clip.py:762)

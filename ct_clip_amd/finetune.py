@@ -226,7 +226,7 @@ class VocabFineTrainer:
         pooled = []
         for j in range(len(token_pairs)):
             q, _ = vt.vq(pre)
-            pooled.append(Fn.PoolFn.apply(q.view(b, t, -1)))                          # (1, h*w*d)
+            pooled.append(model.pool_tokens(q.view(b, t, h, w, -1)))                  # (1, h*w*d)
         image_lat = Fn.visual_latent(torch.cat(pooled, dim=0), model.to_visual_latent.weight)      # (P, Dl) f32, pre-l2norm
         total = None
         for k in range(0, len(token_pairs), self.group_size):

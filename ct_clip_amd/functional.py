@@ -7,8 +7,8 @@ Weight handling
   * each Linear weight has a compute-dtype *shadow* (bf16 in performance mode), possibly padded / re-laid
     out for 16-byte rows and MFMA tiles, refreshed when the parameter's version counter changes;
   * weight gradients are written straight into ``param._ctclip_grad_sink`` (a view of the trainer's flat f32
-    gradient buffer, accumulated with split-K atomics) when present -- autograd then sees ``None`` for that
-    input; otherwise a fresh f32 gradient tensor is returned as usual.
+    gradient buffer; split-K partial sums go through f32 slabs and a fixed-order reduce -- the library has no float atomics)
+    when present -- autograd then sees ``None`` for that input; otherwise a fresh f32 gradient tensor is returned as usual.
 """
 import os
 
@@ -340,15 +340,21 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype, comp=None):
-        """comp = the residue e of `residual`: the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled)."""
+        """comp = the residue e of `residual`: the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled).
+        Mixed precision (x f32, wsh bf16 -- the text tower's default in bf16 mode): x is rounded ONCE to the operand dtype for the matrix
+        cores, the product is accumulated, biased, added to the residual and stored in f32; backward rounds dy the same way and returns dx
+        in x's dtype."""
         e_out = None
+        ctx.x_dtype = x.dtype
+        if x.dtype != wsh.dtype:
+            x = B().convert_pad(x, x.shape[0], x.shape[1], wsh.dtype)
         if comp is not None and bias is None and residual is not None:
             pair = B().gemm_residual_comp(x, wsh, residual, comp)
             if pair is not None:
                 y, e_out = pair
         if e_out is None:
             y = B().gemm(x, wsh, bias=bias.detach() if bias is not None else None, residual=residual,
-                         out_dtype=out_dtype or x.dtype)
+                         out_dtype=out_dtype or ctx.x_dtype)
         ctx.save_for_backward(x, wsh)
         ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
         ctx.has_res = residual is not None
@@ -382,22 +388,24 @@ class LinearFn(Function):
             if dyc.dtype == torch.bfloat16 and dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0:
                 # big grad-input GEMM: use the transposed weight shadow so that both operands are k-contiguous (global_load_lds path)
                 wt = transposed_shadow(ctx.weight, wsh, ctx.segments)
-                dx = B().gemm(dyc, wt)
+                dx = B().gemm(dyc, wt, out_dtype=ctx.x_dtype)
             else:
-                dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False)
+                dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype)
             if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
                 dx = dx[:, :x.shape[1]]
         db = None
         if ctx.bias is not None and ctx.bias.requires_grad:
-            db = vec_grad(ctx.bias, lambda dst: B().colsum(dyc, dst, N=ctx.bias.numel()))
+            dyb = dy if (dy.dtype == torch.float32 and dy.stride(1) == 1) else dyc      # (mixed precision: the bias gradient sums the unrounded dy)
+            db = vec_grad(ctx.bias, lambda dst: B().colsum(dyb, dst, N=ctx.bias.numel()))
         return dx, dw, db, dres, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None):
+def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None, operand_dtype=None):
     """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros).  comp = the residue e of `residual`: the residual add on the
-    compensated residual stream -> (y, e_out)."""
+    compensated residual stream -> (y, e_out).  operand_dtype: dtype of the matrix-core operands when it differs from the activation's
+    (mixed precision: f32 activations, bf16 operands, f32 accumulate / bias / residual / output)."""
     N, K = weight.shape
-    wsh = plain_shadow(weight, x.dtype, kpad=kpad)
+    wsh = plain_shadow(weight, operand_dtype or x.dtype, kpad=kpad)
     return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype, comp)
 
 
@@ -1063,9 +1071,14 @@ class QkvSdpaFn(Function):
     runs one grad-input GEMM and three weight-gradient GEMMs on column views."""
 
     @staticmethod
-    def forward(ctx, x, wq, wk, wv, bq, bk, bv, keymask, nseq, L, H, D, scale, dropout):
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, keymask, nseq, L, H, D, scale, dropout, operand_dtype=None):
+        """operand_dtype (mixed precision): x arrives in f32, is rounded once to the operand dtype; q | k | v, the attention core and its
+        output are in the operand dtype (they are matrix-core operands of QK^T, PV and the output projection), dx returns in f32."""
         be = B()
         N, K = wq.shape
+        ctx.x_dtype = x.dtype
+        if operand_dtype is not None and x.dtype != operand_dtype:
+            x = be.convert_pad(x, x.shape[0], x.shape[1], operand_dtype)
 
         def make_w():
             out = torch.empty((3 * N, K), dtype=x.dtype, device=x.device)
@@ -1098,13 +1111,13 @@ class QkvSdpaFn(Function):
         dqkv = torch.empty_like(qkv)
         be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, keymask if has_mask else None, dqkv[:, :N], dqkv[:, N:2 * N], dqkv[:, 2 * N:], None,
                     nseq, H, L, D, scale, dropout=dropout)
-        dx = be.gemm(dqkv, wsh, a_kc=True, b_kc=False) if ctx.needs_input_grad[0] else None
+        dx = be.gemm(dqkv, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype) if ctx.needs_input_grad[0] else None
         grads = []
         for i, w in enumerate((wq, wk, wv)):
             grads.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)
         for i, b in enumerate((bq, bk, bv)):
             grads.append(vec_grad(b, lambda dst, i=i: be.colsum(dqkv[:, i * N:(i + 1) * N], dst, N=N)) if b.requires_grad else None)
-        return (dx, *grads, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None, None)
 
 
 class DropoutAddFn(Function):
@@ -1173,14 +1186,17 @@ class Permute0213Fn(Function):
 
 
 class PoolFn(Function):
+    """ct_clip.py:724: mean over the depth axis of the (B, t, h*w*d) token grid.  out_dtype (mixed-precision head: f32 from bf16 tokens):
+    the pooled vector and everything behind it -- to_visual_latent, l2norm, logits -- are f32; backward hands the tokens' dtype back."""
+
     @staticmethod
-    def forward(ctx, x):
-        ctx.t = x.shape[1]
-        return B().pool_fwd(x)
+    def forward(ctx, x, out_dtype=None):
+        ctx.t, ctx.in_dtype = x.shape[1], x.dtype
+        return B().pool_fwd(x, out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        return B().pool_bwd(dy.contiguous(), ctx.t)
+        return B().pool_bwd(dy.contiguous(), ctx.t, ctx.in_dtype), None
 
 
 class CpbExpandFn(Function):

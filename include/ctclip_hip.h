@@ -222,10 +222,10 @@ int ctclip_permute0213(const void* x, void* y, int64_t A, int B, int C, int D, i
 int ctclip_transpose2d(const void* x, void* y, int R, int C, int64_t ldx, int64_t ldy, int dtype, hipStream_t s);
 
 /* torch.mean(enc_image, dim=1) (ct_clip.py:724). */
-int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
+int ctclip_pool_fwd(const void* x, void* y, int64_t B, int t, int64_t R, int dtype, int out_dtype, hipStream_t s);
 
 /* backward of the depth mean-pool. [replaces autograd through torch.mean(enc_image, dim=1), ct_clip.py:724] */
-int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, hipStream_t s);
+int ctclip_pool_bwd(const void* dy, void* dx, int64_t B, int t, int64_t R, int dtype, int out_dtype, hipStream_t s);
 
 /* f32 master weight -> padded compute-dtype shadow (optionally scaled per column). [replaces tensor.to(dtype) casts around the latent projections (ct_clip.py:762-771) and gradient bucket staging (accelerate DDP, scripts/CTCLIPTrainer.py:138-140)] */
 int ctclip_convert_pad(const void* src, void* dst, const float* colscale, int64_t rows, int64_t cols, int64_t lds_, int64_t rows_dst, int64_t cols_dst, int64_t ldd, int src_dtype, int dst_dtype, hipStream_t s);

@@ -333,6 +333,91 @@ def run_full8_fwd_case(name="full8_fwd", c=FULL8_CASE, inter_limit=60000):
     print(f"{name}: loss={float(loss):.6f} -> {path} ({os.path.getsize(path) / 1e6:.1f} MB, {time.time() - t0:.0f} s)")
 
 
+def run_full8_bwd_case(name="full8_bwd", c=FULL8_CASE, grad_limit=3000):
+    """tests/golden/full8_bwd.pt: every gradient of the step bench.py times (12+12 layers, B = 8) from the REAL reference.
+
+    The autograd graph of the reference at this size (f32 score tensors 2 GB per spatial layer and volume group, f32 feed-forward
+    hiddens) is ~4x the 60 GB this container has, so the backward is taken through the reference's own modules in three stages
+    that are the chain rule written out -- every stage runs reference code, nothing is restated:
+      A. the whole batch through `CTCLIP.forward(return_loss=True)` under no_grad (train mode), keeping what the two towers return;
+      B. the same `CTCLIP.forward` with the towers replaced by modules that hand back those tensors as leaves: the reference's
+         pooling / projections / l2norm / logits / loss and their backward give the head gradients and d loss / d tower outputs;
+      C. each volume alone through the reference `CTViT` with grad (VQ buffers restored before every pass so each sees the
+         codebook the batch saw), backward from its slice of d loss / d tokens; the BERT tower in one pass.  Gradients add up in
+         `.grad` exactly as the batch-wide backward would add them (f32 summation order aside).
+    Checks stored next to the gradients: stage A's loss == full8_fwd.pt's, stage-C tower outputs == stage A's."""
+    import time
+    t0 = time.time()
+    clip, t, hw = build(c)
+    video, ids, mask = synth_inputs(c)
+    text = ref_shim.TextBatch(ids, mask)
+    dev = torch.device("cpu")
+    vt, tt = clip.visual_transformer, clip.text_transformer
+    vq0 = {k: v.detach().clone() for k, v in vt.vq.state_dict().items()}
+    print(f"[{name}] reference built ({time.time() - t0:.0f} s)", flush=True)
+
+    # ---- A
+    kept = {}
+    h1 = vt.register_forward_hook(lambda _m, _i, o: kept.__setitem__("image", o.detach().clone()))
+    h2 = tt.register_forward_hook(lambda _m, _i, o: kept.__setitem__("text", o[0].detach().clone()))
+    clip.train()
+    with torch.no_grad():
+        loss_a = clip(text, video, return_loss=True, device=dev)
+    h1.remove(), h2.remove()
+    vq_after = {k: v.detach().clone() for k, v in vt.vq.state_dict().items()}
+    print(f"[{name}] A: batch forward, loss {float(loss_a):.7f} ({time.time() - t0:.0f} s)", flush=True)
+
+    # ---- B
+    class Handback(torch.nn.Module):
+        def __init__(self, value, as_tuple):
+            super().__init__()
+            self.value, self.as_tuple = value, as_tuple
+
+        def forward(self, *a, **k):
+            return (self.value,) if self.as_tuple else self.value
+    enc_image = kept["image"].clone().requires_grad_(True)
+    enc_text = kept["text"].clone().requires_grad_(True)
+    clip._modules["visual_transformer"] = Handback(enc_image, False)
+    clip._modules["text_transformer"] = Handback(enc_text, True)
+    loss_b = clip(text, video, return_loss=True, device=dev)
+    loss_b.backward()
+    clip._modules["visual_transformer"], clip._modules["text_transformer"] = vt, tt
+    d_image, d_text = enc_image.grad.clone(), enc_text.grad.clone()
+    print(f"[{name}] B: head backward, loss {float(loss_b):.7f} ({time.time() - t0:.0f} s)", flush=True)
+
+    # ---- C
+    worst_image = 0.0
+    for b in range(c["batch"]):
+        vt.vq.load_state_dict(vq0)
+        out = vt(video[b:b + 1], return_encoded_tokens=True)
+        worst_image = max(worst_image, float((out.detach() - kept["image"][b:b + 1]).abs().max()))
+        out.backward(d_image[b:b + 1])
+        del out
+        print(f"[{name}] C: volume {b} done, tower output vs batch pass {worst_image:.2e} ({time.time() - t0:.0f} s)", flush=True)
+    vt.vq.load_state_dict(vq_after)
+    out = tt(ids, attention_mask=mask)[0]
+    worst_text = float((out.detach() - kept["text"]).abs().max())
+    out.backward(d_text)
+    print(f"[{name}] C: text tower done, output vs batch pass {worst_text:.2e} ({time.time() - t0:.0f} s)", flush=True)
+
+    grads = {}
+    for k, p in clip.named_parameters():
+        if p.grad is not None:
+            grads[k] = subsample(p.grad, grad_limit)
+    grad_sq = sum(float((p.grad.double() ** 2).sum()) for p in clip.parameters() if p.grad is not None)
+    fwd_path = os.path.join(OUT, "full8_fwd.pt")
+    loss_fwd = torch.load(fwd_path, weights_only=False)["loss"] if os.path.exists(fwd_path) else None
+    out = dict(config=c, loss=loss_a.detach().clone(), loss_head_pass=loss_b.detach().clone(), loss_full8_fwd=loss_fwd,
+               tower_recompute_maxabs=dict(image=worst_image, text=worst_text), grads=grads,
+               grad_norm=torch.tensor(grad_sq).sqrt().float(), d_tokens=subsample(d_image, 20000), d_text_cls=d_text[:, 0].clone(),
+               vq_cluster_size_after=vq_after["_codebook.cluster_size"].clone())
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: loss={float(loss_a):.7f} (full8_fwd {None if loss_fwd is None else float(loss_fwd):.7f}) "
+          f"grad_norm={float(out['grad_norm']):.6f} {len(grads)} gradients -> {path} ({os.path.getsize(path) / 1e6:.1f} MB, "
+          f"{time.time() - t0:.0f} s)")
+
+
 def run_finetune_case(name="finetune_tiny", base="tiny"):
     """Fixtures for the two fine-tuning loops on the REAL reference towers, tiny configuration
     (same seed / weights / volumes as tiny.pt, which the tests load next to this file).
@@ -477,6 +562,8 @@ if __name__ == "__main__":
             run_full_case("full2", FULL2_CASE, every_layer=True)
         elif name == "full8_fwd":
             run_full8_fwd_case()
+        elif name == "full8_bwd":
+            run_full8_bwd_case()
         elif name == "finetune_tiny":
             run_finetune_case()
         else:

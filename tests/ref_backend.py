@@ -502,11 +502,11 @@ class RefBackend:
     def transpose2d(self, x):
         return x.t().contiguous()
 
-    def pool_fwd(self, x):
-        return _f(x).mean(1).to(x.dtype)
+    def pool_fwd(self, x, out_dtype=None):
+        return _f(x).mean(1).to(out_dtype or x.dtype)
 
-    def pool_bwd(self, dy, t):
-        return (_f(dy)[:, None, :] / t).expand(-1, t, -1).to(dy.dtype).contiguous()
+    def pool_bwd(self, dy, t, out_dtype=None):
+        return (_f(dy)[:, None, :] / t).expand(-1, t, -1).to(out_dtype or dy.dtype).contiguous()
 
     def convert_pad(self, src, rows_dst, cols_dst, dtype, colscale=None, out=None):
         rows, cols = src.shape

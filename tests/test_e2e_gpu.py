@@ -63,13 +63,14 @@ def test_f32_eval_modes_match_reference(golden, name):
 
 @pytest.mark.parametrize("name", ["tiny", "small"])
 def test_bf16_performance_mode_stays_close(golden, name):
-    """bf16 storage / MFMA inputs, f32 accumulate and statistics.  Bounds <= 3x the deviations measured on MI355X (tiny: loss 1.33e-3, small:
-    8.2e-4; code agreement 1.000 at both): loss 4e-3 rel, gradient norm 3e-2 rel, VQ code agreement >= 0.99."""
+    """bf16 storage / MFMA inputs, f32 accumulate and statistics, default precision policy (round 5: text tower with an f32 residual stream and
+    bf16 matrix-core operands, f32 image head).  Free-running (code agreement 1.000 at both sizes).  Loss: the north_star bar, 1e-3 rel (rounds
+    1-4, all-bf16: 1.33e-3 / 8.2e-4 measured against a 4e-3 bound); gradient norm 3e-2 rel; VQ code agreement >= 0.99."""
     g = golden(name)
     clip, text, video = _run(g, torch.bfloat16)
     loss = clip(text, video, return_loss=True, device=DEV)
     rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
-    assert rel < 4e-3, (float(loss), float(g["loss"]))
+    assert rel < 1e-3, (float(loss), float(g["loss"]))
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in clip.parameters() if p.grad is not None))
     gn_rel = abs(float(gn) - float(g["grad_norm"])) / float(g["grad_norm"])

@@ -155,8 +155,9 @@ def _bf16_run(full, teacher):
 # Measured, teacher-forced: full1 loss 4.78e-4, grad norm 1.73e-2, cosines image 0.999996 / text 0.999949, worst gradient cosine 0.974 (BERT position
 # embeddings); full2 (12+12) loss 1.00e-3, grad norm 9.3e-3, same cosines, worst gradient cosine 0.967.  The text tower (12 bf16 BERT layers: cosine
 # 0.99995 = 1 % of latent error) carries the teacher-forced loss error; with CTCLIP_TEXT_DTYPE=f32 it is below 1e-3 at both depths (test below).
+# Round 5 (default precision policy: text tower f32 stream + bf16 operands, f32 image head): the loss bound of BOTH depths is the bar itself, 1e-3.
 TEACHER_BOUNDS = {"full1": dict(rel=1e-3, gn_rel=5e-2, cos_i=0.99998, cos_t=0.99985, grad_cos=0.92),
-                  "full2": dict(rel=2.5e-3, gn_rel=2.8e-2, cos_i=0.99998, cos_t=0.99985, grad_cos=0.90)}
+                  "full2": dict(rel=1e-3, gn_rel=2.8e-2, cos_i=0.99998, cos_t=0.99985, grad_cos=0.90)}
 # Free-running: the loss / gradient deviations are dominated by WHICH codes flip (2.1 % at 4+4 layers, 3.6 % at 12+12: a discrete, chaotic
 # event -- two builds of round 2 measured 1.15e-4 and 2.03e-3 for the same loss); bounds from the largest values seen.  The agreement itself is
 # what the bf16 residual stream allows (profiles/r03_bf16_error_budget.md: 0.968 emulated on the CPU oracle, 0.991 with an f32 residual stream).
@@ -376,3 +377,78 @@ def test_bench_shape_bf16_forward_as_timed(full8, monkeypatch):
           f"max logit difference {r['dlog']:.2e}, residual stream {', '.join(f'{k} {v:.1e}' for k, v in r['errs'].items())}")
     assert r["rel"] < 3e-3 and r["agree"] >= 0.955 and r["cos_t"] > 0.9998 and r["cos_i"] > 0.96 and r["dlog"] < 0.16
     assert max(r["errs"].values()) < 3e-2
+
+
+# tests/golden/full8_bwd.pt: EVERY gradient of that step (B = 8, 12+12 layers) from the real reference (oracle/gen_golden.py full8_bwd: the
+# reference's own modules, backward accumulated volume by volume because its B = 8 autograd graph does not fit the build container).  This pins
+# what only runs at the benchmarked size: the TN split-K weight-gradient GEMMs at K = 110 592 tokens, the one-pass attention backward over 192
+# sequences, the large-problem dispatch of the LayerNorm / PEG / column-sum backward kernels.
+@functools.lru_cache(maxsize=None)
+def _load_bwd():
+    gb = torch.load(os.path.join(ROOT, "tests", "golden", "full8_bwd.pt"), weights_only=False)
+    assert gb["config"] == _load("full8_fwd")[0]["config"]
+    assert float(gb["loss"]) == float(_load("full8_fwd")[0]["loss"])          # same weights, same inputs: the generator reproduced full8_fwd's loss
+    return gb
+
+
+def _grad_table(gb, grads):
+    gnorm = float(gb["grad_norm"])
+    rows = []
+    for k, rec in gb["grads"].items():
+        if rec["value"].numel() == 0 or float(rec["norm"]) < 1e-7 * gnorm:
+            continue        # mathematically-zero gradients (a bias in front of a LayerNorm) are rounding noise on both sides
+        a, b_ = sub(rec, grads[k]).reshape(-1).double(), rec["value"].reshape(-1).double()
+        rows.append((k, float((a - b_).norm() / (b_.norm() + 1e-300)), float((a * b_).sum() / (a.norm() * b_.norm() + 1e-300)),
+                     float(rec["norm"]) / gnorm))
+    return rows
+
+
+def test_bench_shape_f32_backward_matches_reference(full8):
+    gb = _load_bwd()
+    g, clip, text, video = prepare(full8, torch.float32, True)
+    loss = clip(text, video, return_loss=True, device=DEV)
+    rel = abs(float(loss) - float(gb["loss"])) / abs(float(gb["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = dict((n, p.grad) for n, p in clip.named_parameters() if p.grad is not None)
+    gn = torch.sqrt(sum((p.double() ** 2).sum() for p in grads.values()))
+    gn_rel = abs(float(gn) - float(gb["grad_norm"])) / float(gb["grad_norm"])
+    rows = _grad_table(gb, grads)
+    worst = max(rows, key=lambda r: r[1])
+    print(f"[full8_bwd f32] loss rel {rel:.2e}, grad norm {float(gn):.5f} reference {float(gb['grad_norm']):.5f} rel {gn_rel:.2e}, {len(rows)} gradients, "
+          f"worst relative Frobenius error {worst[1]:.2e} ({worst[0]})")
+    for p in clip.parameters():
+        p.grad = None
+    assert rel < 1e-4 and gn_rel < 1e-3
+    assert len(rows) > 400 and worst[1] < 1e-3
+
+
+# bf16, teacher-forced codes (the kernels' error without code flips), default settings = what bench.py times apart from the forced codes.
+# Bounds <= 3x the values measured on MI355X (profiles/r05_full_size_parity.log).
+def test_bench_shape_bf16_backward_teacher_forced(full8):
+    gb = _load_bwd()
+    g, clip, text, video = prepare(full8, torch.bfloat16, True)
+    clip.visual_transformer.vq.teacher_indices = g["vq_indices"].long().to(DEV)
+    try:
+        loss = clip(text, video, return_loss=True, device=DEV)
+        rel = abs(float(loss) - float(gb["loss"])) / abs(float(gb["loss"]))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        clip.visual_transformer.vq.__dict__.pop("teacher_indices", None)
+    grads = dict((n, p.grad) for n, p in clip.named_parameters() if p.grad is not None)
+    gn = torch.sqrt(sum((p.double() ** 2).sum() for p in grads.values()))
+    gn_rel = abs(float(gn) - float(gb["grad_norm"])) / float(gb["grad_norm"])
+    rows = _grad_table(gb, grads)
+    big = [r for r in rows if r[3] > 1e-3]          # tensors that carry more than 0.1 % of the gradient norm
+    worst_cos = min(big, key=lambda r: r[2])
+    worst_fro = max(big, key=lambda r: r[1])
+    # norm-weighted mean relative error: sqrt(sum_k |g_k - r_k|^2 / sum_k |r_k|^2) over the sampled entries
+    num = sum((r[1] * r[3]) ** 2 for r in rows) ** 0.5
+    den = sum(r[3] ** 2 for r in rows) ** 0.5
+    print(f"[full8_bwd bf16 teacher-forced] loss rel {rel:.2e}, grad norm rel {gn_rel:.2e}, {len(rows)} gradients ({len(big)} above 0.1 % of the norm): "
+          f"norm-weighted relative error {num / den:.2e}, worst relative Frobenius {worst_fro[1]:.2e} ({worst_fro[0]}), worst cosine {worst_cos[2]:.5f} ({worst_cos[0]})")
+    for p in clip.parameters():
+        p.grad = None
+    assert rel < 1e-3
+    assert gn_rel < 3e-2 and num / den < 0.2 and worst_cos[2] > 0.9

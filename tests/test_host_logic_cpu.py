@@ -401,3 +401,40 @@ def test_committed_bench_lines_keep_the_contract(name):
     c = b["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == b["unit"] and c["sample"]
     assert b["value"] / c["value"] > 10           # (reported beside the GPU number, not the target)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_bf16_mode_default_precision_policy(golden, ref_backend, name):
+    """The bf16 mode's default precision policy (round 5), emulated with the torch checker (which rounds where the HIP kernels round): the text
+    tower's residual stream / LayerNorms / adds in f32 with bf16 matrix-core operands only (CTCLIP.text_compute_dtype None = "mixed") and the
+    image head (pooled vector, to_visual_latent) in f32.  With the reference's code ids forced, the loss is inside the north_star bar with an
+    order of magnitude to spare; the all-bf16 text tower + bf16 head of rounds 1-4 sat AT the bar on the same inputs.  Gradients flow through
+    the mixed nodes with the right dtypes (an f32 dy into a bf16-operand GEMM, an f32 dx out of it)."""
+    g = golden(name)
+    text = TextBatch(g["input_ids"], g["attention_mask"])
+    rels = {}
+    for mode in ("default", "rounds 1-4"):
+        clip = build_model(g["config"], g["state_dict"], torch.device("cpu"), torch.bfloat16)
+        clip.train()
+        if mode != "default":
+            clip.text_compute_dtype, clip.head_dtype = torch.bfloat16, torch.bfloat16
+        assert clip._text_dtypes() == ((torch.float32, torch.bfloat16) if mode == "default" else (torch.bfloat16, None))
+        clip.visual_transformer.vq.teacher_indices = g["vq_indices"]
+        loss = clip(text, g["video"], return_loss=True, device=torch.device("cpu"))
+        rels[mode] = abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"]))
+        if mode == "default":
+            loss.backward()
+            grads = dict((n, p.grad) for n, p in clip.named_parameters() if p.grad is not None)
+            worst = 1.0
+            for k, rec in g["grads"].items():
+                if not k.startswith(("text_transformer.", "to_text_latent", "to_visual_latent")) or rec["value"].numel() < 64:
+                    continue
+                if float(rec["value"].norm()) < 1e-6 * float(g["grad_norm"]) or k not in grads:
+                    continue
+                assert grads[k].dtype == torch.float32
+                a = (grads[k] if rec["full"] else grads[k].reshape(-1)[::rec["stride"]]).reshape(-1).double()
+                b = rec["value"].reshape(-1).double()
+                worst = min(worst, float((a * b).sum() / (a.norm() * b.norm())))
+            assert worst > 0.999, worst
+    assert rels["default"] < 3e-4, rels
+    assert rels["rounds 1-4"] > 2 * rels["default"], rels
