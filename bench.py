@@ -673,15 +673,16 @@ def main():
             # the whole optimisation step captured once into a hipGraph and replayed (ct_clip_amd.trainer.GraphedStep): the device work is
             # the same kernels in the same order; what changes is the host's share (~1 900 launches through Python + ctypes per step)
             from ct_clip_amd.trainer import GraphedStep
+            eager_step = step
+            graphed = GraphedStep(trainer)         # (constructed BEFORE the capture so that close() is reachable when it fails)
             try:
-                graphed = GraphedStep(trainer).capture(video, text)
+                graphed.capture(video, text)
                 step = lambda: graphed.run()      # noqa: E731
                 step()
             except Exception as e:                # never lose the measurement to the capture: eager steps are always valid
                 print(f"bench: hipGraph capture failed, staying eager: {e!r}", file=sys.stderr)
-                if graphed is not None:
-                    graphed.close()
-                graphed = None
+                graphed.close()
+                graphed, step = None, eager_step
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -760,8 +760,8 @@ class HipBackend:
     def vq_ema(self, idx, x, inv, cluster_size, embed, decay):
         """bins = histogram(idx), esum[c] = sum of the unit rows x[r] * inv[r] assigned to code c (row order: deterministic)."""
         C, d = embed.shape
-        bins = torch.empty(C, dtype=torch.float32, device=embed.device)
-        esum = torch.empty((C, d), dtype=torch.float32, device=embed.device)
+        stats = torch.empty(C * (d + 1), dtype=torch.float32, device=embed.device)      # ONE buffer [bins | esum]: one all-reduce under data parallelism
+        bins, esum = stats[:C], stats[C:].view(C, d)
         self.segment_sum(idx.reshape(-1), x, esum, C, rowscale=inv, counts=bins)
         return bins, esum
 

@@ -649,7 +649,9 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
         int e; (void)frexpf(B, &e);                              // B < 2^e
         kk = FIX_BITS - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
         invK = ldexpf(1.f, -kk);
-      }
+      } else if (!(B < 3.0e38f)) {
+        invK = __builtin_nanf("");                               // a non-finite dO: NaN in, NaN out (dq / dk / dv carry it by arithmetic; the
+      }                                                          // fixed-point table gradient would otherwise come out as finite garbage)
       const float lgK = (float)kk;                               // K = 2^kk enters through the logits: exp2(s + kk - lse2) = K x probability
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) {
@@ -758,10 +760,13 @@ __global__ __launch_bounds__(256) void bwd1_dtab_sum_kernel(const float* __restr
   }
 }
 
-int ncus1() {
-  static int ncu = 0;
-  if (!ncu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-  return ncu;
+constexpr int MAXDEV1 = 64;
+int cur_dev1() { int dev = 0; (void)hipGetDevice(&dev); return (dev >= 0 && dev < MAXDEV1) ? dev : 0; }
+int ncus1() {        // cached per DEVICE (one process may drive several)
+  static int ncu[MAXDEV1] = {};
+  const int dev = cur_dev1();
+  if (!ncu[dev]) { hipDeviceProp_t prop; ncu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+  return ncu[dev];
 }
 inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
 
@@ -794,7 +799,8 @@ bool plan1(int nseq, int H, int L, int gh, int gw, bool tab, Plan1& pl) {
   if (NW1 * P > L) return false;                                // (the step table is built where the L per-query floats log2 K - lse2 live later)
   const int ncu = ncus1(), total = nseq * H;
   int ipw = (total + ncu - 1) / ncu;
-  while (nseq % ipw) ++ipw;                                     // a workgroup stays inside one head
+  if (ipw > nseq) ipw = nseq;                                   // (H above the CU count with few sequences: one workgroup per head walks them all)
+  while (nseq % ipw) ++ipw;                                     // a workgroup stays inside one head (terminates at ipw = nseq at the latest)
   pl.ipw = ipw; pl.wph = nseq / ipw; pl.nwg = pl.wph * H;
   return true;
 }
@@ -846,7 +852,8 @@ extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void
   hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, pl.ncls);
   int rc = ctclip_check_launch("attn2_bwd_fused (stage)");
   if (rc) return rc;
-  static bool raised = false;
+  static bool raised_dev[MAXDEV1] = {};                         // the attribute is per device
+  bool& raised = raised_dev[cur_dev1()];
   if (!raised) {
     bool ok = true;
     ok = ok && hipFuncSetAttribute((const void*)bwd1_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;

@@ -48,10 +48,71 @@ def all_gather_latents(text_lat, image_lat):
     return g[:, 0].contiguous(), g[:, 1].contiguous()
 
 
-def sync_vq_stats(bins, esum):
+def _fused_stats(bins, esum):
+    """The [bins | esum] buffer both are views of (backend.vq_ema allocates them as one), or None."""
+    base = bins._base
+    if base is not None and base is esum._base and base.is_contiguous() and base.numel() == bins.numel() + esum.numel():
+        return base
+    return None
+
+
+def sync_vq_stats(bins, esum, *_):
+    """Immediate form (VqFn.stat_sync hook): all-reduce(SUM) in place on the caller's stream, the EMA update follows in the forward."""
     if world_size() > 1:
-        dist.all_reduce(bins, op=dist.ReduceOp.SUM)
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        flat = _fused_stats(bins, esum)
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(bins, op=dist.ReduceOp.SUM)
+            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+    return False
+
+
+class VqStatSync:
+    """Deferred form (the trainer's default): the EMA statistics of the vector quantiser -- 32 KB of bin counts + 16.8 MB of code sums in
+    f32 -- are ONE buffer, all-reduced (SUM) on the COMMUNICATION stream while the forward carries on, and the EMA update of the codebook
+    (which nothing reads before the next forward) is applied by `flush()` when the step's collectives are joined (GradReducer.finish).
+    The immediate form put two blocking all-reduces on the main stream in the middle of every forward.  A second quantiser call on the
+    same codebook before the flush (VocabFine's per-pathology sequence) flushes first: the EMA sequence is preserved."""
+
+    def __init__(self, comm_stream=None):
+        self.comm_stream = comm_stream
+        self.pending = []                  # (bins, esum, cluster_size, embed, decay)
+        self.calls = 0                     # collectives issued (tests / inspection)
+
+    def __call__(self, bins, esum, cluster_size, embed, decay):
+        if world_size() == 1:
+            return False
+        if any(e[3].data_ptr() == embed.data_ptr() for e in self.pending):
+            self.flush()
+        flat = _fused_stats(bins, esum)
+        pieces = [flat] if flat is not None else [bins, esum]
+        if self.comm_stream is not None and bins.is_cuda:
+            cur = torch.cuda.current_stream(bins.device)
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                for t in pieces:
+                    t.record_stream(self.comm_stream)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            for t in pieces:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        self.calls += len(pieces)
+        self.pending.append((bins, esum, cluster_size, embed, decay))
+        return True
+
+    def flush(self):
+        """Join the communication stream and apply the pending EMA updates on the current stream."""
+        if not self.pending:
+            return
+        from . import backend as _be
+        be = _be.get()
+        if self.comm_stream is not None and self.pending[0][0].is_cuda:
+            torch.cuda.current_stream(self.pending[0][0].device).wait_stream(self.comm_stream)
+        with torch.no_grad():
+            for bins, esum, cluster_size, embed, decay in self.pending:
+                be.vq_ema_update(cluster_size, embed, bins, esum, decay)
+        self.pending = []
 
 
 class GradReducer:
@@ -82,6 +143,7 @@ class GradReducer:
         self.launched = []        # ranges already handed to the communication stream this step
         self.works = []
         self.log = []             # (start, end) in launch order -- for tests / inspection
+        self.vq_sync = VqStatSync(self.comm_stream)      # the quantiser's EMA statistics ride the same communication stream (install it as VqFn.stat_sync)
 
     # ---- registration
     @staticmethod
@@ -188,6 +250,7 @@ class GradReducer:
         W = world_size()
         if W == 1:
             return
+        self.vq_sync.flush()            # (joins the communication stream for the statistics' all-reduce, then the EMA update on the compute stream)
         if self.comm_stream is not None:
             from . import functional as Fn
             Fn.join_side_streams()      # gradients written from the text tower's stream: the events below are recorded on the current stream

@@ -147,6 +147,27 @@ def refresh_shadows(params=None):
             cache[key] = (_stamp((param,) + tuple(deps)), ent[1])
 
 
+def restamp_shadows(params=None):
+    """Stamp the registered (batched-refresh) shadows of `params` valid WITHOUT launching anything: for a hipGraph replay whose captured
+    shadow_refresh launch already rewrote them on the device (GraphedStep.run).  Shadows without a recipe keep their old stamp and are
+    rebuilt by their lazy makers at the next use."""
+    if not _SHADOW_BATCH or not _SHADOW_PLAN:
+        return
+    scope = None if params is None else frozenset(id(p) for p in params)
+    ent = _SHADOW_JOBS.get(scope)
+    if ent is None or ent[0] != _SHADOW_PLAN_VERSION:
+        return            # no job list was ever built for this scope (nothing was refreshed on the device either): everything stays lazy
+    for pref, key, deprefs in ent[2]:
+        param = pref()
+        deps = [d() for d in deprefs]
+        if param is None or any(d is None for d in deps):
+            continue
+        cache = param.__dict__.get("_ctclip_shadow", {})
+        e = cache.get(key)
+        if e is not None:
+            cache[key] = (_stamp((param,) + tuple(deps)), e[1])
+
+
 def plain_shadow(weight, dtype, kpad=None, npad=None):
     """(N, K) f32 -> (Np, Kp) compute dtype, zero padded."""
     N, K = weight.shape
@@ -1240,9 +1261,11 @@ class VqFn(Function):
                 _, inv = be.l2norm_rows(x, torch.float32)
             bins, esum = be.vq_ema(idx, x, inv, cluster_size, embed, decay)
             hook = getattr(VqFn, "stat_sync", None)
-            if hook is not None:
-                hook(bins, esum)            # data-parallel: all-reduce(SUM) the statistics
-            be.vq_ema_update(cluster_size, embed, bins, esum, decay)
+            # data-parallel: all-reduce(SUM) the statistics.  The hook either reduces them in place (returns falsy: the update follows here) or
+            # takes them over (returns True: distributed.VqStatSync reduces them on the communication stream and applies the EMA update when
+            # the step's collectives are joined -- nothing in this forward reads the updated codebook)
+            if hook is None or not hook(bins, esum, cluster_size, embed, decay):
+                be.vq_ema_update(cluster_size, embed, bins, esum, decay)
         ctx.training = training
         ctx.mark_non_differentiable(idx)
         return q, idx

@@ -77,8 +77,12 @@ class VolumeUploader:
         self._k = 0
 
     def host_buffer(self, slot):
-        """The pinned staging buffer of a slot (a decoder can write the voxels here directly and pass `staged=n_voxels` to submit)."""
-        return self._host[slot % len(self._host)]
+        """The pinned staging buffer of a slot (a decoder can write the voxels here directly and pass `staged=(H, W, D)` to submit).  Waits until
+        the slot's previous upload has LEFT the pinned memory (the asynchronous H2D copy of submit k - slots may still be reading it)."""
+        s = slot % len(self._host)
+        if self._copied[s] is not None:
+            self._copied[s].synchronize()
+        return self._host[s]
 
     def submit(self, voxels, slope, intercept, xy_spacing, z_spacing, out=None, staged=None):
         """voxels: (H, W, D) int16 array (numpy / torch, host).  staged = (H, W, D): the voxels are ALREADY in this call's pinned slot

@@ -142,6 +142,20 @@ class GraphedStep:
     def __init__(self, trainer):
         self.t = trainer
         self.graph = None
+        self.state = None
+        self.lr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
 
     def capture(self, video, text):
         be = _be.get()
@@ -149,34 +163,55 @@ class GraphedStep:
         dev = video.device
         self.state = torch.zeros(2, dtype=torch.int64, device=dev)
         self.state[1] = t.optim.step_count
-        _be._lib.check(be.lib.ctclip_set_step_state(self.state.data_ptr()), "ctclip_set_step_state")
+        step0 = t.optim.step_count
         self.video = video.clone()
         self.ids, self.mask = text.input_ids.clone(), text.attention_mask.clone()
         self.text = type(text)(self.ids, self.mask) if not hasattr(text, "_replace") else text._replace(input_ids=self.ids, attention_mask=self.mask)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            _be._lib.check(be.lib.ctclip_advance_step_state(self.state.data_ptr(), _be._stream()), "ctclip_advance_step_state")
-            self.loss = t.forward_backward(self.video, self.text)
-            t.optim.step(t.max_grad_norm)
-            t.optim.zero_grad()
-        torch.cuda.synchronize(dev)
+        _be._lib.check(be.lib.ctclip_set_step_state(self.state.data_ptr()), "ctclip_set_step_state")
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _be._lib.check(be.lib.ctclip_advance_step_state(self.state.data_ptr(), _be._stream()), "ctclip_advance_step_state")
+                self.loss = t.forward_backward(self.video, self.text)
+                t.optim.step(t.max_grad_norm)
+                t.optim.zero_grad()
+            torch.cuda.synchronize(dev)
+        except BaseException:
+            # a failed capture must leave the process as it found it: the library's step-state pointer (every later EAGER Adam launch and
+            # dropout seed would read a device counter nobody advances) and the host step counter the recorded optim.step() bumped
+            be.lib.ctclip_set_step_state(None)
+            t.optim.step_count = step0
+            self.state = None
+            raise
+        self.graph = graph
+        self.lr = t.optim.param_groups[0]["lr"]
         # the capture only RECORDED the step (nothing ran): state and step counter are where the first replay expects them
-        t.optim.step_count -= 1
+        t.optim.step_count = step0
         return self
 
     def run(self, video=None, text=None):
+        t = self.t
+        # the learning rate is a by-value kernel argument frozen by the capture: a schedule needs a re-capture
+        assert t.optim.param_groups[0]["lr"] == self.lr, "the learning rate changed since capture(): re-capture the GraphedStep"
         if video is not None and video.data_ptr() != self.video.data_ptr():
             self.video.copy_(video, non_blocking=True)
         if text is not None and text.input_ids.data_ptr() != self.ids.data_ptr():
             self.ids.copy_(text.input_ids, non_blocking=True)
             self.mask.copy_(text.attention_mask, non_blocking=True)
         self.graph.replay()
-        self.t.optim.step_count += 1
+        # the HOST half of optim.step(): the replay updated the parameters and rewrote the registered weight shadows on the device; shadows
+        # WITHOUT a batched-refresh recipe (the stacked q|k|v bias, non-2D weights, everything under CTCLIP_SHADOW_BATCH=0) are rebuilt lazily
+        # from the parameter's epoch, which only the host can advance -- an eager forward between replays would otherwise read stale ones
+        t.optim.step_count += 1
+        Fn.bump_weight_epoch(t.optim.params)
+        Fn.restamp_shadows(t.optim.params)
         return self.loss
 
     def close(self):
-        _be.get().lib.ctclip_set_step_state(None)
+        if self.state is not None:
+            _be.get().lib.ctclip_set_step_state(None)
+            self.state = None
         self.graph = None
 
 
@@ -222,7 +257,9 @@ class CTClipTrainer(nn.Module):
             grad_comm_dtype = torch.bfloat16 if env in ("bf16", "bfloat16") else torch.float32
         self.reducer = _dist.GradReducer(self.optim, op="sum" if gather else "mean", comm_dtype=grad_comm_dtype,
                                          min_bucket_bytes=grad_bucket_bytes, overlap=overlap_grad_reduce).install(self.CTClip)
-        Fn.VqFn.stat_sync = staticmethod(_dist.sync_vq_stats)
+        # VQ EMA statistics: one fused buffer, all-reduced on the communication stream, EMA applied when the step's collectives are joined
+        # (reducer.finish, before the optimiser step); CTCLIP_VQ_SYNC=immediate restores the blocking in-forward all-reduce
+        Fn.VqFn.stat_sync = staticmethod(_dist.sync_vq_stats if os.environ.get("CTCLIP_VQ_SYNC", "") == "immediate" else self.reducer.vq_sync)
 
         if train_dataset is None:
             from data import CTReportDataset  # the reference's scripts/data.py, when run from its scripts directory
@@ -283,6 +320,9 @@ class CTClipTrainer(nn.Module):
         """Detach this trainer from the process-global hooks it installed (the gradient reducer's grad-ready hook): a later model or
         trainer in the same process must not call into this one's reducer."""
         self.reducer.uninstall()
+        if getattr(Fn.VqFn, "stat_sync", None) is self.reducer.vq_sync:
+            self.reducer.vq_sync.flush()
+            Fn.VqFn.stat_sync = None
 
     @property
     def is_main(self):

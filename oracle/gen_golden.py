@@ -28,6 +28,9 @@ CASES = {
                   heads=2, dim_head=32, codebook=128, T=16, bert_hidden=64, bert_layers=2, bert_heads=2,
                   bert_inter=128, vocab=256, max_pos=32, dim_latent=32),
 }
+# BASELINE configs[0] geometry with a batch of FOUR (round 5): the global batch of the world_size-4 data-parallel tests (one sample per rank;
+# rank slices, bucket coalescing and the latent all-gather at W = 4) and of the 2-ranks x 2-samples layout
+CASES["tiny4"] = dict(CASES["tiny"], seed=5, batch=4)
 
 
 def synth_inputs(c):

@@ -558,8 +558,10 @@ class RefBackend:
     def vq_ema(self, idx, x, inv, cluster_size, embed, decay):
         C, d = embed.shape
         xn = _f(x) * inv[:, None]
-        bins = torch.zeros(C, dtype=torch.float32, device=embed.device).index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), device=embed.device))
-        esum = torch.zeros((C, d), dtype=torch.float32, device=embed.device).index_add_(0, idx.reshape(-1), xn)
+        stats = torch.zeros(C * (d + 1), dtype=torch.float32, device=embed.device)      # one buffer [bins | esum], as the HIP backend
+        bins, esum = stats[:C], stats[C:].view(C, d)
+        bins.index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), device=embed.device))
+        esum.index_add_(0, idx.reshape(-1), xn)
         return bins, esum
 
     def vq_ema_update(self, cluster_size, embed, bins, esum, decay):

@@ -143,3 +143,83 @@ def test_graphed_step_replays_the_eager_step_bit_for_bit(golden, tmp_path):
     assert all(torch.equal(qa[k], qb[k]) for k in qa)
     lc = run(3, 3, 0.1)[0]
     assert len(set(lc[3:])) == 3, lc          # fresh dropout masks per replay (and a moving model)
+
+
+def test_graphed_step_mixed_with_eager_forwards_and_failed_capture(golden, tmp_path, monkeypatch):
+    """ADVICE r04.  (1) An eager forward BETWEEN replays (the trainer's own validation / zero-shot) must see the weights the replay just wrote:
+    shadows without a batched-refresh recipe (the stacked q|k|v bias of the text tower, ...) are rebuilt from the host-side weight epoch, which
+    GraphedStep.run() now advances -- replay, eval, replay, eval gives the eval results of the eager sequence bit for bit.  (2) A capture that
+    raises leaves no trace: the library's step-state pointer is cleared and the optimiser's step count restored, so the eager steps that follow
+    are the steps of a process that never tried (bit-identical parameters)."""
+    import ct_clip_amd
+    from ct_clip_amd.trainer import GraphedStep
+    g = golden("tiny")
+    c = g["config"]
+    text = TextBatch(g["input_ids"].to(DEV), g["attention_mask"].to(DEV))
+    video = g["video"].to(DEV)
+
+    def trainer(tag):
+        clip = build_model(c, g["state_dict"], DEV, torch.bfloat16)
+        clip.train()
+        return clip, ct_clip_amd.CTClipTrainer(clip, num_train_steps=10, batch_size=2, tokenizer=object(), lr=1e-3, train_dataset=[0], evaluate=False,
+                                               checkpoint=False, results_folder=str(tmp_path / tag), num_workers=0)
+
+    def eager(tr):
+        loss = tr.forward_backward(video, text)
+        tr.optim.step(tr.max_grad_norm)
+        tr.optim.zero_grad()
+        return loss
+
+    def evaluate(clip):
+        clip.eval()
+        with torch.no_grad():
+            tl, il, _ = clip(text, video, return_latents=True, device=DEV)
+        clip.train()
+        return tl.clone(), il.clone()
+
+    # (1)
+    outs = {}
+    for mode in ("eager", "graph"):
+        clip, tr = trainer(mode)
+        for _ in range(3):
+            eager(tr)
+        evals = []
+        gs = GraphedStep(tr).capture(video, text) if mode == "graph" else None
+        try:
+            for _ in range(3):
+                gs.run() if gs is not None else eager(tr)
+                evals.append(evaluate(clip))
+        finally:
+            if gs is not None:
+                gs.close()
+        eager(tr)                                    # the first eager step after close()
+        evals.append(evaluate(clip))
+        outs[mode] = evals
+        tr.close()
+    for (ta, ia), (tb, ib) in zip(outs["eager"], outs["graph"]):
+        assert torch.equal(ta, tb) and torch.equal(ia, ib)
+    assert not torch.equal(outs["eager"][0][0], outs["eager"][1][0])      # (the weights did move between the evaluations)
+
+    # (2)
+    ref_clip, ref_tr = trainer("ref")
+    for _ in range(5):
+        eager(ref_tr)
+    want = ref_tr.optim.flat_param.clone()
+    ref_tr.close()
+    clip, tr = trainer("failed")
+    for _ in range(3):
+        eager(tr)
+    boom = RuntimeError("injected")
+    real = tr.optim.zero_grad      # (the last call of the recorded step: every side stream has been joined, optim.step() has bumped its counter)
+    monkeypatch.setattr(tr.optim, "zero_grad", lambda *a, **k: (_ for _ in ()).throw(boom))
+    gs = GraphedStep(tr)
+    with pytest.raises(RuntimeError):
+        gs.capture(video, text)
+    monkeypatch.setattr(tr.optim, "zero_grad", real)
+    assert gs.state is None and tr.optim.step_count == 3
+    tr.optim.zero_grad()
+    for _ in range(2):
+        eager(tr)
+    torch.cuda.synchronize()
+    assert tr.optim.step_count == 5 and torch.equal(tr.optim.flat_param, want)
+    tr.close()

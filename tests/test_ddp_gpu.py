@@ -47,7 +47,7 @@ def _worker(rank, world, port, backend_name, single_device, name, out, comm, dty
     dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
     clip = build_model(g["config"], g["state_dict"], dev, dtype)
     clip.train()
-    trainer = ct_clip_amd.CTClipTrainer(clip, num_train_steps=1, batch_size=per, tokenizer=object(), lr=1e-3, train_dataset=[0, 1], evaluate=False,
+    trainer = ct_clip_amd.CTClipTrainer(clip, num_train_steps=1, batch_size=per, tokenizer=object(), lr=1e-3, train_dataset=list(range(world)), evaluate=False,
                                         checkpoint=False, results_folder=os.path.join(os.path.dirname(out), f"r{rank}"), num_workers=0, device=dev,
                                         grad_comm_dtype=torch.float32 if comm == "f32" else torch.bfloat16, grad_bucket_bytes=1)
     text = TextBatch(g["input_ids"][sl].to(dev), g["attention_mask"][sl].to(dev))
@@ -89,6 +89,21 @@ def test_two_ranks_one_device_gloo_match_golden(golden, tmp_path, comm):
     out = str(tmp_path / "rank0.pt")
     mp.spawn(_worker, args=(2, _free_port(), "gloo", True, "tiny", out, comm, "f32"), nprocs=2, join=True)
     _check(golden, torch.load(out, weights_only=False), "tiny", comm)
+
+
+def test_four_ranks_one_device_gloo_match_golden(golden, tmp_path):
+    """world_size 4 (round 5): one sample of tests/golden/tiny4.pt (the real reference at B = 4) per rank, all four on cuda:0 through gloo --
+    rank slices of the gathered latents, 4-way gradient sums, the deferred VQ-statistics all-reduce on the communication stream."""
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(4, _free_port(), "gloo", True, "tiny4", out, "f32", "f32"), nprocs=4, join=True)
+    _check(golden, torch.load(out, weights_only=False), "tiny4", "f32")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 4, reason="needs four GPUs (RCCL over xGMI)")
+def test_four_ranks_four_devices_nccl_match_golden(golden, tmp_path):
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(4, _free_port(), "nccl", False, "tiny4", out, "f32", "f32"), nprocs=4, join=True)
+    _check(golden, torch.load(out, weights_only=False), "tiny4", "f32")
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")

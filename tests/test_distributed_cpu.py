@@ -1,6 +1,7 @@
-"""Data-parallel logic on CPU with the gloo backend, world_size 2: gathered-negatives loss, gradient all-reduce(SUM), VQ-statistic
-all-reduce.  Parity oracle for W ranks = the single-process reference on the concatenated global batch, i.e.
-exactly the golden fixture: rank r gets sample r of the tiny case; loss, summed gradients and VQ buffers must match the golden ones."""
+"""Data-parallel logic on CPU with the gloo backend, world_size 2 and 4: gathered-negatives loss, gradient all-reduce(SUM), VQ-statistic
+all-reduce.  Parity oracle for W ranks = the single-process REAL reference on the concatenated global batch, i.e.
+exactly the golden fixture: rank r gets its contiguous slice of the tiny (B = 2) / tiny4 (B = 4) case; loss, summed gradients and VQ
+buffers must match the golden ones."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, out, mode="overlap"):
+def _worker(rank, world, port, name, out, mode="overlap", vq_mode="deferred", bucket_bytes=1):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -31,7 +32,6 @@ def _worker(rank, world, port, name, out, mode="overlap"):
     from tests.ref_backend import RefBackend
     from tests.helpers import TextBatch, build_model
     backend.use(RefBackend())
-    Fn.VqFn.stat_sync = staticmethod(D.sync_vq_stats)
     g = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
     B = g["video"].shape[0]
     per = B // world
@@ -39,16 +39,25 @@ def _worker(rank, world, port, name, out, mode="overlap"):
     clip = build_model(g["config"], g["state_dict"], torch.device("cpu"), torch.float32)
     clip.train()
     opt = FusedAdam(hot_path_parameters(clip), lr=1e-3)
-    red = D.GradReducer(opt, op="sum", comm_dtype=torch.bfloat16 if mode == "overlap_bf16" else torch.float32, min_bucket_bytes=1,
+    red = D.GradReducer(opt, op="sum", comm_dtype=torch.bfloat16 if mode == "overlap_bf16" else torch.float32, min_bucket_bytes=bucket_bytes,
                         overlap=mode != "serial").install(clip)
+    # the quantiser's EMA statistics: deferred (the trainer's default: one fused buffer, all-reduced when produced, EMA applied at finish())
+    # or immediate (in-forward all-reduce, EMA applied in the forward)
+    Fn.VqFn.stat_sync = staticmethod(red.vq_sync if vq_mode == "deferred" else D.sync_vq_stats)
+    cs0 = clip.visual_transformer.vq._codebook.cluster_size.clone()
     loss = clip(TextBatch(g["input_ids"][sl], g["attention_mask"][sl]), g["video"][sl], return_loss=True, device=torch.device("cpu"))
+    if vq_mode == "deferred":          # the statistics are reduced (one collective), the codebook is untouched until finish()
+        assert red.vq_sync.calls == 1 and len(red.vq_sync.pending) == 1
+        assert torch.equal(clip.visual_transformer.vq._codebook.cluster_size, cs0)
     loss.backward()
     during_backward = len(red.log)          # collectives launched from inside backward (overlap) vs. none (serial)
     red.finish()
     cover = sorted(red.log)
     assert cover[0][0] == 0 and cover[-1][1] == opt.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), \
         "every element of the flat gradient buffer must be reduced exactly once"
+    assert not red.vq_sync.pending
     Fn.set_grad_ready_hook(None)
+    Fn.VqFn.stat_sync = None
     if rank == 0:
         grads = {n: p.grad.detach().clone() for n, p in hot_path_parameters(clip)}
         vq = {k: v.clone() for k, v in clip.state_dict().items() if "vq._codebook" in k}
@@ -57,20 +66,27 @@ def _worker(rank, world, port, name, out, mode="overlap"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,mode", [("tiny", "overlap"), ("tiny", "serial"), ("tiny", "overlap_bf16")])
-def test_two_ranks_match_single_process_global_batch(golden, tmp_path, name, mode):
+@pytest.mark.parametrize("name,world,mode,vq_mode,bucket_bytes", [
+    ("tiny", 2, "overlap", "deferred", 1), ("tiny", 2, "serial", "immediate", 1), ("tiny", 2, "overlap_bf16", "deferred", 1),
+    ("tiny4", 4, "overlap", "deferred", 1),          # one sample per rank at W = 4: rank slices of the gathered latents, 4-way sums
+    ("tiny4", 4, "overlap", "immediate", 2000000),   # buckets of >= 2 MB: neighbouring blocks coalesce before they are launched
+    ("tiny4", 2, "serial", "deferred", 1),           # two samples per rank
+])
+def test_ranks_match_single_process_global_batch(golden, tmp_path, name, world, mode, vq_mode, bucket_bytes):
     """overlap: the all-reduce of a layer's gradients is launched from inside backward as soon as they are final; serial: one
     reduction after backward.  Both must give the single-process global-batch gradients (bf16 buckets: to bf16 rounding)."""
     from tests.helpers import check_grad
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), name, out, mode), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, out, mode, vq_mode, bucket_bytes), nprocs=world, join=True)
     res = torch.load(out, weights_only=False)
     g = golden(name)
     torch.testing.assert_close(res["loss"], g["loss"], rtol=1e-4, atol=1e-5)
     if mode == "serial":
         assert res["during_backward"] == 0
-    else:
+    elif bucket_bytes == 1:
         assert res["during_backward"] >= 4 and res["launches"] > res["during_backward"]
+    else:      # coalescing: fewer, larger launches than blocks (6 announced blocks + the rest at finish), still overlapped
+        assert 1 <= res["during_backward"] < 6 and res["launches"] > res["during_backward"]
     n = 0
     for k, rec in g["grads"].items():
         if rec["value"].numel() == 0 or k not in res["grads"]:
