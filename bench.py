@@ -686,6 +686,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+            trainer.reducer.start_timing()        # event pairs on the communication stream (no host synchronisation): `comm` of the JSON line
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -695,6 +696,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        run_config.comm = trainer.reducer.stop_timing() if world > 1 else None
         run_config.graphed = graphed is not None
         if graphed is not None:
             graphed.close()
@@ -755,6 +757,10 @@ def main():
         "mfma_fraction_whole_step": round(train_flops * args.batch / (ms / 1e3) / 2.5e15, 4),
         "peak_mem_gib": round(peak_mem, 1),
     }
+    if getattr(run_config, "comm", None):
+        # rank 0's view of the gradient all-reduce: how long the buckets occupied the communication stream and how much of that the compute
+        # stream had to WAIT for at the end of backward (the rest was hidden under backward); diagnoses the first multi-GPU run
+        out["comm"] = dict(run_config.comm, backend=dist.get_backend(), vq_stats="fused buffer on the communication stream, EMA applied at finish()")
     if timing:
         timing["traffic"] = None
         if rank == 0 and world == 1 and not args.no_pmc:

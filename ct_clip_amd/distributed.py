@@ -143,7 +143,25 @@ class GradReducer:
         self.launched = []        # ranges already handed to the communication stream this step
         self.works = []
         self.log = []             # (start, end) in launch order -- for tests / inspection
+        self.timing = None        # start_timing(): [(event before, event after)] per collective on the communication stream + exposed waits
         self.vq_sync = VqStatSync(self.comm_stream)      # the quantiser's EMA statistics ride the same communication stream (install it as VqFn.stat_sync)
+
+    # ---- diagnostics: where does the step's communication time go?  (bench.py --gpus N prints it with the throughput line)
+    def start_timing(self):
+        self.timing = dict(coll=[], exposed=[], bytes=0, steps=0)
+
+    def stop_timing(self):
+        """-> per-step means: collectives, bytes, time the collectives occupied the communication stream, and the EXPOSED part -- how long the
+        compute stream waited in finish() for the last bucket (the rest ran under backward)."""
+        t, self.timing = self.timing, None
+        if not t or not t["steps"] or self.comm_stream is None:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        n = t["steps"]
+        return dict(collectives_per_step=round(len(t["coll"]) / n, 1), MB_per_step=round(t["bytes"] / n / 1e6, 1),
+                    comm_stream_busy_ms_per_step=round(sum(a.elapsed_time(b) for a, b in t["coll"]) / n, 3),
+                    exposed_wait_ms_per_step=round(sum(a.elapsed_time(b) for a, b in t["exposed"]) / n, 3),
+                    wire_dtype=str(self.comm_dtype).replace("torch.", ""), min_bucket_MB=round(self.min_elems * 4 / 2 ** 20, 1))
 
     # ---- registration
     @staticmethod
@@ -227,7 +245,13 @@ class GradReducer:
                 for ev in events:
                     self.comm_stream.wait_event(ev)
                 with torch.cuda.stream(self.comm_stream):
+                    if self.timing is not None:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
                     self._reduce_slice(s, e)
+                    if self.timing is not None:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
+                        self.timing["coll"].append((e0, e1))
+                        self.timing["bytes"] += (e - s) * (4 if self.stage is None else self.stage.element_size())
             else:
                 self._reduce_slice(s, e)
 
@@ -236,7 +260,10 @@ class GradReducer:
         if self.stage is None:
             w = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=self.comm_stream is not None)
             if w is not None and self.comm_stream is not None:
-                self.works.append(w)
+                if dist.get_backend() == "nccl":
+                    w.wait()              # RCCL: stream-ordered (the COMMUNICATION stream waits for the collective; the host does not block)
+                else:
+                    self.works.append(w)  # gloo: wait() blocks the host -- deferred to finish() so that backward keeps being enqueued
             return
         from . import backend as _be
         be = _be.get()
@@ -272,7 +299,14 @@ class GradReducer:
             with torch.cuda.stream(self.comm_stream):
                 for w in self.works:
                     w.wait()
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            if self.timing is not None:
+                m0 = torch.cuda.Event(enable_timing=True); m0.record(cur)
+            cur.wait_stream(self.comm_stream)
+            if self.timing is not None:
+                m1 = torch.cuda.Event(enable_timing=True); m1.record(cur)
+                self.timing["exposed"].append((m0, m1))
+                self.timing["steps"] += 1
         self.works = []
         self.launched = []
         if self.op == "mean":

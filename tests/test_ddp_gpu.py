@@ -133,6 +133,8 @@ def test_bench_self_launches_without_a_launcher(tmp_path):
                        "--no-attn-block", "--profile-steps", "0"], env, str(tmp_path))
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert abs(rec["loss"] - 1.386) < 0.2          # ln 4 for random towers: the loss saw the gathered batch
+    c = rec["comm"]                                # per-step communication diagnostics of the N > 1 line
+    assert c["collectives_per_step"] >= 1 and c["MB_per_step"] > 100 and c["comm_stream_busy_ms_per_step"] > 0 and c["exposed_wait_ms_per_step"] >= 0
 
 
 @pytest.mark.parametrize("workload,cfgi", [("lipro", 4), ("vocabfine", 3)])
