@@ -143,6 +143,11 @@ class HipBackend:
         _lib.check(rc, "ctclip_gemm")
         return out
 
+    def gemm_nt2_select(self, mask):
+        """Which epilogue families of the big bf16 NT GEMMs run on the two-workgroups-per-CU kernel (csrc/gemm_nt2.hip): bit 0 plain /
+        residual, bit 1 GEGLU forward, bit 2 GEGLU backward; -1 = environment / built-in default.  Returns the previous mask."""
+        return int(self.lib.ctclip_gemm_nt2_select(int(mask)))
+
     def gemm_argmax(self, a, b):
         M, K = a.shape
         N = b.shape[0]

@@ -736,6 +736,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 
 }  // namespace
 
+// second form (gemm_nt2.hip): two 4-wave workgroups per CU, a tile's epilogue under the other workgroup's main loop
+int ctclip_gemm_nt2_try(const void* A, const void* B, void* C, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                        int64_t ldc, int64_t ldr, float alpha, bool nontemporal, hipStream_t stream);
+int ctclip_gemm_nt2_geglu_try(const void* A, const void* B, void* U, void* G, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb, int64_t ldu,
+                              int64_t ldg, bool nontemporal, hipStream_t stream);
+int ctclip_gemm_nt2_dgeglu_try(const void* A, const void* B, const void* U, void* dU, int64_t M, int hp, int64_t K, int64_t lda, int64_t ldb,
+                               int64_t ldu, int64_t lddu, bool nontemporal, hipStream_t stream);
+
 static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
   const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : (p.comp_out ? 3 : (p.hn_out[0] ? 4 : 0)));
   static bool raised = false;
@@ -793,6 +801,10 @@ int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias,
   // outputs that cannot stay in the 32 MiB of L2 anyway are written with the non-temporal hint (measured -9 % on the 623-MB FF
   // hidden activation: they no longer evict the operand panels the other CUs of the XCD are about to re-read)
   const bool nontemporal = ((NT_ABL & 64) != 0) || (M * N * (out_dtype == DT_F32 ? 4 : 2) > ((int64_t)NT_STREAM_MB << 20));
+  if (!bias && !accumulate && out_dtype == DT_BF16 && (!residual || res_dtype == DT_BF16)) {
+    const int rc2 = ctclip_gemm_nt2_try(A, B, C, residual, M, N, K, lda, ldb, ldc, ldr, alpha, nontemporal, stream);
+    if (rc2 != 1) return rc2;
+  }
   return nt_launch(p, nontemporal, stream);
 }
 
@@ -855,6 +867,10 @@ int ctclip_gemm_nt_geglu_try(const void* A, const void* B, void* U, void* G, con
   p.geglu_g = (bf16_t*)G; p.ldg = ldg; p.geglu_hp = hp;
   p.geglu_dg = (const bf16_t*)dG; p.lddg = lddg;
   const int64_t out_bytes = (U ? M * N * 2 : 0) + (G ? M * (int64_t)hp * 2 : 0);
+  if (!dG && G) {
+    const int rc2 = ctclip_gemm_nt2_geglu_try(A, B, U, G, M, hp, K, lda, ldb, ldu, ldg, out_bytes > ((int64_t)NT_STREAM_MB << 20), stream);
+    if (rc2 != 1) return rc2;
+  }
   return nt_launch(p, out_bytes > ((int64_t)NT_STREAM_MB << 20), stream);
 }
 
@@ -874,5 +890,9 @@ int ctclip_gemm_nt_dgeglu_try(const void* A, const void* B, const void* U, void*
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = dU; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = lddu;
   p.out_dtype = DT_BF16; p.alpha = 1.f; p.ntm = (int)ntm; p.ntn = (int)ntn;
   p.dgeglu_u = (const bf16_t*)U; p.dgeglu_ldu = ldu; p.dgeglu_hp = hp;
+  {
+    const int rc2 = ctclip_gemm_nt2_dgeglu_try(A, B, U, dU, M, hp, K, lda, ldb, ldu, lddu, M * 2 * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
+    if (rc2 != 1) return rc2;
+  }
   return nt_launch(p, M * 2 * N * 2 > ((int64_t)NT_STREAM_MB << 20), stream);
 }

@@ -167,6 +167,9 @@ int ctclip_gemm_residual_comp(const void* A, const void* B, void* C, void* E, co
 /* the q and k|v projections of the spatial attention with the operand layout of the attention kernels written by the GEMM (replaces nn.Linear at attention.py:141-143 + the head split / l2norm / learned scale of :145-154, i.e. nn.Linear + ctclip_attn2_prep): A (M, K) bf16, B (nsec * 256, K) bf16; per 256-column section s (8 heads x 32): inv_s != NULL -> out_s[h][m][d] = bf16(a_m . b_n) / max(|head row|, 1e-12) * scale_s[d] * mult_s, inv_s[m * 8 + h] = the inverse norm; inv_s == NULL -> head-planar copy (v).  CTCLIP_EUNSUPPORTED unless bf16, M % 256 == 0, K % 64 == 0, 1 <= nsec <= 3. */
 int ctclip_gemm_headnorm(const void* A, const void* B, int64_t M, int nsec, int64_t K, int64_t lda, int64_t ldb, void* out0, float* inv0, const float* scale0, float mult0, void* out1, float* inv1, const float* scale1, float mult1, void* out2, float* inv2, const float* scale2, float mult2, int dtype, hipStream_t stream);
 
+/* Tuning / test knob: which epilogue families of ctclip_gemm / ctclip_gemm_geglu / ctclip_gemm_dgeglu run on the two-workgroups-per-CU kernel (bit 0 plain / residual, bit 1 GEGLU forward, bit 2 GEGLU backward; negative = environment CTCLIP_GEMM_NT2 / built-in default); returns the previous mask; results are bit-identical either way. [no reference counterpart: torch picks its GEMM kernels inside ATen for nn.Linear, attention.py:48,51,119,120,125] */
+int ctclip_gemm_nt2_select(int mask);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). [workspace query of ctclip_visual_latent_fwd (to_visual_latent, ct_clip.py:549,771)] */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

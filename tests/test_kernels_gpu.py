@@ -230,6 +230,47 @@ def test_gemm_dgeglu_fused(hip, ref, M, inner, K):
     assert torch.equal(du, hip.gemm_dgeglu(dy, wt, u))
 
 
+# ---------------------------------------------------------------- second form of the NT GEMM: two 4-wave workgroups per CU (gemm_nt2.hip)
+@pytest.mark.parametrize("M,K", [(768 * 40, 512), (768 * 16, 128), (110592, 256)])
+def test_gemm_nt2_bit_identical_to_first_form(hip, ref, M, K):
+    """csrc/gemm_nt2.hip (192 x 128 tiles, double-buffered stages, a tile's epilogue under the other workgroup's main loop) accumulates every
+    output element over the same k-steps in the same order as gemm_nt.hip: plain, residual, GEGLU forward (with and without u) and the
+    out-projection grad-input + GEGLU backward are BIT-IDENTICAL between the two forms, and close to the checker."""
+    bf = torch.bfloat16
+    inner, Hp = 1365, 1408
+    x = rnd(M, K, dtype=bf, seed=1)
+    w = rnd(512, K, dtype=bf, seed=2, scale=K ** -0.5)
+    res = rnd(M, 512, dtype=bf, seed=3)
+    w_in = rnd(2 * inner, K, seed=4, scale=K ** -0.5)
+    w_il = hip.geglu_weight_interleave(w_in, Hp, bf)
+    wt = torch.zeros(Hp, K, dtype=bf, device=DEV)
+    wt[:inner] = rnd(inner, K, seed=5, scale=inner ** -0.5).to(bf)
+    u_in = rnd(M, 2 * Hp, dtype=bf, seed=6)
+    u_in[:, inner:Hp] = 0; u_in[:, Hp + inner:] = 0
+
+    def run():
+        out = [hip.gemm(x, w), hip.gemm(x, w, residual=res)]
+        u, g = hip.gemm_geglu(x, w_il, Hp)
+        out += [u, g, hip.gemm_geglu(x, w_il, Hp, save_u=False)[1], hip.gemm_dgeglu(x, wt, u_in)]
+        torch.cuda.synchronize()
+        return out
+    prev = hip.gemm_nt2_select(0)
+    try:
+        first = run()
+        hip.gemm_nt2_select(7)
+        second = run()
+        again = run()
+    finally:
+        hip.gemm_nt2_select(prev)
+    names = ["plain", "residual", "geglu u", "geglu g", "geglu g (no u)", "dgeglu"]
+    for n, a, b, c in zip(names, first, second, again):
+        assert torch.equal(a, b), f"{n}: the two forms differ ({float((a.float() - b.float()).abs().max()):.3e})"
+        assert torch.equal(b, c), f"{n}: not reproducible"
+    close(second[0], ref.gemm(x, w), rtol=2e-2, atol=2e-2)
+    close(second[1], ref.gemm(x, w, residual=res), rtol=2e-2, atol=2e-2)
+    close(second[5], ref.gemm_dgeglu(x, wt, u_in), rtol=3e-2, atol=2e-2)
+
+
 # ---------------------------------------------------------------- compensated residual stream (gemm_nt epilogue family 3, peg_march<.., 2>)
 @pytest.mark.parametrize("M,N,K", [(20480, 512, 256), (20480, 512, 1408), (110592, 512, 256), (512, 512, 256)])
 def test_gemm_residual_comp(hip, ref, M, N, K):
