@@ -155,17 +155,19 @@ def _bf16_run(full, teacher):
 # Measured, teacher-forced: full1 loss 4.78e-4, grad norm 1.73e-2, cosines image 0.999996 / text 0.999949, worst gradient cosine 0.974 (BERT position
 # embeddings); full2 (12+12) loss 1.00e-3, grad norm 9.3e-3, same cosines, worst gradient cosine 0.967.  The text tower (12 bf16 BERT layers: cosine
 # 0.99995 = 1 % of latent error) carries the teacher-forced loss error; with CTCLIP_TEXT_DTYPE=f32 it is below 1e-3 at both depths (test below).
-# Round 5 (default precision policy: text tower f32 stream + bf16 operands, f32 image head): the loss bound of BOTH depths is the bar itself, 1e-3.
-TEACHER_BOUNDS = {"full1": dict(rel=1e-3, gn_rel=5e-2, cos_i=0.99998, cos_t=0.99985, grad_cos=0.92),
-                  "full2": dict(rel=1e-3, gn_rel=2.8e-2, cos_i=0.99998, cos_t=0.99985, grad_cos=0.90)}
+# Round 5 (default precision policy: text tower f32 stream + bf16 operands, f32 image head), measured (profiles/r05_full_size_parity.log): full1
+# loss 1.05e-5, grad norm 2.5e-3, cosines image 0.999999 / text 0.999991, worst gradient cosine 0.9982; full2 (12+12) loss 7.9e-5, grad norm 2.6e-3,
+# same cosines, worst gradient cosine 0.9950.  Bounds <= 4x measured: the loss bound of both depths is 3e-4, a third of the north_star bar.
+TEACHER_BOUNDS = {"full1": dict(rel=3e-4, gn_rel=8e-3, cos_i=0.99999, cos_t=0.99997, grad_cos=0.99),
+                  "full2": dict(rel=3e-4, gn_rel=8e-3, cos_i=0.99999, cos_t=0.99997, grad_cos=0.985)}
 # Free-running: the loss / gradient deviations are dominated by WHICH codes flip (2.1 % at 4+4 layers, 3.6 % at 12+12: a discrete, chaotic
 # event -- two builds of round 2 measured 1.15e-4 and 2.03e-3 for the same loss); bounds from the largest values seen.  The agreement itself is
 # what the bf16 residual stream allows (profiles/r03_bf16_error_budget.md: 0.968 emulated on the CPU oracle, 0.991 with an f32 residual stream).
 # (agreement / latent cosines come from the EVAL forward: compensated residual stream by default -- measured 0.9872 / 0.9878 at 4+4 and
 # 0.9841 / 0.9882 at 12+12; with the plain stream 0.9793 / 0.9804 and 0.9640 / 0.9737.)
 # train_agree: the TRAINING forward's own code agreement (plain bf16 stream, what bench.py times): measured 0.979 at 4+4 and 0.966 at 12+12
-FREE_BOUNDS = {"full1": dict(rel=3e-3, gn_rel=0.3, agree=0.98, train_agree=0.97, cos_i=0.965, cos_t=0.99985),
-               "full2": dict(rel=3e-3, gn_rel=0.3, agree=0.975, train_agree=0.955, cos_i=0.965, cos_t=0.99985)}
+FREE_BOUNDS = {"full1": dict(rel=3e-3, gn_rel=0.3, agree=0.98, train_agree=0.97, cos_i=0.965, cos_t=0.99997),
+               "full2": dict(rel=3e-3, gn_rel=0.3, agree=0.975, train_agree=0.955, cos_i=0.965, cos_t=0.99997)}
 
 
 def test_bf16_full_size_teacher_forced(full):
@@ -375,7 +377,7 @@ def test_bench_shape_bf16_forward_as_timed(full8, monkeypatch):
     r = _bench_shape_forward(full8, torch.bfloat16, monkeypatch, "0")
     print(f"[full8_fwd bf16 as timed] loss rel {r['rel']:.2e}, code agreement {r['agree']:.4f}, latent cosines text {r['cos_t']:.6f} image {r['cos_i']:.6f}, "
           f"max logit difference {r['dlog']:.2e}, residual stream {', '.join(f'{k} {v:.1e}' for k, v in r['errs'].items())}")
-    assert r["rel"] < 3e-3 and r["agree"] >= 0.955 and r["cos_t"] > 0.9998 and r["cos_i"] > 0.96 and r["dlog"] < 0.16
+    assert r["rel"] < 3e-3 and r["agree"] >= 0.955 and r["cos_t"] > 0.99997 and r["cos_i"] > 0.96 and r["dlog"] < 0.16
     assert max(r["errs"].values()) < 3e-2
 
 
@@ -450,5 +452,6 @@ def test_bench_shape_bf16_backward_teacher_forced(full8):
           f"norm-weighted relative error {num / den:.2e}, worst relative Frobenius {worst_fro[1]:.2e} ({worst_fro[0]}), worst cosine {worst_cos[2]:.5f} ({worst_cos[0]})")
     for p in clip.parameters():
         p.grad = None
-    assert rel < 1e-3
-    assert gn_rel < 3e-2 and num / den < 0.2 and worst_cos[2] > 0.9
+    # measured: loss 7.0e-5, gradient norm 4.6e-4, norm-weighted relative error 4.2e-2, worst cosine 0.9979 (a temporal k_scale)
+    assert rel < 3e-4
+    assert gn_rel < 2e-3 and num / den < 0.12 and worst_cos[2] > 0.99
