@@ -32,6 +32,9 @@ int ctclip_gemm_tn_try(const void* A, const void* B, void* C, const float* bias,
 int64_t ctclip_gemm_tn_workspace(int64_t M, int64_t N, int64_t K, int split_k);
 int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
                               int32_t* part_idx, int* nparts, hipStream_t stream);
+int ctclip_gemm_sm_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype, int accumulate,
+                       float alpha, hipStream_t stream);
 int ctclip_gemm_nt_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_dtype, int res_dtype, int accumulate, float alpha,
                        hipStream_t stream);
@@ -386,6 +389,10 @@ extern "C" int ctclip_gemm(const void* A, const void* B, void* C, const float* b
   if (use_tn && in_dtype == DT_BF16 && !a_kc && !b_kc) {       // weight gradients: split-K kernel with transposing LDS reads (gemm_tn.hip)
     rc = ctclip_gemm_tn_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, out_dtype, accumulate, split_k, alpha, workspace,
                             workspace_bytes, stream);
+    if (rc != 1) return rc;
+  }
+  if (in_dtype == DT_BF16 && a_kc == b_kc) {   // the text tower's sizes (M = B * T rows): one-tile-per-workgroup LDS-DMA kernel (gemm_sm.hip)
+    rc = ctclip_gemm_sm_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_kc, b_kc, out_dtype, res_dtype, accumulate, alpha, stream);
     if (rc != 1) return rc;
   }
   if (in_dtype == DT_BF16) {   // large-tile fast path (gemm256.hip) when the shape fills the chip

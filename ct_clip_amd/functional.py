@@ -52,7 +52,8 @@ def shadow(param, tag, dtype, maker, recipe=None, deps=()):
     """Cached derived tensor of a parameter (recomputed when the parameter -- or one of `deps`, the other parameters it is built
     from -- is modified).
     recipe: how the batched refresh (refresh_shadows) rebuilds this tensor from f32 master weights -- a list of jobs
-    (source parameter, first destination row, destination rows, destination columns, map, aux, transposed), see csrc/shadow.hip."""
+    (source parameter, first destination row, destination rows, destination columns, map, aux, transposed[, first destination column]),
+    see csrc/shadow.hip."""
     cache = param.__dict__.setdefault("_ctclip_shadow", {})
     key = (tag, dtype)
     ent = cache.get(key)
@@ -101,8 +102,9 @@ def _build_shadow_jobs(scope):
             continue                       # none of this shadow's sources belongs to the calling optimiser: untouched by its step
         if any(s_.device != val.device or s_.dtype != torch.float32 for s_ in srcs):
             continue                       # (a model moved to another device keeps its lazy makers)
-        for src, (_, row0, rows, cols, mp, aux, tr) in zip(srcs, recipe):
-            dst = val[row0:row0 + rows, :cols]
+        for src, (_, row0, rows, cols, mp, aux, tr, *rest) in zip(srcs, recipe):
+            col0 = rest[0] if rest else 0          # (optional 8th field: first destination column -- stacked transposed shadows)
+            dst = val[row0:row0 + rows, col0:col0 + cols]
             jobs.append(dict(src_ref=weakref.ref(src), src_ptr=src.data_ptr(), src_stride=src.stride(0), src_shape=tuple(src.shape), dst=dst,
                              map=mp, aux=aux, transposed=bool(tr)))
             checks.append((weakref.ref(src), src.data_ptr()))
@@ -406,8 +408,10 @@ class LinearFn(Function):
             dw = weight_grad(dyc, x, ctx.weight, ctx.segments, ctx.K)
         dx = None
         if ctx.needs_input_grad[0]:
-            if dyc.dtype == torch.bfloat16 and dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0:
-                # big grad-input GEMM: use the transposed weight shadow so that both operands are k-contiguous (global_load_lds path)
+            if dyc.dtype == torch.bfloat16 and ((dyc.shape[0] >= 4096 and dyc.shape[1] % 32 == 0) or
+                                                (dyc.shape[0] >= 256 and dyc.shape[1] % 64 == 0 and dyc.shape[1] >= 128 and wsh.shape[1] >= 64)):
+                # grad-input GEMM against the TRANSPOSED weight shadow: both operands k-contiguous (the LDS-DMA kernels: gemm_nt.hip for the
+                # image tower's sizes, gemm_sm.hip for the text tower's)
                 wt = transposed_shadow(ctx.weight, wsh, ctx.segments)
                 dx = B().gemm(dyc, wt, out_dtype=ctx.x_dtype)
             else:
@@ -1115,6 +1119,17 @@ class QkvSdpaFn(Function):
         q, k, v = qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:]
         vt = be.head_transpose(v, nseq, H, L, D)
         o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale, dropout=dropout)
+        wt = None
+        if x.dtype == torch.bfloat16 and x.shape[0] >= 256 and N % 64 == 0 and K % 8 == 0 and torch.is_grad_enabled():
+            # (K, 3 N) = the stacked weight transposed: the grad-input GEMM dx = [dq | dk | dv] W then has both operands k-contiguous (gemm_sm.hip)
+            def make_wt():
+                out = torch.empty((K, 3 * N), dtype=x.dtype, device=x.device)
+                for i, w in enumerate((wq, wk, wv)):
+                    out[:, i * N:(i + 1) * N].copy_(be.transpose2d(be.convert_pad(w.detach(), N, K, x.dtype)))
+                return out
+            wt = shadow(wq, ("qkvT", id(wk), id(wv)), x.dtype, make_wt,
+                        recipe=[(w, 0, K, N, MAP_PLAIN, 0, True, i * N) for i, w in enumerate((wq, wk, wv))], deps=(wk, wv))
+        ctx.wt = wt
         ctx.save_for_backward(x, wsh, qkv, o, lse, keymask if keymask is not None else x.new_empty(0))
         ctx.params = (wq, wk, wv, bq, bk, bv)
         ctx.dims = (nseq, L, H, D, scale, keymask is not None, dropout, N, K)
@@ -1132,7 +1147,10 @@ class QkvSdpaFn(Function):
         dqkv = torch.empty_like(qkv)
         be.attn_bwd(q, k, v, qt, kt, o, do, dot, lse, None, keymask if has_mask else None, dqkv[:, :N], dqkv[:, N:2 * N], dqkv[:, 2 * N:], None,
                     nseq, H, L, D, scale, dropout=dropout)
-        dx = be.gemm(dqkv, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (be.gemm(dqkv, ctx.wt, out_dtype=ctx.x_dtype) if ctx.wt is not None
+                  else be.gemm(dqkv, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype))
         grads = []
         for i, w in enumerate((wq, wk, wv)):
             grads.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)

@@ -101,11 +101,33 @@ class FusedAdam:
         last = idx[-1]
         return self.offsets[idx[0]], self.offsets[last] + (self.params[last].numel() + 3) // 4 * 4
 
-    def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()
+    def zero_grad(self, set_to_none=False, overlap=False):
+        """overlap=True (the trainer's step): the 1.1-GB fill runs on a side stream behind the optimiser step, UNDER the next step's forward
+        (nothing writes a gradient before the next backward); `wait_zero()` -- called by the trainer right before backward -- orders the
+        backward behind it.  Default: on the caller's stream, complete in stream order."""
+        if not (overlap and self.flat_grad.is_cuda) or torch.cuda.is_current_stream_capturing():
+            self.wait_zero()
+            self.flat_grad.zero_()
+            return
+        dev = self.flat_grad.device
+        if getattr(self, "_zero_stream", None) is None:
+            self._zero_stream = torch.cuda.Stream(device=dev)
+        self.wait_zero()
+        self._zero_stream.wait_stream(torch.cuda.current_stream(dev))      # behind Adam (which reads the gradients) and the shadow refresh
+        with torch.cuda.stream(self._zero_stream):
+            self.flat_grad.zero_()
+            self._zero_done = self._zero_stream.record_event()
+
+    def wait_zero(self):
+        """The current stream waits for an overlapped zero_grad (no-op otherwise)."""
+        ev = getattr(self, "_zero_done", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_event(ev)
+            self._zero_done = None
 
     def step(self, max_grad_norm=None, extra_sq=None):
         be = _be.get()
+        self.wait_zero()
         self.step_count += 1
         # the text tower's backward writes its gradients into the flat buffer from its own stream; autograd never saw them
         Fn.join_side_streams()
@@ -335,6 +357,7 @@ class CTClipTrainer(nn.Module):
     def forward_backward(self, video, text_tokens):
         """fwd + bwd + gradient all-reduce; returns the (device) loss."""
         loss = self.CTClip(text_tokens, video, return_loss=True, device=self.device)
+        self.optim.wait_zero()   # an overlapped zero_grad of the previous step (side stream, under this forward) must be complete before a gradient is written
         Fn.wgrad_stream_begin()  # the big weight-gradient GEMMs go to a side stream, under the grad-input GEMMs of the main stream
         try:
             loss.backward()      # announces finished layers to the reducer as it goes (functional.grad_ready)
@@ -352,7 +375,7 @@ class CTClipTrainer(nn.Module):
         text_tokens = text if hasattr(text, "input_ids") else self.tokenize(text)
         loss = self.forward_backward(video, text_tokens)
         self.optim.step(self.max_grad_norm)
-        self.optim.zero_grad()
+        self.optim.zero_grad(overlap=True)
         if self.sync_loss_every and steps % self.sync_loss_every == 0:
             logs["loss"] = loss.item()
             self.print(f"{steps}: loss: {logs['loss']}")

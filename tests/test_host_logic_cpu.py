@@ -227,6 +227,10 @@ def _shadow_zoo(dev, dtype):
         mk_qkv = lambda: torch.cat([Fn.B().convert_pad(w.detach(), 64, 96, dtype) for w in (wq, wk, wv)])
         out["qkv"] = Fn.shadow(wq, ("qkv", id(wk), id(wv)), dtype, mk_qkv,
                                recipe=[(w, i * 64, 64, 96, Fn.MAP_PLAIN, 0, False) for i, w in enumerate((wq, wk, wv))])
+        # the stacked weight TRANSPOSED (K, 3 N): three transposed jobs side by side (the 8th recipe field = first destination column)
+        mk_qkvT = lambda: torch.cat([Fn.B().transpose2d(Fn.B().convert_pad(w.detach(), 64, 96, dtype)) for w in (wq, wk, wv)], dim=1)
+        out["qkvT"] = Fn.shadow(wq, ("qkvT", id(wk), id(wv)), dtype, mk_qkvT,
+                                recipe=[(w, 0, 96, 64, Fn.MAP_PLAIN, 0, True, i * 64) for i, w in enumerate((wq, wk, wv))], deps=(wk, wv))
         return out
     return [w_plain, w_pad, w_ff_in, w_ff_out, wq, wk, wv], get
 

@@ -230,6 +230,53 @@ def test_gemm_dgeglu_fused(hip, ref, M, inner, K):
     assert torch.equal(du, hip.gemm_dgeglu(dy, wt, u))
 
 
+# ---------------------------------------------------------------- the text tower's GEMM sizes (gemm_sm.hip)
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (1024, 2304, 768), (1024, 3072, 768), (1024, 768, 3072), (4096, 768, 768), (1000, 776, 192),
+                                   (13824, 512, 256), (72, 64, 128)])
+def test_gemm_sm_text_tower_shapes_nt(hip, ref, M, N, K):
+    """BERT's forward / grad-input GEMMs at M = B * T rows (and the image tower at one volume): bf16 operands with every epilogue the
+    mixed-precision text tower uses -- f32 bias, f32 or bf16 residual, f32 or bf16 output, alpha, f32 accumulate -- ragged tiles included."""
+    bf = torch.bfloat16
+    a, b = rnd(M, K, dtype=bf, seed=1), rnd(N, K, dtype=bf, seed=2, scale=K ** -0.5)
+    bias, res32, res16 = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, dtype=bf, seed=5)
+    for kw in (dict(), dict(bias=bias), dict(bias=bias, residual=res32, out_dtype=torch.float32), dict(residual=res16),
+               dict(out_dtype=torch.float32, alpha=0.5), dict(bias=bias, out_dtype=torch.float32)):
+        y, yr = hip.gemm(a, b, **kw), ref.gemm(a, b, **kw)
+        assert y.dtype == yr.dtype
+        close(y, yr, rtol=2e-2, atol=2e-2)
+        assert torch.equal(y, hip.gemm(a, b, **kw))
+    acc = rnd(M, N, seed=9)
+    out = acc.clone()
+    hip.gemm(a, b, out=out, accumulate=True)
+    close(out, acc + ref.gemm(a, b, out_dtype=torch.float32), rtol=2e-2, atol=2e-2)
+    # strided operands / outputs (column views of wider buffers, as QkvSdpaFn uses them)
+    wide = rnd(M, N + 64, dtype=bf, seed=6)
+    hip.gemm(a, b, out=wide[:, 32:32 + N])
+    close(wide[:, 32:32 + N], ref.gemm(a, b), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("T,M,N", [(1024, 2304, 768), (1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (960, 200, 136), (512, 64, 64)])
+def test_gemm_sm_text_tower_shapes_tn(hip, ref, T, M, N):
+    """dW = dy^T x with the reduction over the T = B * T token rows (k-major operands, transposing LDS reads), accumulated into an f32 slice
+    of a wider buffer as functional.weight_grad does; column views of a stacked dq | dk | dv buffer as the A operand."""
+    bf = torch.bfloat16
+    dywide = rnd(T, M + 128, dtype=bf, seed=1)
+    dy = dywide[:, 64:64 + M] if M % 8 == 0 else rnd(T, M, dtype=bf, seed=1)
+    x = rnd(T, N, dtype=bf, seed=2)
+    want = dy.float().t() @ x.float()
+    out = torch.zeros(M, N, device=DEV)
+    hip.gemm(dy, x, a_kc=False, b_kc=False, out=out, accumulate=False, split_k=0, M=M, N=N, K=T)
+    close(out, want, rtol=2e-2, atol=2e-2 * T ** 0.5)
+    base = rnd(M, N + 8, seed=3)
+    got = base.clone()
+    hip.gemm(dy, x, a_kc=False, b_kc=False, out=got[:, :N], accumulate=True, split_k=0, M=M, N=N, K=T)
+    close(got[:, :N], base[:, :N] + want, rtol=2e-2, atol=2e-2 * T ** 0.5)
+    assert torch.equal(got[:, N:], base[:, N:])
+    again = base.clone()
+    hip.gemm(dy, x, a_kc=False, b_kc=False, out=again[:, :N], accumulate=True, split_k=0, M=M, N=N, K=T)
+    assert torch.equal(got, again)
+
+
 # ---------------------------------------------------------------- second form of the NT GEMM: two 4-wave workgroups per CU (gemm_nt2.hip)
 @pytest.mark.parametrize("M,K", [(768 * 40, 512), (768 * 16, 128), (110592, 256)])
 def test_gemm_nt2_bit_identical_to_first_form(hip, ref, M, K):
