@@ -26,6 +26,8 @@ SIGNATURES = {
     "ctclip_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
     "ctclip_layernorm_bwd_workspace": (_L, [_L, _I]),
     "ctclip_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "ctclip_layernorm_bwd_partials": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "ctclip_layernorm_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P]),
     "ctclip_patch_ln_fwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "ctclip_l2norm_rows": (_I, [_P, _P, _P, _L, _I, _L, _F, _I, _I, _P]),
     "ctclip_l2norm_split3": (_I, [_P, _P, _P, _L, _I, _L, _F, _I, _I, _P]),

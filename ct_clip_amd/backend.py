@@ -184,6 +184,22 @@ class HipBackend:
         _lib.check(rc, "ctclip_layernorm_bwd")
         return dx
 
+    def layernorm_bwd_partials(self, dy, x, gamma, mean, rstd, add1=None, add2=None):
+        """First half of layernorm_bwd: -> (dx, partials); the dgamma / dbeta fold is layernorm_bwd_reduce (possibly on another stream)."""
+        rows, cols = x.shape
+        assert x.is_contiguous() and dy.is_contiguous()
+        assert all(a is None or (a.is_contiguous() and a.shape == x.shape and a.dtype == x.dtype) for a in (add1, add2))
+        dx = torch.empty_like(x)
+        nbytes = self.lib.ctclip_layernorm_bwd_workspace(rows, cols)
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        rc = self.lib.ctclip_layernorm_bwd_partials(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add1), _p(add2), rows, cols,
+                                                    dcode(x.dtype), _p(part), nbytes, _stream())
+        _lib.check(rc, "ctclip_layernorm_bwd_partials")
+        return dx, part
+
+    def layernorm_bwd_reduce(self, part, dgamma, dbeta, rows, cols):
+        _lib.check(self.lib.ctclip_layernorm_bwd_reduce(_p(part), _p(dgamma), _p(dbeta), rows, cols, _stream()), "ctclip_layernorm_bwd_reduce")
+
     def patch_ln(self, video, pt, p1, p2, kpad, eps, dtype):
         B, C, Fr, H, W = video.shape
         assert C == 1 and video.dtype == torch.float32 and video.is_contiguous()

@@ -346,16 +346,17 @@ extern "C" int ctclip_layernorm_fwd(const void* x, const float* gamma, const flo
 static int64_t ln_bwd_blocks(int64_t rows) { int64_t nb = cdiv(rows, 8); if (nb > 1024) nb = 1024; return nb < 1 ? 1 : nb; }
 extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) { return ln_bwd_blocks(rows) * 2 * cols * 4; }
 
-// LayerNorm backward: dx (+ add1 + add2: optional same-shape gradients of the input's other consumers, see the kernel), and
-// dgamma/dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
-extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                    void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols,
-                                    int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+// LayerNorm backward, first half: dx (+ add1 + add2: optional same-shape gradients of the input's other consumers, see the kernel) and, when
+// `partials` is given (ctclip_layernorm_bwd_workspace bytes), the per-workgroup partial sums of dgamma / dbeta.  The second half
+// (ctclip_layernorm_bwd_reduce) folds them; a caller may launch it on ANOTHER stream: dgamma / dbeta are leaves of the backward graph, the 13-us
+// fold of 1 024 partial rows by 16 workgroups is pure latency on the stream that carries the grad-input chain (76 times per step).
+extern "C" int ctclip_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                             void* dx, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* partials,
+                                             int64_t partials_bytes, hipStream_t stream) {
   if (!dy || !x || !dx || !mean || !rstd || cols % 8 || cols > 64 * 8 * LN_MAXV) { ctclip_set_error("layernorm_bwd: bad args"); return CTCLIP_EBADARG; }
   const int64_t nb = ln_bwd_blocks(rows);
-  const bool want = dgamma || dbeta;
-  if (want && (!workspace || workspace_bytes < ctclip_layernorm_bwd_workspace(rows, cols))) { ctclip_set_error("layernorm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
-  float* part = want ? (float*)workspace : nullptr;
+  if (partials && partials_bytes < ctclip_layernorm_bwd_workspace(rows, cols)) { ctclip_set_error("layernorm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  float* part = (float*)partials;
   const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
   const int nv = (cols + 511) / 512;
   const bool two = nv == 1 && rows >= 65536;        // two rows in flight per wave on the big token grids of the image tower
@@ -366,10 +367,28 @@ extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* 
   else return CTCLIP_EUNSUPPORTED;
 #undef LNB
 #undef LNB_NV
-  int rc = ctclip_check_launch("layernorm_bwd");
-  if (rc || !want) return rc;
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, stream, part, dgamma, dbeta, (int)nb, cols);
+  return ctclip_check_launch("layernorm_bwd");
+}
+
+// LayerNorm backward, second half: dgamma / dbeta (either may be null) += the fixed-order sum of the partial rows written by
+// ctclip_layernorm_bwd_partials for the same (rows, cols).
+extern "C" int ctclip_layernorm_bwd_reduce(const void* partials, float* dgamma, float* dbeta, int64_t rows, int cols, hipStream_t stream) {
+  if (!partials || cols % 8) { ctclip_set_error("layernorm_bwd_reduce: bad args"); return CTCLIP_EBADARG; }
+  if (!dgamma && !dbeta) return CTCLIP_OK;
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, stream, (const float*)partials, dgamma, dbeta,
+                     (int)ln_bwd_blocks(rows), cols);
   return ctclip_check_launch("ln_partial_reduce");
+}
+
+// LayerNorm backward (both halves on one stream): dx (+ add1 + add2), and dgamma / dbeta ACCUMULATED (+=) into f32 buffers (either may be null).
+extern "C" int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                    void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols,
+                                    int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  const bool want = dgamma || dbeta;
+  if (want && (!workspace || workspace_bytes < ctclip_layernorm_bwd_workspace(rows, cols))) { ctclip_set_error("layernorm_bwd: workspace too small"); return CTCLIP_EWORKSPACE; }
+  int rc = ctclip_layernorm_bwd_partials(dy, x, gamma, mean, rstd, dx, add1, add2, rows, cols, dtype, want ? workspace : nullptr, workspace_bytes, stream);
+  if (rc || !want) return rc;
+  return ctclip_layernorm_bwd_reduce(workspace, dgamma, dbeta, rows, cols, stream);
 }
 
 // CTViT.to_patch_emb[0:2] (ctvit.py:171-172): Rearrange + LayerNorm statistics; out is (B*t*h*w, kpad).

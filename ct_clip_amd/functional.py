@@ -603,6 +603,23 @@ def linear_geglu_out(g, weight, residual, comp=None):
 
 # ------------------------------------------------------------------------------------------ LayerNorm
 
+def _layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, sunk, add1=None, add2=None):
+    """LayerNorm backward through the backend.  Inside the trainer's backward (wgrad_stream_begin) on the image tower's big token grids, with
+    the parameter gradients going to the flat gradient buffer (`sunk`): the dgamma / dbeta fold -- a leaf of the backward graph, 13 us of pure
+    latency by 16 workgroups -- is launched on the weight-gradient side stream, under the grad-input chain that continues on this one."""
+    be = B()
+    side = _wgrad_side(dy) if (sunk and (dgam is not None or dbet is not None) and dy.shape[0] >= 4096) else None
+    if side is None:
+        return be.layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, add1, add2)
+    dx, part = be.layernorm_bwd_partials(dy, x, g, mean, rstd, add1, add2)
+    side.wait_stream(torch.cuda.current_stream(dy.device))
+    part.record_stream(side)
+    _WG["used"].add(dy.device.index)
+    with torch.cuda.stream(side):
+        be.layernorm_bwd_reduce(part, dgam, dbet, x.shape[0], x.shape[1])
+    return dx
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -622,7 +639,8 @@ class LayerNormFn(Function):
         bs = sink_of(b) if want_b else None
         dgam = (gs if gs is not None else torch.zeros_like(g, dtype=torch.float32)) if want_g else None
         dbet = (bs if bs is not None else torch.zeros_like(b, dtype=torch.float32)) if want_b else None
-        dx = B().layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet)
+        sunk = (not want_g or gs is not None) and (not want_b or bs is not None)
+        dx = _layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet, sunk)
         return dx, (None if (not want_g or gs is not None) else dgam), (None if (not want_b or bs is not None) else dbet), None
 
 
@@ -662,8 +680,9 @@ class LayerNormBranchFn(Function):
             adds[0] = adds[0] + extra
         if dy is None:
             dy = torch.zeros_like(x)
-        dx = B().layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet,
-                               adds[0] if len(adds) > 0 else None, adds[1] if len(adds) > 1 else None)
+        sunk = (not want_g or gs is not None) and (not want_b or bs is not None)
+        dx = _layernorm_bwd(dy.contiguous(), x, g.detach() if g is not None else None, mean, rstd, dgam, dbet, sunk,
+                            adds[0] if len(adds) > 0 else None, adds[1] if len(adds) > 1 else None)
         return dx, (None if (not want_g or gs is not None) else dgam), (None if (not want_b or bs is not None) else dbet), None, None
 
 

@@ -263,6 +263,12 @@ int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 /* bytes of workspace ctclip_layernorm_bwd needs when dgamma/dbeta are requested. [workspace query of ctclip_layernorm_bwd (autograd through F.layer_norm, attention.py:28-35,47)] */
 int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols);
 
+/* LayerNorm backward, first half: dx (+ add1 + add2) and the per-workgroup partial sums of dgamma / dbeta into `partials` (ctclip_layernorm_bwd_workspace bytes; may be null = no parameter gradients). [replaces autograd through F.layer_norm / nn.LayerNorm (attention.py:28-35,47; ctvit.py:174), split so that the parameter-gradient fold can run on another stream] */
+int ctclip_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* partials, int64_t partials_bytes, hipStream_t stream);
+
+/* LayerNorm backward, second half: dgamma / dbeta (either may be null) += the fixed-order sum of the partial rows ctclip_layernorm_bwd_partials wrote for the same (rows, cols); deterministic. [the weight / bias gradient of F.layer_norm, attention.py:28-35,47] */
+int ctclip_layernorm_bwd_reduce(const void* partials, float* dgamma, float* dbeta, int64_t rows, int cols, hipStream_t stream);
+
 /* backward of the above; dgamma/dbeta are ACCUMULATED (+=), may be NULL. [replaces autograd through F.layer_norm, attention.py:28-35,47,333, ctvit.py:172,174 and HF LayerNorm] */
 int ctclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, const void* add1, const void* add2, int64_t rows, int cols, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 

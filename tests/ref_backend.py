@@ -70,6 +70,17 @@ class RefBackend:
             dbeta += _f(dy).sum(0)
         return dx.to(x.dtype)
 
+    def layernorm_bwd_partials(self, dy, x, gamma, mean, rstd, add1=None, add2=None):
+        xh = (_f(x) - mean[:, None]) * rstd[:, None]
+        part = torch.stack([(_f(dy) * xh).sum(0), _f(dy).sum(0)])
+        return self.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, add1, add2), part
+
+    def layernorm_bwd_reduce(self, part, dgamma, dbeta, rows, cols):
+        if dgamma is not None:
+            dgamma += part[0]
+        if dbeta is not None:
+            dbeta += part[1]
+
     def patch_ln(self, video, pt, p1, p2, kpad, eps, dtype):
         b, c, f, H, W = video.shape
         t, h, w = f // pt, H // p1, W // p2
