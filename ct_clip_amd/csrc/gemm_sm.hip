@@ -55,6 +55,44 @@ template <int FA, int FB> __device__ __forceinline__ void wait_frags(u32x4 (&a)[
   else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
 }
 
+// FB (2 or 4) consecutive elements <-> floats; `vec` (kernel-uniform): the pointers / pitches allow one 8- / 16-byte access
+template <int FB> __device__ __forceinline__ void ldf(const float* p, float (&v)[FB], bool vec) {
+  if (vec) {
+    if constexpr (FB == 4) { const f32x4 q = *reinterpret_cast<const f32x4*>(p); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+    else { const hw_f32x2 q = *reinterpret_cast<const hw_f32x2*>(p); v[0] = q[0]; v[1] = q[1]; }
+  } else {
+#pragma unroll
+    for (int b = 0; b < FB; ++b) v[b] = p[b];
+  }
+}
+template <int FB> __device__ __forceinline__ void ldh(const bf16_t* p, float (&v)[FB], bool vec) {
+  if (vec) {
+    if constexpr (FB == 4) { const u32x2 q = *reinterpret_cast<const u32x2*>(p); v[0] = __uint_as_float(q[0] << 16); v[1] = __uint_as_float(q[0] & 0xffff0000u); v[2] = __uint_as_float(q[1] << 16); v[3] = __uint_as_float(q[1] & 0xffff0000u); }
+    else { const uint32_t q = *reinterpret_cast<const uint32_t*>(p); v[0] = __uint_as_float(q << 16); v[1] = __uint_as_float(q & 0xffff0000u); }
+  } else {
+#pragma unroll
+    for (int b = 0; b < FB; ++b) v[b] = bf2f(p[b]);
+  }
+}
+template <int FB> __device__ __forceinline__ void stf(float* p, const float (&v)[FB], bool vec) {
+  if (vec) {
+    if constexpr (FB == 4) *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    else *reinterpret_cast<hw_f32x2*>(p) = hw_f32x2{v[0], v[1]};
+  } else {
+#pragma unroll
+    for (int b = 0; b < FB; ++b) p[b] = v[b];
+  }
+}
+template <int FB> __device__ __forceinline__ void sth(bf16_t* p, const float (&v)[FB], bool vec) {
+  if (vec) {
+    if constexpr (FB == 4) *reinterpret_cast<u32x2*>(p) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    else *reinterpret_cast<uint32_t*>(p) = pack2bf(v[0], v[1]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < FB; ++b) p[b] = f2bf(v[b]);
+  }
+}
+
 // TRANS = false: NT.  A (M, lda) and B (N, ldb) k-contiguous.  LDS stage = [BM rows of A | BN rows of B], 128 B per row (one k-step).
 // TRANS = true: TN.  A = [K][M] (lda), B = [K][N] (ldb).  LDS stage = [A image | B image], image = [column block of 64][64 k][128 B].
 template <int BM, int BN, int NS, bool TRANS>
@@ -206,6 +244,9 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 
   // ---- epilogue: NT: acc[a][b][r] = C[m0 + wm WM + 16 a + 4 lg + r][n0 + wn WN + li FB + b]; TN: same rows, column n0 + wn WN + 16 b + li
   const int64_t rbase = m0 + wm * WM + lg * 4;
+  // (kernel-uniform) every row of C / residual starts FB-element aligned for the widest access used: 16 bytes covers all of them
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(p.C) | (uintptr_t)(p.ldc * 2)) % 16 == 0) && (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
+                      (!p.residual || ((reinterpret_cast<uintptr_t>(p.residual) | (uintptr_t)(p.ldr * 2)) % 16 == 0));
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -219,23 +260,29 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 #pragma unroll
         for (int b = 0; b < FB; ++b) v[b] = acc[a][b][r] * p.alpha;
         if (p.bias) {
+          float t[FB];
+          ldf<FB>(p.bias + col, t, vec_ok);
 #pragma unroll
-          for (int b = 0; b < FB; ++b) v[b] += p.bias[col + b];
+          for (int b = 0; b < FB; ++b) v[b] += t[b];
         }
         if (p.residual) {
+          float t[FB];
+          if (p.res_dtype == DT_F32) ldf<FB>(reinterpret_cast<const float*>(p.residual) + row * p.ldr + col, t, vec_ok);
+          else ldh<FB>(reinterpret_cast<const bf16_t*>(p.residual) + row * p.ldr + col, t, vec_ok);
 #pragma unroll
-          for (int b = 0; b < FB; ++b)
-            v[b] += p.res_dtype == DT_F32 ? reinterpret_cast<const float*>(p.residual)[row * p.ldr + col + b]
-                                          : bf2f(reinterpret_cast<const bf16_t*>(p.residual)[row * p.ldr + col + b]);
+          for (int b = 0; b < FB; ++b) v[b] += t[b];
         }
         if (p.out_dtype == DT_F32) {
           float* c = reinterpret_cast<float*>(p.C) + row * p.ldc + col;
+          if (p.accumulate) {
+            float t[FB];
+            ldf<FB>(c, t, vec_ok);
 #pragma unroll
-          for (int b = 0; b < FB; ++b) c[b] = p.accumulate ? c[b] + v[b] : v[b];
+            for (int b = 0; b < FB; ++b) v[b] += t[b];
+          }
+          stf<FB>(c, v, vec_ok);
         } else {
-          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col;
-#pragma unroll
-          for (int b = 0; b < FB; b += 2) *reinterpret_cast<uint32_t*>(c + b) = pack2bf(v[b], v[b + 1]);
+          sth<FB>(reinterpret_cast<bf16_t*>(p.C) + row * p.ldc + col, v, vec_ok);
         }
       } else {
 #pragma unroll

@@ -608,7 +608,8 @@ def _layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, sunk, add1=None, add2=None)
     the parameter gradients going to the flat gradient buffer (`sunk`): the dgamma / dbeta fold -- a leaf of the backward graph, 13 us of pure
     latency by 16 workgroups -- is launched on the weight-gradient side stream, under the grad-input chain that continues on this one."""
     be = B()
-    side = _wgrad_side(dy) if (sunk and (dgam is not None or dbet is not None) and dy.shape[0] >= 4096) else None
+    side = _wgrad_side(dy) if (sunk and (dgam is not None or dbet is not None) and dy.shape[0] >= 4096
+                               and os.environ.get("CTCLIP_LN_REDUCE_SIDE", "1") != "0") else None
     if side is None:
         return be.layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, add1, add2)
     dx, part = be.layernorm_bwd_partials(dy, x, g, mean, rstd, add1, add2)
