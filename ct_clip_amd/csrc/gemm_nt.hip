@@ -149,6 +149,25 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   // PERSISTENT: one workgroup per CU walks the tile list.  In round i the workgroups of XCD x (blockIdx % 8) take consecutive
   // tile ids, which share A row panels through that XCD's L2.
   const int G = gridDim.x;
+#ifndef NT_XCD_CONTIG
+#define NT_XCD_CONTIG 1
+#endif
+#if NT_XCD_CONTIG
+  // Round 5: every XCD owns ONE contiguous run of tile ids for the whole launch (ntiles / 8 of them, +1 for the first ntiles % 8) and walks it
+  // G / 8 tiles per round.  Before, round i dealt ids [256 i + 32 x, + 32) to XCD x: with 11 column tiles per A row panel (the GEGLU
+  // in-projection) the 32-id windows straddle row panels, and every straddled panel was fetched from HBM by two XCDs' L2s -- 242 MB fetched
+  // against 116 MB algorithmic (profiles/r04: 2.08 x).  With N = 512 (2 column tiles) the two maps give the same locality.
+  const int xcd = blockIdx.x & 7, xidx = blockIdx.x >> 3, xper = G >> 3;       // G is a multiple of 8
+  const int t_per = ntiles >> 3, t_rem = ntiles & 7;
+  const int x_start = xcd * t_per + (xcd < t_rem ? xcd : t_rem), x_cnt = t_per + (xcd < t_rem ? 1 : 0);
+  auto tile_of = [&](int it, int64_t& m0, int64_t& n0) -> bool {
+    const int local = it * xper + xidx;
+    if (local >= x_cnt) return false;
+    const int id = x_start + local;
+    m0 = (int64_t)(id / p.ntn) * TM; n0 = (int64_t)(id % p.ntn) * TN;
+    return true;
+  };
+#else
   const int slotb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);     // G is a multiple of 8
   auto tile_of = [&](int it, int64_t& m0, int64_t& n0) -> bool {
     const int id = it * G + slotb;
@@ -156,6 +175,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     m0 = (int64_t)(id / p.ntn) * TM; n0 = (int64_t)(id % p.ntn) * TN;
     return true;
   };
+#endif
   int64_t m0, n0;
   if (!tile_of(0, m0, n0)) return;
 
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   // De-synchronise the CUs: every tile takes the same time, so without this all 256 workgroups reach their epilogue together and
   // the chip writes 32 MB in one burst every tile period, then nothing.  Phase offsets of 1/8 tile period spread the stores.
   {
-    const int phase = NT_STAGGER == 1 ? (blockIdx.x & 7) : ((slotb >> 2) & 7);
+    const int phase = NT_STAGGER == 1 ? (blockIdx.x & 7) : (int)((blockIdx.x >> 2) & 7);
     for (int z = (phase * nk * 137) >> 10; z > 0; --z) __builtin_amdgcn_s_sleep(32);   // 32 * 64 clk; a step is ~2200 clk
   }
 #endif

@@ -604,12 +604,14 @@ def linear_geglu_out(g, weight, residual, comp=None):
 # ------------------------------------------------------------------------------------------ LayerNorm
 
 def _layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, sunk, add1=None, add2=None):
-    """LayerNorm backward through the backend.  Inside the trainer's backward (wgrad_stream_begin) on the image tower's big token grids, with
-    the parameter gradients going to the flat gradient buffer (`sunk`): the dgamma / dbeta fold -- a leaf of the backward graph, 13 us of pure
-    latency by 16 workgroups -- is launched on the weight-gradient side stream, under the grad-input chain that continues on this one."""
+    """LayerNorm backward through the backend.  CTCLIP_LN_REDUCE_SIDE=1: inside the trainer's backward (wgrad_stream_begin) on the image tower's
+    big token grids, with the parameter gradients going to the flat gradient buffer (`sunk`), the dgamma / dbeta fold -- a leaf of the backward
+    graph, 13 us of latency by 16 workgroups, 76 times per step -- is launched on the weight-gradient side stream instead of in front of the next
+    grad-input kernel.  Measured in round 5 (same box, 2 x 20 steps each): 84.28 / 84.36 ms against 84.04 / 84.01 with the fold in line -- the
+    two extra stream hand-offs per LayerNorm cost what the fold's latency saved.  Off by default; the split entry points stay."""
     be = B()
     side = _wgrad_side(dy) if (sunk and (dgam is not None or dbet is not None) and dy.shape[0] >= 4096
-                               and os.environ.get("CTCLIP_LN_REDUCE_SIDE", "1") != "0") else None
+                               and os.environ.get("CTCLIP_LN_REDUCE_SIDE", "0") == "1") else None      # (measured: no gain, +0.3 ms -- off by default)
     if side is None:
         return be.layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet, add1, add2)
     dx, part = be.layernorm_bwd_partials(dy, x, g, mean, rstd, add1, add2)
@@ -1140,7 +1142,7 @@ class QkvSdpaFn(Function):
         vt = be.head_transpose(v, nseq, H, L, D)
         o, lse = be.attn_fwd(q, k, vt, None, keymask, nseq, H, L, D, scale, dropout=dropout)
         wt = None
-        if x.dtype == torch.bfloat16 and x.shape[0] >= 256 and N % 64 == 0 and K % 8 == 0 and torch.is_grad_enabled():
+        if x.dtype == torch.bfloat16 and x.shape[0] >= 256 and N % 64 == 0 and K % 8 == 0 and ctx.needs_input_grad[0]:
             # (K, 3 N) = the stacked weight transposed: the grad-input GEMM dx = [dq | dk | dv] W then has both operands k-contiguous (gemm_sm.hip)
             def make_wt():
                 out = torch.empty((K, 3 * N), dtype=x.dtype, device=x.device)
