@@ -14,7 +14,7 @@ from ct_clip_amd import ctclip  # noqa: E402
 if os.environ.get("PROBE_SKIP_TEXT") == "1":
     cache = {}
 
-    def constant_text(bert, ids, mask, dt):
+    def constant_text(bert, ids, mask, dt, od=None):
         key = (tuple(ids.shape), dt)
         if key not in cache:
             cache[key] = torch.randn(ids.numel(), bert.config.hidden_size, device=ids.device).to(dt or torch.float32)
