@@ -150,13 +150,16 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   // tile ids, which share A row panels through that XCD's L2.
   const int G = gridDim.x;
 #ifndef NT_XCD_CONTIG
-#define NT_XCD_CONTIG 1
+#define NT_XCD_CONTIG 0
 #endif
 #if NT_XCD_CONTIG
-  // Round 5: every XCD owns ONE contiguous run of tile ids for the whole launch (ntiles / 8 of them, +1 for the first ntiles % 8) and walks it
-  // G / 8 tiles per round.  Before, round i dealt ids [256 i + 32 x, + 32) to XCD x: with 11 column tiles per A row panel (the GEGLU
-  // in-projection) the 32-id windows straddle row panels, and every straddled panel was fetched from HBM by two XCDs' L2s -- 242 MB fetched
-  // against 116 MB algorithmic (profiles/r04: 2.08 x).  With N = 512 (2 column tiles) the two maps give the same locality.
+  // Round 5 experiment, compiled OFF: every XCD owns ONE contiguous run of tile ids for the whole launch (ntiles / 8 of
+  // them, +1 for the first ntiles % 8) and walks it G / 8 tiles per round.  The default map below deals ids [256 i + 32 x, + 32) to XCD x in
+  // round i: with 11 column tiles per A row panel (the GEGLU in-projection) the 32-id windows straddle row panels and a straddled panel is
+  // fetched by two XCDs' L2s.  Measured (profiles/r05_ab_experiments.md): FETCH 242 -> 214 MB per launch (2.08 x -> 1.84 x the algorithmic
+  // 116 MB; traffic / algorithmic 1.12 -> 1.09) -- and the step 84.80 / 84.27 ms against 84.23 / 84.11 with the default map: the kernel is
+  // bound by its main loop + store path (3.0 of 8 TB/s), not by what it fetches, and the contiguous runs give up the default map's balance
+  // of the last round across XCDs.  Kept as a build option (tools/build_variant.py x gemm_nt.hip:NT_XCD_CONTIG=1).
   const int xcd = blockIdx.x & 7, xidx = blockIdx.x >> 3, xper = G >> 3;       // G is a multiple of 8
   const int t_per = ntiles >> 3, t_rem = ntiles & 7;
   const int x_start = xcd * t_per + (xcd < t_rem ? xcd : t_rem), x_cnt = t_per + (xcd < t_rem ? 1 : 0);
