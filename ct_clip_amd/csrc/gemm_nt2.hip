@@ -346,7 +346,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm_nt2_kernel(Nt2Params p) {
 }
 
 int nt2_launch(const Nt2Params& p, int epi, bool nontemporal, hipStream_t stream) {
-  static bool raised = false;
+  static bool raised_dev[64] = {};                        // (per device)
+  int dev_ = 0; (void)hipGetDevice(&dev_);
+  bool& raised = raised_dev[(dev_ >= 0 && dev_ < 64) ? dev_ : 0];
   if (!raised) {
     const void* fns[6] = {(const void*)gemm_nt2_kernel<false, 0>, (const void*)gemm_nt2_kernel<true, 0>, (const void*)gemm_nt2_kernel<false, 1>,
                           (const void*)gemm_nt2_kernel<true, 1>, (const void*)gemm_nt2_kernel<false, 2>, (const void*)gemm_nt2_kernel<true, 2>};

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 template <int BM, int NS, bool TRANS>
 int sm_launch(const SmParams& p, hipStream_t stream) {
   constexpr int LDSB = NS * 2 * BM * ROWB;
-  static bool raised = false;
+  static bool raised_dev[64] = {};                        // (the attribute is per device: one process may drive several)
+  int dev = 0; (void)hipGetDevice(&dev);
+  bool& raised = raised_dev[(dev >= 0 && dev < 64) ? dev : 0];
   if (!raised) {
     if (hipFuncSetAttribute((const void*)gemm_sm_kernel<BM, BM, NS, TRANS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return 1;
     raised = true;

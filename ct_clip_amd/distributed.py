@@ -72,19 +72,24 @@ class VqStatSync:
     """Deferred form (the trainer's default): the EMA statistics of the vector quantiser -- 32 KB of bin counts + 16.8 MB of code sums in
     f32 -- are ONE buffer, all-reduced (SUM) on the COMMUNICATION stream while the forward carries on, and the EMA update of the codebook
     (which nothing reads before the next forward) is applied by `flush()` when the step's collectives are joined (GradReducer.finish).
-    The immediate form put two blocking all-reduces on the main stream in the middle of every forward.  A second quantiser call on the
-    same codebook before the flush (VocabFine's per-pathology sequence) flushes first: the EMA sequence is preserved."""
+    The immediate form put two blocking all-reduces on the main stream in the middle of every forward.  A quantiser call that finds an update
+    of the same codebook pending (VocabFine's per-pathology sequence, an evaluation forward inside the step) applies it BEFORE reading the
+    codebook (`before_forward`, called at the top of VqFn.forward): the EMA sequence is preserved."""
 
     def __init__(self, comm_stream=None):
         self.comm_stream = comm_stream
         self.pending = []                  # (bins, esum, cluster_size, embed, decay)
         self.calls = 0                     # collectives issued (tests / inspection)
 
+    def before_forward(self, embed):
+        """Called by VqFn.forward before it reads the codebook: a pending update of the same codebook is applied first."""
+        if any(e[3].data_ptr() == embed.data_ptr() for e in self.pending):
+            self.flush()
+
     def __call__(self, bins, esum, cluster_size, embed, decay):
         if world_size() == 1:
             return False
-        if any(e[3].data_ptr() == embed.data_ptr() for e in self.pending):
-            self.flush()
+        self.before_forward(embed)
         flat = _fused_stats(bins, esum)
         pieces = [flat] if flat is not None else [bins, esum]
         if self.comm_stream is not None and bins.is_cuda:

@@ -1285,6 +1285,9 @@ class VqFn(Function):
     def forward(ctx, x, embed, cluster_size, training, decay, forced_idx=None):
         be = B()
         inv = None
+        pre = getattr(getattr(VqFn, "stat_sync", None), "before_forward", None)
+        if pre is not None:
+            pre(embed)                      # a deferred EMA update of THIS codebook (distributed.VqStatSync) is applied before the codebook is read
         if forced_idx is not None:
             idx = forced_idx.reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
         elif x.dtype == torch.float32:

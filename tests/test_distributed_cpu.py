@@ -105,3 +105,50 @@ def test_all_gather_rows_backward_is_local_slice():
     """Unit check of the autograd rule without a process group is not possible; world_size 1 must be the identity path."""
     from ct_clip_amd import distributed as D
     assert D.world_size() == 1 and D.rank() == 0
+
+
+def _vq_twice_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from ct_clip_amd import backend, distributed as D, functional as Fn
+    from ct_clip_amd.ctvit import VectorQuantize
+    from tests.ref_backend import RefBackend
+    backend.use(RefBackend())
+    res = {}
+    for mode in ("immediate", "deferred"):
+        torch.manual_seed(0)
+        vq = VectorQuantize(dim=32, codebook_size=64).train()
+        sync = D.VqStatSync(None)
+        Fn.VqFn.stat_sync = staticmethod(D.sync_vq_stats if mode == "immediate" else sync)
+        g = torch.Generator().manual_seed(10 + rank)
+        cb0 = vq._codebook.embed.clone()
+        for call in range(3):                                  # three quantiser calls before the step's collectives are joined (VocabFine's sequence)
+            x = torch.randn(40, 32, generator=g)
+            q, idx = vq(x)
+            if mode == "deferred":                             # never more than one update pending: a second call on the same codebook flushed the first
+                assert len(sync.pending) == 1 and sync.calls == call + 1
+                if call == 0:
+                    assert torch.equal(vq._codebook.embed, cb0)
+        sync.flush()
+        assert not sync.pending
+        res[mode] = (vq._codebook.embed.clone(), vq._codebook.cluster_size.clone(), idx.clone())
+    Fn.VqFn.stat_sync = None
+    assert torch.equal(res["immediate"][0], res["deferred"][0]) and torch.equal(res["immediate"][1], res["deferred"][1])
+    assert torch.equal(res["immediate"][2], res["deferred"][2])
+    if rank == 0:
+        torch.save(dict(ok=True, cluster=res["deferred"][1]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_vq_sync_preserves_the_ema_sequence(tmp_path):
+    """distributed.VqStatSync defers the EMA update to the end of the step; a quantiser call that finds an update of the SAME codebook pending
+    (the fused VocabFine step quantises 18 times per step, each call reading the codebook the previous one moved) flushes it first: buffers and
+    code ids after three calls equal the immediate (in-forward) form bit for bit, on both ranks."""
+    out = str(tmp_path / "vq.pt")
+    mp.spawn(_vq_twice_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["ok"] and float(r["cluster"].sum()) > 0
