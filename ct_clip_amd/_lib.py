@@ -21,6 +21,7 @@ SIGNATURES = {
     "ctclip_gemm": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _P]),
     "ctclip_gemm_workspace": (_L, [_L, _L, _L, _I, _I]),
     "ctclip_gemm_nt2_select": (_I, [_I]),
+    "ctclip_gemm_dw_db": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_gemm_argmax_workspace": (_L, [_L, _L]),
     "ctclip_gemm_argmax": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P, _L, _P]),
     "ctclip_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),

@@ -148,6 +148,20 @@ class HipBackend:
         residual, bit 1 GEGLU forward, bit 2 GEGLU backward; -1 = environment / built-in default.  Returns the previous mask."""
         return int(self.lib.ctclip_gemm_nt2_select(int(mask)))
 
+    def gemm_dw_db(self, dy, x, dw, db, accumulate=True):
+        """dw (N_out, K_in) f32 (+)= dy^T x and db (N_out) f32 (+)= column sums of dy in ONE launch (csrc/gemm_sm.hip); dy (T, N_out), x (T, K_in) bf16,
+        possibly column views.  False when the shape is not served (the caller composes gemm + colsum)."""
+        T, n_out = dy.shape
+        k_in = x.shape[1]
+        if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dw.dtype != torch.float32 or db.dtype != torch.float32 or not db.is_contiguous()
+                or dy.stride(1) != 1 or x.stride(1) != 1 or dw.stride(1) != 1 or tuple(dw.shape) != (n_out, k_in) or db.numel() != n_out):
+            return False
+        rc = self.lib.ctclip_gemm_dw_db(_p(dy), _p(x), _p(dw), _p(db), T, n_out, k_in, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), _stream())
+        if rc == -2:
+            return False
+        _lib.check(rc, "ctclip_gemm_dw_db")
+        return True
+
     def gemm_argmax(self, a, b):
         M, K = a.shape
         N = b.shape[0]

@@ -29,6 +29,7 @@ struct SmParams {
   int out_dtype, res_dtype, accumulate;
   float alpha;
   int ntm, ntn;
+  float* colsum;      // TN only: colsum[m] (+)= sum_k A[k][m] -- the bias gradient of the Linear whose weight gradient this GEMM is (same `accumulate`)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -193,6 +194,14 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 #pragma unroll
     for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // TN + colsum: the workgroups of the first column tile also sum A over k -- one more MFMA per A fragment against a fragment of ones
+  // (D[i][j] = sum_k A[k][i] for every j); only the waves wn == 0 of those workgroups (both wn waves of a row block hold the same A fragments)
+  const bool do_colsum = TRANS && p.colsum != nullptr && n0 == 0 && wn == 0;
+  f32x4 accb[FA];
+#pragma unroll
+  for (int a = 0; a < FA; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
   auto read_set = [&](u32x4 (&fa_)[FA], u32x4 (&fb_)[FB], int ks, uint32_t so) {      // so: byte offset of the stage
     if constexpr (!TRANS) {
       const uint32_t aa = pa[ks] + so, bb = pb[ks] + so;
@@ -213,6 +222,11 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 #pragma unroll
       for (int a = 0; a < FA; ++a)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa_[a]), __builtin_bit_cast(bf16x8, fb_[b]), acc[a][b], 0, 0, 0);
+    if (TRANS && do_colsum) {      // (wave-uniform)
+#pragma unroll
+      for (int a = 0; a < FA; ++a)
+        accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa_[a]), __builtin_bit_cast(bf16x8, ones), accb[a], 0, 0, 0);
+    }
   };
 
   // ---- prologue: NS - 1 steps in flight (steps past the end re-load the last one: the vmcnt arithmetic stays uniform)
@@ -244,6 +258,15 @@ __global__ __launch_bounds__(NTH) void gemm_sm_kernel(SmParams p) {
 
   // ---- epilogue: NT: acc[a][b][r] = C[m0 + wm WM + 16 a + 4 lg + r][n0 + wn WN + li FB + b]; TN: same rows, column n0 + wn WN + 16 b + li
   const int64_t rbase = m0 + wm * WM + lg * 4;
+  if (TRANS && do_colsum && li == 0) {
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = rbase + a * 16 + r;
+        if (row < p.M) p.colsum[row] = (p.accumulate ? p.colsum[row] : 0.f) + accb[a][r] * p.alpha;
+      }
+  }
   // (kernel-uniform) every row of C / residual starts FB-element aligned for the widest access used: 16 bytes covers all of them
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(p.C) | (uintptr_t)(p.ldc * 2)) % 16 == 0) && (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                       (!p.residual || ((reinterpret_cast<uintptr_t>(p.residual) | (uintptr_t)(p.ldr * 2)) % 16 == 0));
@@ -323,12 +346,34 @@ int sm_enabled() {
 
 }  // namespace
 
+static int sm_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                  int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype, int accumulate, float alpha, float* colsum, hipStream_t stream);
+
+// Weight AND bias gradient of a Linear layer in one launch: dW (N_out x K_in, f32, ldw) (+)= dy^T x and db (N_out, f32) (+)= column sums of dy, with dy =
+// (T, N_out) and x = (T, K_in) bf16, k-major (a row is one token).  [replaces autograd through nn.Linear with bias: HF BertSelfAttention query / key /
+// value, BertSelfOutput.dense, BertIntermediate.dense, BertOutput.dense -- the reference's text tower, ct_clip.py:685-686]  The column sums ride the
+// A fragments of the first column tile's workgroups (one more MFMA per fragment against ones): no second pass over dy, no reduce launch.
+// CTCLIP_EUNSUPPORTED when the shape is not served by this kernel (callers fall back to ctclip_gemm (0,0) + ctclip_colsum).
+extern "C" int ctclip_gemm_dw_db(const void* dy, const void* x, float* dW, float* db, int64_t T, int64_t n_out, int64_t k_in, int64_t lddy, int64_t ldx,
+                                 int64_t ldw, int accumulate, hipStream_t stream) {
+  if (!dy || !x || !dW || !db) { ctclip_set_error("gemm_dw_db: null argument"); return CTCLIP_EBADARG; }
+  const int rc = sm_try(dy, x, dW, nullptr, nullptr, n_out, k_in, T, lddy, ldx, ldw, 0, 0, 0, DT_F32, 0, accumulate, 1.f, db, stream);
+  if (rc == 1) { ctclip_set_error("gemm_dw_db: shape not served"); return CTCLIP_EUNSUPPORTED; }
+  return rc;
+}
+
 // Internal entry used by ctclip_gemm's dispatcher (gemm.hip) for the shapes the persistent kernels decline.  Returns 1 when not eligible.
 // a_kc && b_kc: NT; !a_kc && !b_kc: TN (M, N = rows / columns of C; K = the reduction = rows of both operands).
 int ctclip_gemm_sm_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype, int accumulate,
                        float alpha, hipStream_t stream) {
-  if (!sm_enabled() || a_kc != b_kc) return 1;
+  if (!sm_enabled()) return 1;
+  return sm_try(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_kc, b_kc, out_dtype, res_dtype, accumulate, alpha, nullptr, stream);
+}
+
+static int sm_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                  int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype, int accumulate, float alpha, float* colsum, hipStream_t stream) {
+  if (a_kc != b_kc) return 1;
   const bool trans = !a_kc;
   if (K % TK || K < 2 * TK || M < 64 || N < 64 || (N % 8) || (trans && (M % 8))) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
@@ -341,7 +386,7 @@ int ctclip_gemm_sm_try(const void* A, const void* B, void* C, const float* bias,
   SmParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.residual = residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
-  p.out_dtype = out_dtype; p.res_dtype = res_dtype; p.accumulate = accumulate; p.alpha = alpha;
+  p.out_dtype = out_dtype; p.res_dtype = res_dtype; p.accumulate = accumulate; p.alpha = alpha; p.colsum = colsum;
   const int64_t t128 = cdiv(M, 128) * cdiv(N, 128);
   if (t128 >= 120) {
     p.ntm = (int)cdiv(M, 128); p.ntn = (int)cdiv(N, 128);

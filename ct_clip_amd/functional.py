@@ -309,6 +309,21 @@ def _weight_grad(dy, x, weight, segments, K, sink):
     return None if sink is not None else dst
 
 
+def weight_bias_grad(dy, x, weight, bias, K):
+    """Weight AND bias gradient of a Linear in one launch (ctclip_gemm_dw_db: the column sums of dy ride the dW GEMM's A fragments) for the text
+    tower's sizes: -> (dw, db) as weight_grad / vec_grad would return them (None = written to the flat gradient buffer), or None when the shape
+    is not served."""
+    if not (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and weight.dim() == 2 and 128 <= dy.shape[0] <= 16384 and dy.shape[0] % 64 == 0
+            and K == weight.shape[1] and os.environ.get("CTCLIP_DW_DB", "1") != "0"):
+        return None
+    wsink, bsink = sink_of(weight), sink_of(bias)
+    dstw = wsink if wsink is not None else torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
+    dstb = bsink if bsink is not None else torch.zeros(bias.shape, dtype=torch.float32, device=dy.device)
+    if not B().gemm_dw_db(dy, x[:, :K], dstw.view(weight.shape[0], -1), dstb, accumulate=True):
+        return None
+    return (None if wsink is not None else dstw), (None if bsink is not None else dstb)
+
+
 def vec_grad(param, compute):
     """compute(dst) accumulates a vector gradient into dst (f32, param-shaped).  Returns grad or None (sink)."""
     sink = sink_of(param)
@@ -403,8 +418,13 @@ class LinearFn(Function):
             dyc = B().convert_pad(dy, dy.shape[0], round_up(nout, 8), x.dtype)[:, :nout]
         else:
             dyc = dy
-        dw = None
-        if ctx.weight.requires_grad:      # first: on the weight-gradient stream it then runs under the grad-input GEMM below
+        dw, db, fused_wb = None, None, None
+        if (ctx.weight.requires_grad and ctx.bias is not None and ctx.bias.requires_grad and len(ctx.segments) == 1
+                and ctx.segments[0] == (0, ctx.weight.shape[0], 0) and dyc.shape[1] == ctx.weight.shape[0]):
+            fused_wb = weight_bias_grad(dyc, x, ctx.weight, ctx.bias, ctx.K)      # dW and db in one launch (text tower sizes)
+        if fused_wb is not None:
+            dw, db = fused_wb
+        elif ctx.weight.requires_grad:      # first: on the weight-gradient stream it then runs under the grad-input GEMM below
             dw = weight_grad(dyc, x, ctx.weight, ctx.segments, ctx.K)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -418,8 +438,7 @@ class LinearFn(Function):
                 dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype)
             if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
                 dx = dx[:, :x.shape[1]]
-        db = None
-        if ctx.bias is not None and ctx.bias.requires_grad:
+        if fused_wb is None and ctx.bias is not None and ctx.bias.requires_grad:
             dyb = dy if (dy.dtype == torch.float32 and dy.stride(1) == 1) else dyc      # (mixed precision: the bias gradient sums the unrounded dy)
             db = vec_grad(ctx.bias, lambda dst: B().colsum(dyb, dst, N=ctx.bias.numel()))
         return dx, dw, db, dres, None, None, None, None, None
@@ -1173,12 +1192,16 @@ class QkvSdpaFn(Function):
         if ctx.needs_input_grad[0]:
             dx = (be.gemm(dqkv, ctx.wt, out_dtype=ctx.x_dtype) if ctx.wt is not None
                   else be.gemm(dqkv, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype))
-        grads = []
-        for i, w in enumerate((wq, wk, wv)):
-            grads.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)
-        for i, b in enumerate((bq, bk, bv)):
-            grads.append(vec_grad(b, lambda dst, i=i: be.colsum(dqkv[:, i * N:(i + 1) * N], dst, N=N)) if b.requires_grad else None)
-        return (dx, *grads, None, None, None, None, None, None, None, None)
+        gw, gb = [], []
+        for i, (w, b) in enumerate(zip((wq, wk, wv), (bq, bk, bv))):
+            dyi = dqkv[:, i * N:(i + 1) * N]
+            fused = weight_bias_grad(dyi, x, w, b, K) if (w.requires_grad and b.requires_grad) else None      # dW and db in one launch
+            if fused is not None:
+                gw.append(fused[0]); gb.append(fused[1])
+                continue
+            gw.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)
+            gb.append(vec_grad(b, lambda dst, i=i: be.colsum(dqkv[:, i * N:(i + 1) * N], dst, N=N)) if b.requires_grad else None)
+        return (dx, *gw, *gb, None, None, None, None, None, None, None, None)
 
 
 class DropoutAddFn(Function):

@@ -170,6 +170,9 @@ int ctclip_gemm_headnorm(const void* A, const void* B, int64_t M, int nsec, int6
 /* Tuning / test knob: which epilogue families of ctclip_gemm / ctclip_gemm_geglu / ctclip_gemm_dgeglu run on the two-workgroups-per-CU kernel (bit 0 plain / residual, bit 1 GEGLU forward, bit 2 GEGLU backward; negative = environment CTCLIP_GEMM_NT2 / built-in default); returns the previous mask; results are bit-identical either way. [no reference counterpart: torch picks its GEMM kernels inside ATen for nn.Linear, attention.py:48,51,119,120,125] */
 int ctclip_gemm_nt2_select(int mask);
 
+/* Weight AND bias gradient of a Linear layer in one launch: dW (n_out x k_in, f32, row stride ldw) (+)= dy^T x and db (n_out, f32) (+)= the column sums of dy; dy (T, n_out) and x (T, k_in) bf16 token-major (row strides lddy, ldx: column views allowed); the column sums ride the dW GEMM's A fragments (one more MFMA per fragment against ones): no second pass over dy, no reduce launch; deterministic.  CTCLIP_EUNSUPPORTED when the shape is not served (callers compose ctclip_gemm (0,0) + ctclip_colsum). [replaces autograd through nn.Linear WITH bias: HF BertSelfAttention query / key / value, BertSelfOutput.dense, BertIntermediate.dense, BertOutput.dense -- the text tower the reference calls at ct_clip.py:685-686] */
+int ctclip_gemm_dw_db(const void* dy, const void* x, float* dW, float* db, int64_t T, int64_t n_out, int64_t k_in, int64_t lddy, int64_t ldx, int64_t ldw, int accumulate, hipStream_t stream);
+
 /* bytes of workspace ctclip_visual_latent_fwd needs (split-K partial sums of the 294912-wide projection, summed in a fixed order). [workspace query of ctclip_visual_latent_fwd (to_visual_latent, ct_clip.py:549,771)] */
 int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 

@@ -39,6 +39,16 @@ class RefBackend:
     def gemm_nt2_select(self, mask):
         return 0
 
+    def gemm_dw_db(self, dy, x, dw, db, accumulate=True):
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.shape[0] % 64 or dy.shape[0] < 128:
+            return False
+        gw, gb = _f(dy).t() @ _f(x), _f(dy).sum(0)
+        if accumulate:
+            dw += gw; db += gb
+        else:
+            dw.copy_(gw); db.copy_(gb)
+        return True
+
     def gemm_argmax(self, a, b):
         s = _f(a) @ _f(b).t()
         val, idx = s.max(dim=-1)

@@ -442,3 +442,38 @@ def test_bf16_mode_default_precision_policy(golden, ref_backend, name):
             assert worst > 0.999, worst
     assert rels["default"] < 3e-4, rels
     assert rels["rounds 1-4"] > 2 * rels["default"], rels
+
+
+def test_linear_backward_fused_weight_and_bias_gradient(ref_backend):
+    """Text-tower sizes (>= 128 token rows, bf16 matrix-core operands): LinearFn / QkvSdpaFn hand dW and db to ONE backend call (gemm_dw_db) -- with and
+    without gradient sinks, f32 (mixed precision) and bf16 activations -- and produce the gradients of the composed path."""
+    from ct_clip_amd import functional as Fn
+    torch.manual_seed(0)
+    M, K, N = 128, 64, 96
+    for act in (torch.float32, torch.bfloat16):
+        x = (torch.randn(M, K) * 0.5).to(act).requires_grad_(True)
+        w, b = torch.nn.Parameter(torch.randn(N, K) * 0.1), torch.nn.Parameter(torch.randn(N) * 0.1)
+        res = torch.randn(M, N).to(act)
+        calls = []
+        be = Fn.B()
+        orig = be.gemm_dw_db
+        be.gemm_dw_db = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            y = Fn.linear(x, w, b, residual=res, operand_dtype=torch.bfloat16)
+            g = torch.randn(M, N).to(y.dtype)
+            y.backward(g)
+        finally:
+            del be.gemm_dw_db
+        assert calls == [1]
+        xb, gb = x.detach().to(torch.bfloat16).float(), g.to(torch.bfloat16).float()
+        torch.testing.assert_close(w.grad, gb.t() @ xb, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b.grad, gb.sum(0), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(x.grad.float(), (gb @ w.detach().to(torch.bfloat16).float()).to(act).float(), rtol=2e-2, atol=2e-2)
+        # with sinks (the trainer's flat gradient buffer): accumulated in place, autograd sees None
+        w2, b2 = torch.nn.Parameter(w.detach().clone()), torch.nn.Parameter(b.detach().clone())
+        w2._ctclip_grad_sink, b2._ctclip_grad_sink = torch.ones(N, K), torch.ones(N)
+        x2 = x.detach().clone().requires_grad_(True)
+        Fn.linear(x2, w2, b2, residual=res, operand_dtype=torch.bfloat16).backward(g)
+        assert w2.grad is None and b2.grad is None
+        torch.testing.assert_close(w2._ctclip_grad_sink, 1 + gb.t() @ xb, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b2._ctclip_grad_sink, 1 + gb.sum(0), rtol=1e-4, atol=1e-4)

@@ -277,6 +277,37 @@ def test_gemm_sm_text_tower_shapes_tn(hip, ref, T, M, N):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("T,n_out,k_in", [(1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (4096, 768, 768), (960, 200, 136), (128, 64, 64)])
+def test_gemm_dw_db_weight_and_bias_gradient_in_one_launch(hip, ref, T, n_out, k_in):
+    """ctclip_gemm_dw_db: dW (+)= dy^T x and db (+)= colsum(dy) from ONE launch (the column sums ride the A fragments of the first column tile's
+    workgroups) -- against the composed gemm + colsum, with dy a column view of a stacked dq | dk | dv buffer and dW / db slices of a flat buffer."""
+    bf = torch.bfloat16
+    wide = rnd(T, n_out + 128, dtype=bf, seed=1)
+    dy = wide[:, 64:64 + n_out] if n_out % 8 == 0 else rnd(T, n_out, dtype=bf, seed=1)
+    x = rnd(T, k_in, dtype=bf, seed=2)
+    flat = rnd(n_out * k_in + n_out + 32, seed=3)
+    base = flat.clone()
+    dw, db = flat[16:16 + n_out * k_in].view(n_out, k_in), flat[16 + n_out * k_in:16 + n_out * k_in + n_out]
+    ok = hip.gemm_dw_db(dy, x, dw, db, accumulate=True)
+    if n_out * k_in < 64 * 64 * 8:
+        assert not ok          # (fewer than 8 workgroups: declined, the caller composes)
+        return
+    assert ok
+    want_w, want_b = dy.float().t() @ x.float(), dy.float().sum(0)
+    bw, bb = base[16:16 + n_out * k_in].view(n_out, k_in), base[16 + n_out * k_in:16 + n_out * k_in + n_out]
+    close(dw, bw + want_w, rtol=2e-2, atol=2e-2 * T ** 0.5)
+    close(db, bb + want_b, rtol=2e-2, atol=2e-2 * T ** 0.5)
+    assert torch.equal(flat[:16], base[:16]) and torch.equal(flat[16 + n_out * k_in + n_out:], base[16 + n_out * k_in + n_out:])
+    again = base.clone()
+    hip.gemm_dw_db(dy, x, again[16:16 + n_out * k_in].view(n_out, k_in), again[16 + n_out * k_in:16 + n_out * k_in + n_out], accumulate=True)
+    assert torch.equal(again, flat)
+    # overwrite form
+    dw2, db2 = torch.full((n_out, k_in), 7.0, device=DEV), torch.full((n_out,), 7.0, device=DEV)
+    assert hip.gemm_dw_db(dy, x, dw2, db2, accumulate=False)
+    close(dw2, want_w, rtol=2e-2, atol=2e-2 * T ** 0.5)
+    close(db2, want_b, rtol=2e-2, atol=2e-2 * T ** 0.5)
+
+
 # ---------------------------------------------------------------- second form of the NT GEMM: two 4-wave workgroups per CU (gemm_nt2.hip)
 @pytest.mark.parametrize("M,K", [(768 * 40, 512), (768 * 16, 128), (110592, 256)])
 def test_gemm_nt2_bit_identical_to_first_form(hip, ref, M, K):
