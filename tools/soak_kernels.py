@@ -130,3 +130,22 @@ nseq_t, L_t = 4608, 24
 soak("attn_short_fwd", lambda: [be.attn_short_fwd(q, kv, qs, ks, nseq_t, L_t, H, 8.0)])
 dqs, dks = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
 soak("attn_short_bwd", lambda: as_list(be.attn_short_bwd(q, kv, qs, ks, do, nseq_t, L_t, H, 8.0, dqs.zero_(), dks.zero_())) + [dqs, dks])
+# ---- round 5: the text tower's GEMM sizes (csrc/gemm_sm.hip: LDS-DMA ring with counted vmcnt waits, one barrier per k-step) and the second form of the NT GEMM
+Mt = 1024
+xt, wt768, wt3072, bt = rnd(Mt, 768), rnd(768, 768, scale=0.05), rnd(3072, 768, scale=0.05), rnd(3072, dtype=torch.float32)
+rt = rnd(Mt, 3072, dtype=torch.float32)
+soak("gemm_sm NT 64x64 (1024 x 768 x 768, bf16 out)", lambda: [be.gemm(xt, wt768)])
+soak("gemm_sm NT 128x128 (1024 x 3072 x 768, bias + f32 residual, f32 out)", lambda: [be.gemm(xt, wt3072, bias=bt, residual=rt, out_dtype=torch.float32)])
+dyt = rnd(Mt, 3072, scale=0.1)
+dwt, dbt = torch.zeros(3072, 768, device=dev), torch.zeros(3072, device=dev)
+soak("gemm_sm TN 128x128 (3072 x 768 x 1024, accumulate)",
+     lambda: [be.gemm(dyt, xt, a_kc=False, b_kc=False, out=dwt.zero_(), accumulate=True, split_k=0, M=3072, N=768, K=Mt)])
+soak("gemm_dw_db (dW + db in one launch, 3072 x 768 x 1024)", lambda: [be.gemm_dw_db(dyt, xt, dwt.zero_(), dbt.zero_(), accumulate=True), dwt, dbt][1:])
+dyt7 = rnd(Mt, 768, scale=0.1)
+dw7, db7 = torch.zeros(768, 768, device=dev), torch.zeros(768, device=dev)
+soak("gemm_dw_db 64x64 (768 x 768 x 1024)", lambda: [be.gemm_dw_db(dyt7, xt, dw7.zero_(), db7.zero_(), accumulate=True), dw7, db7][1:])
+prev_mask = be.gemm_nt2_select(7)
+soak("gemm_nt2 plain + residual (N=512, K=1408)", lambda: [be.gemm(g1408, w_ffout, residual=res)])
+soak("gemm_nt2 in-projection + GEGLU (u, g)", lambda: as_list(be.gemm_geglu(x512, w_il, 1408)))
+soak("gemm_nt2 out-projection grad-input + GEGLU backward", lambda: [be.gemm_dgeglu(x512, wt_out, u)])
+be.gemm_nt2_select(prev_mask)
