@@ -53,6 +53,9 @@
 #ifndef NT_PLANAR_TEST
 #define NT_PLANAR_TEST 0
 #endif
+#ifndef NT_DEPHASE
+#define NT_DEPHASE 0
+#endif
 #ifndef NT_COUNTED_EPI
 // 1 = the first step of a tile waits with vmcnt(GL + n) for its panels only, not for the previous tile's epilogue stores (n = the VMEM
 // instructions of that epilogue).  Measured +1..3 % on the GEMMs (profiles/r02_gemm_epilogue_experiments.md) and bit-identical results in
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   NT_RA(0, 0) NT_RA(1, 0)
   NT_RB(0, 0) NT_RB(1, 0) NT_RB(2, 0) NT_RB(3, 0) NT_RB(4, 0) NT_RB(5, 0) NT_RB(6, 0) NT_RB(7, 0)
   int cs = 0;             // ring slot of A(g) for the consumer's current step g
+  const bool dph = (wave & 4) != 0;      // (NT_DEPHASE) the second wave of every SIMD
   int pn = 0;             // VMEM instructions this wave issued in the previous tile's epilogue (exact or an under-count; 0 = unknown)
   auto wait_prev = [&](int n) {      // wave-uniform
     switch (n) {
@@ -316,6 +320,20 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     // previous tile's epilogue], A(g+2)) and every wave holds all of step g in registers; H4: (t, 1), rows a = 2,3, fetch (t+1, ks=0)
     // -- of the next tile after the last step -- and the LDS-DMA of B(g+2) into the slot of A(g), free since barrier_g.
     // WAITVM = the vmcnt wait in front of barrier_g.
+    // NT_DEPHASE (round-5 experiment, compiled off): the two waves that share a SIMD (w and w + 4) issue their A-panel LDS-DMA pieces in different
+    // half-phases -- waves 0-3 in H1 as always, waves 4-7 in H3 -- so that a SIMD's matrix pipe has one wave issuing MFMAs while the other is held by
+    // its DMA issues (60-185 clk each).  Same vmcnt arithmetic: the newest GL pieces at barrier_g are A(g+2) for both classes.
+#if NT_DEPHASE
+#define NT_DMA_A1(i) if (!dph) glds(a_k, a_off[i], slot_a2, i);
+#define NT_DMA_A3(i) if (dph) glds(a_k, a_off[i], slot_a2, i);
+#define NT_ADV_A1
+#define NT_ADV_A3 if (++a_t == nk) enter_a(a_it + 1);
+#else
+#define NT_DMA_A1(i) glds(a_k, a_off[i], slot_a2, i);
+#define NT_DMA_A3(i)
+#define NT_ADV_A1 if (++a_t == nk) enter_a(a_it + 1);
+#define NT_ADV_A3
+#endif
 #define NT_STEP(WAITVM) { \
       const int slot_b2 = cs; \
       const int slot_a2 = wrap(cs + 4); \
@@ -325,14 +343,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       NT_RA(2, 0) NT_RA(3, 0) \
       __builtin_amdgcn_sched_barrier(0); \
       NT_H13(0) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(1) glds(a_k, a_off[0], slot_a2, 0); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(1) NT_DMA_A1(0) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(2) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(3) glds(a_k, a_off[1], slot_a2, 1); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(3) NT_DMA_A1(1) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(4) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(5) glds(a_k, a_off[2], slot_a2, 2); __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(5) NT_DMA_A1(2) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(6) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(7) glds(a_k, a_off[3], slot_a2, 3); __builtin_amdgcn_sched_barrier(0); \
-      if (++a_t == nk) enter_a(a_it + 1); \
+      NT_H13(7) NT_DMA_A1(3) __builtin_amdgcn_sched_barrier(0); \
+      NT_ADV_A1 \
       NT_RA(0, 1) NT_RA(1, 1) \
       wait_lds<2>(fa[2], fa[3]); \
       __builtin_amdgcn_sched_barrier(0); \
@@ -347,13 +365,14 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       NT_RA(2, 1) NT_RA(3, 1) \
       __builtin_amdgcn_sched_barrier(0); \
       NT_H13(0) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(1) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(1) NT_DMA_A3(0) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(2) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(3) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(3) NT_DMA_A3(1) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(4) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(5) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(5) NT_DMA_A3(2) __builtin_amdgcn_sched_barrier(0); \
       NT_H13(6) __builtin_amdgcn_sched_barrier(0); \
-      NT_H13(7) __builtin_amdgcn_sched_barrier(0); \
+      NT_H13(7) NT_DMA_A3(3) __builtin_amdgcn_sched_barrier(0); \
+      NT_ADV_A3 \
       WAITVM; \
       wait_lds<0>(fa[2], fa[3]); \
       __builtin_amdgcn_s_barrier(); \

@@ -17,6 +17,10 @@
 // 637 TFLOP/s.
 #include "common.h"
 
+#ifndef TN_DEPHASE
+#define TN_DEPHASE 0      // round-5 experiment (see gemm_nt.hip NT_DEPHASE): waves 4-7 issue their A-panel LDS-DMA pieces in H3 instead of H1
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(TnParams p) {
     TN_RA(0, 0) TN_RA(1, 0)
     TN_RB(0, 0) TN_RB(1, 0) TN_RB(2, 0) TN_RB(3, 0) TN_RB(4, 0) TN_RB(5, 0) TN_RB(6, 0) TN_RB(7, 0)
     int cs = 0;
+    const bool dph = (wave & 4) != 0;      // (TN_DEPHASE)
 
 #define TN_MFMA2(a0, b)                                                                                                              \
     acc[a0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a0]), __builtin_bit_cast(bf16x8, fb[b]),      \
@@ -176,10 +181,16 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(TnParams p) {
       for (int b = 0; b < 8; ++b) {
         if (b == 0) { TN_H13(0, 0) } else if (b == 1) { TN_H13(1, 0) } else if (b == 2) { TN_H13(2, 0) } else if (b == 3) { TN_H13(3, 0) }
         else if (b == 4) { TN_H13(4, 0) } else if (b == 5) { TN_H13(5, 0) } else if (b == 6) { TN_H13(6, 0) } else { TN_H13(7, 0) }
+#if TN_DEPHASE
+        if ((b & 1) && !dph) glds(a_k, a_off[b >> 1], slot_a2, b >> 1);
+#else
         if (b & 1) glds(a_k, a_off[b >> 1], slot_a2, b >> 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
+#if !TN_DEPHASE
       adv(a_t);
+#endif
       // ---- H2: (t, 0), rows a = 2,3; fetch (t, ks = 1)
       TN_RA(0, 1) TN_RA(1, 1)
       wait_lds<4>(fa[2], fa[3]);
@@ -199,8 +210,14 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(TnParams p) {
       for (int b = 0; b < 8; ++b) {
         if (b == 0) { TN_H13(0, 1) } else if (b == 1) { TN_H13(1, 1) } else if (b == 2) { TN_H13(2, 1) } else if (b == 3) { TN_H13(3, 1) }
         else if (b == 4) { TN_H13(4, 1) } else if (b == 5) { TN_H13(5, 1) } else if (b == 6) { TN_H13(6, 1) } else { TN_H13(7, 1) }
+#if TN_DEPHASE
+        if ((b & 1) && dph) glds(a_k, a_off[b >> 1], slot_a2, b >> 1);      // (the second wave of every SIMD issues its A pieces here: see gemm_nt.hip NT_DEPHASE)
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
+#if TN_DEPHASE
+      adv(a_t);
+#endif
       // ---- barrier_g: A(g+1), B(g+1) landed (A(g+2) may stay in flight); every wave holds all of step g in registers
       wait_vm<GL>();
       wait_lds<0>(fa[2], fa[3]);
