@@ -20,8 +20,9 @@
 //   * fragment reads through inline asm with explicit lgkmcnt waits (two register sets, no in-place rolling: 184 registers), LDS layout,
 //     swizzle, B-row permutation and the register-direct epilogues are those of gemm_nt.hip.
 // Eligible shapes: M % 192 == 0, N % 128 == 0, K % 64 == 0 (>= 2 steps), bf16 in / bf16 out, no bias; epilogue families: plain / residual,
-// GEGLU forward, out-projection grad-input + GEGLU backward.  Everything else stays on gemm_nt.hip.  CTCLIP_GEMM_NT2 selects the families
-// (bit 0 plain / residual, bit 1 GEGLU forward, bit 2 GEGLU backward; default: see nt2_mask()).
+// GEGLU forward, out-projection grad-input + GEGLU backward.  Everything else stays on gemm_nt.hip.  CTCLIP_GEMM_NT2 / ctclip_gemm_nt2_select choose the
+// families (bit 0 plain / residual, bit 1 GEGLU forward, bit 2 GEGLU backward).  DEFAULT 0: MEASURED SLOWER than the first form on every family
+// (1.02 - 1.43 x per launch, profiles/r05_gemm_nt2.md) -- the kernel stays as the measurement, bit-identical to gemm_nt.hip.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
