@@ -657,8 +657,11 @@ def main():
                 vid = bufs[cur]
                 pipe["tickets"] = fill(cur ^ 1)                  # the NEXT step's batch goes up under this step
             loss = trainer.forward_backward(vid, text)
-            trainer.optim.step(trainer.max_grad_norm)
-            trainer.optim.zero_grad(overlap=os.environ.get("CTCLIP_ZERO_OVERLAP", "1") != "0")      # as CTClipTrainer.train_step
+            if os.environ.get("CTCLIP_ADAM_ZERO", "1") != "0":      # as CTClipTrainer.train_step: Adam clears the gradients it has just read
+                trainer.optim.step(trainer.max_grad_norm, zero_grad=True)
+            else:
+                trainer.optim.step(trainer.max_grad_norm)
+                trainer.optim.zero_grad(overlap=os.environ.get("CTCLIP_ZERO_OVERLAP", "1") != "0")
             if pipe is not None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(device))

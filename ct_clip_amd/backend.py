@@ -928,10 +928,12 @@ class HipBackend:
         _lib.check(rc, "ctclip_grad_norm_clip")
         return out
 
-    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None, decay_mask4=None):
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None, decay_mask4=None, zero_grad=False):
+        """zero_grad: the gradient buffer is cleared in the same pass (ctclip_adam_step_zero_grad: no separate fill launch)."""
         assert decay_mask4 is None or (decay_mask4.dtype == torch.uint8 and decay_mask4.numel() >= (p.numel() + 3) // 4)
-        rc = self.lib.ctclip_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                                       int(step), float(weight_decay), _p(clip), _p(decay_mask4), _stream())
+        fn = self.lib.ctclip_adam_step_zero_grad if zero_grad else self.lib.ctclip_adam_step
+        rc = fn(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                int(step), float(weight_decay), _p(clip), _p(decay_mask4), _stream())
         _lib.check(rc, "ctclip_adam_step")
 
 

@@ -61,18 +61,20 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype
     for li, layer in enumerate(bert.encoder.layer):
         x = Fn.grad_ready(x, layer)
         sa, so = layer.attention.self, layer.attention.output
-        c = Fn.QkvSdpaFn.apply(x, sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias, keymask,
-                               Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None, od)
+        # (x feeds the attention AND the residual connection: the node hands back a view of x for the latter, so that in backward the residual
+        # path's gradient is added inside the grad-input GEMM's epilogue instead of by an elementwise accumulation kernel)
+        c, x_res = Fn.QkvSdpaFn.apply(x, sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias, keymask,
+                                      Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None, od, True)
         if p_hid > 0:    # dense -> dropout -> + input -> LayerNorm
-            h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias, out_dtype=dtype, operand_dtype=od), x, 1 + 2 * li)
+            h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias, out_dtype=dtype, operand_dtype=od), x_res, 1 + 2 * li)
         else:
-            h1 = Fn.linear(c, so.dense.weight, so.dense.bias, residual=x, out_dtype=dtype, operand_dtype=od)
+            h1 = Fn.linear(c, so.dense.weight, so.dense.bias, residual=x_res, out_dtype=dtype, operand_dtype=od)
         x = Fn.layer_norm(h1, so.LayerNorm.weight, so.LayerNorm.bias, eps)
-        u = Fn.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, operand_dtype=od)
+        u, x_res = Fn.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, operand_dtype=od, passthrough=True)
         m = Fn.GeluFn.apply(u)
         if p_hid > 0:
-            h2 = drop(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, operand_dtype=od), x, 2 + 2 * li)
+            h2 = drop(Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, operand_dtype=od), x_res, 2 + 2 * li)
         else:
-            h2 = Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x, operand_dtype=od)
+            h2 = Fn.linear(m, layer.output.dense.weight, layer.output.dense.bias, residual=x_res, operand_dtype=od)
         x = Fn.layer_norm(h2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
     return x

@@ -377,13 +377,17 @@ class LinearFn(Function):
     """y = x @ Wshadow^T (+ bias) (+ residual).  ``segments``/``K`` describe how dW maps back onto the real weight."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype, comp=None):
-        """comp = the residue e of `residual`: the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled).
+    def forward(ctx, x, weight, bias, residual, wsh, segments, K, out_dtype, comp=None, passthrough=False):
+        """passthrough: also return a VIEW of x for x's other consumer (BERT's residual connections read the tensor the dense layer reads):
+        backward then receives that consumer's gradient and adds it in the grad-input GEMM's epilogue (no elementwise accumulation kernel).
+        comp = the residue e of `residual`: the residual add runs on the compensated stream -> (y, e_out) (see residual_comp_enabled).
         Mixed precision (x f32, wsh bf16 -- the text tower's default in bf16 mode): x is rounded ONCE to the operand dtype for the matrix
         cores, the product is accumulated, biased, added to the residual and stored in f32; backward rounds dy the same way and returns dx
         in x's dtype."""
         e_out = None
         ctx.x_dtype = x.dtype
+        ctx.passthrough = bool(passthrough)
+        x_in = x
         if x.dtype != wsh.dtype:
             x = B().convert_pad(x, x.shape[0], x.shape[1], wsh.dtype)
         if comp is not None and bias is None and residual is not None:
@@ -397,6 +401,9 @@ class LinearFn(Function):
         ctx.weight, ctx.bias, ctx.segments, ctx.K = weight, bias, segments, K
         ctx.has_res = residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
+        if passthrough:
+            assert comp is None
+            return y, x_in.view_as(x_in)
         if comp is None:
             return y
         if e_out is None:      # shape not served: plain bf16 rounding at this add, the incoming residue travels on
@@ -408,6 +415,7 @@ class LinearFn(Function):
     def backward(ctx, dy, _de=None):
         x, wsh = ctx.saved_tensors
         dy = dy.contiguous()
+        d_pass = _de.contiguous() if (ctx.passthrough and _de is not None) else None      # gradient of x's other consumer: added in the dX epilogue
         dres = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
@@ -433,24 +441,26 @@ class LinearFn(Function):
                 # grad-input GEMM against the TRANSPOSED weight shadow: both operands k-contiguous (the LDS-DMA kernels: gemm_nt.hip for the
                 # image tower's sizes, gemm_sm.hip for the text tower's)
                 wt = transposed_shadow(ctx.weight, wsh, ctx.segments)
-                dx = B().gemm(dyc, wt, out_dtype=ctx.x_dtype)
+                dx = B().gemm(dyc, wt, residual=d_pass, out_dtype=ctx.x_dtype)
             else:
-                dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype)
+                dx = B().gemm(dyc, wsh, a_kc=True, b_kc=False, residual=d_pass, out_dtype=ctx.x_dtype)
             if x.stride(0) != x.shape[1]:  # strided-view input (e.g. CLS rows): match its logical shape
                 dx = dx[:, :x.shape[1]]
+        elif d_pass is not None:
+            dx = d_pass
         if fused_wb is None and ctx.bias is not None and ctx.bias.requires_grad:
             dyb = dy if (dy.dtype == torch.float32 and dy.stride(1) == 1) else dyc      # (mixed precision: the bias gradient sums the unrounded dy)
             db = vec_grad(ctx.bias, lambda dst: B().colsum(dyb, dst, N=ctx.bias.numel()))
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None, operand_dtype=None):
+def linear(x, weight, bias=None, residual=None, out_dtype=None, kpad=None, comp=None, operand_dtype=None, passthrough=False):
     """nn.Linear on a (M, K[p]) activation.  kpad: activation/weight K padding (zeros).  comp = the residue e of `residual`: the residual add on the
     compensated residual stream -> (y, e_out).  operand_dtype: dtype of the matrix-core operands when it differs from the activation's
     (mixed precision: f32 activations, bf16 operands, f32 accumulate / bias / residual / output)."""
     N, K = weight.shape
     wsh = plain_shadow(weight, operand_dtype or x.dtype, kpad=kpad)
-    return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype, comp)
+    return LinearFn.apply(x, weight, bias, residual, wsh, [(0, N, 0)], K, out_dtype, comp, passthrough)
 
 
 def geglu_hidden_pad(inner):
@@ -1137,12 +1147,15 @@ class QkvSdpaFn(Function):
     runs one grad-input GEMM and three weight-gradient GEMMs on column views."""
 
     @staticmethod
-    def forward(ctx, x, wq, wk, wv, bq, bk, bv, keymask, nseq, L, H, D, scale, dropout, operand_dtype=None):
-        """operand_dtype (mixed precision): x arrives in f32, is rounded once to the operand dtype; q | k | v, the attention core and its
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, keymask, nseq, L, H, D, scale, dropout, operand_dtype=None, passthrough=False):
+        """passthrough: also return a view of x for the residual connection (its gradient is added in the grad-input GEMM's epilogue).
+        operand_dtype (mixed precision): x arrives in f32, is rounded once to the operand dtype; q | k | v, the attention core and its
         output are in the operand dtype (they are matrix-core operands of QK^T, PV and the output projection), dx returns in f32."""
         be = B()
         N, K = wq.shape
         ctx.x_dtype = x.dtype
+        ctx.passthrough = bool(passthrough)
+        x_in = x
         if operand_dtype is not None and x.dtype != operand_dtype:
             x = be.convert_pad(x, x.shape[0], x.shape[1], operand_dtype)
 
@@ -1174,12 +1187,15 @@ class QkvSdpaFn(Function):
         ctx.save_for_backward(x, wsh, qkv, o, lse, keymask if keymask is not None else x.new_empty(0))
         ctx.params = (wq, wk, wv, bq, bk, bv)
         ctx.dims = (nseq, L, H, D, scale, keymask is not None, dropout, N, K)
+        if passthrough:
+            return o, x_in.view_as(x_in)
         return o
 
     @staticmethod
-    def backward(ctx, do):
+    def backward(ctx, do, d_pass=None):
         be = B()
         x, wsh, qkv, o, lse, keymask = ctx.saved_tensors
+        d_pass = d_pass.contiguous() if (ctx.passthrough and d_pass is not None) else None
         nseq, L, H, D, scale, has_mask, dropout, N, K = ctx.dims
         wq, wk, wv, bq, bk, bv = ctx.params
         do = do.contiguous()
@@ -1190,8 +1206,8 @@ class QkvSdpaFn(Function):
                     nseq, H, L, D, scale, dropout=dropout)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = (be.gemm(dqkv, ctx.wt, out_dtype=ctx.x_dtype) if ctx.wt is not None
-                  else be.gemm(dqkv, wsh, a_kc=True, b_kc=False, out_dtype=ctx.x_dtype))
+            dx = (be.gemm(dqkv, ctx.wt, residual=d_pass, out_dtype=ctx.x_dtype) if ctx.wt is not None
+                  else be.gemm(dqkv, wsh, a_kc=True, b_kc=False, residual=d_pass, out_dtype=ctx.x_dtype))
         gw, gb = [], []
         for i, (w, b) in enumerate(zip((wq, wk, wv), (bq, bk, bv))):
             dyi = dqkv[:, i * N:(i + 1) * N]
@@ -1201,7 +1217,7 @@ class QkvSdpaFn(Function):
                 continue
             gw.append(weight_grad(dqkv, x, w, [(0, N, i * N)], K) if w.requires_grad else None)
             gb.append(vec_grad(b, lambda dst, i=i: be.colsum(dqkv[:, i * N:(i + 1) * N], dst, N=N)) if b.requires_grad else None)
-        return (dx, *gw, *gb, None, None, None, None, None, None, None, None)
+        return (dx, *gw, *gb, None, None, None, None, None, None, None, None, None)
 
 
 class DropoutAddFn(Function):

@@ -125,7 +125,9 @@ class FusedAdam:
             torch.cuda.current_stream(self.flat_grad.device).wait_event(ev)
             self._zero_done = None
 
-    def step(self, max_grad_norm=None, extra_sq=None):
+    def step(self, max_grad_norm=None, extra_sq=None, zero_grad=False):
+        """zero_grad=True: optimizer.step() AND optimizer.zero_grad() (scripts/CTCLIPTrainer.py:259-264) -- the Adam kernel overwrites every
+        gradient with zero right after reading it (ctclip_adam_step_zero_grad): the caller must not clear the buffer again."""
         be = _be.get()
         self.wait_zero()
         self.step_count += 1
@@ -135,7 +137,7 @@ class FusedAdam:
         self.last_norm = clip
         self.lr = self.param_groups[0]["lr"]          # learning-rate schedules write param_groups (finetune.cosine_lr)
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                     self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4)
+                     self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4, zero_grad=zero_grad)
         Fn.bump_weight_epoch(self.params)
         Fn.refresh_shadows(self.params)   # every bf16 GEMM operand of THIS optimiser's parameters rebuilt from the new f32 weights in one launch
 
@@ -196,8 +198,7 @@ class GraphedStep:
             with torch.cuda.graph(graph):
                 _be._lib.check(be.lib.ctclip_advance_step_state(self.state.data_ptr(), _be._stream()), "ctclip_advance_step_state")
                 self.loss = t.forward_backward(self.video, self.text)
-                t.optim.step(t.max_grad_norm)
-                t.optim.zero_grad()
+                t.optim.step(t.max_grad_norm, zero_grad=True)
             torch.cuda.synchronize(dev)
         except BaseException:
             # a failed capture must leave the process as it found it: the library's step-state pointer (every later EAGER Adam launch and
@@ -374,8 +375,7 @@ class CTClipTrainer(nn.Module):
         video = video.to(self.device, non_blocking=True)
         text_tokens = text if hasattr(text, "input_ids") else self.tokenize(text)
         loss = self.forward_backward(video, text_tokens)
-        self.optim.step(self.max_grad_norm)
-        self.optim.zero_grad(overlap=True)
+        self.optim.step(self.max_grad_norm, zero_grad=True)      # (step + zero_grad of CTCLIPTrainer.py:259-264 in one pass over the flat buffers)
         if self.sync_loss_every and steps % self.sync_loss_every == 0:
             logs["loss"] = loss.item()
             self.print(f"{steps}: loss: {logs['loss']}")

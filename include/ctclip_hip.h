@@ -293,6 +293,9 @@ int ctclip_grad_norm_clip(const float* g, int64_t n, const float* extra_sq, floa
 /* torch.optim.Adam / AdamW(lr, betas, eps, weight_decay).step() over a flat buffer (optimizer.py:24-32; CTCLIPTrainer.py:262).  weight_decay > 0 is the decoupled AdamW decay; decay_mask4 (one byte per 4 parameters, 1 = decayed) or null (all decayed) implements the reference's no-decay group for parameters with ndim < 2 (transformer_maskgit/optimizer.py:3-8).  clip: the 2-float result of ctclip_grad_norm_clip or null. */
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s);
 
+/* ctclip_adam_step followed by optimizer.zero_grad() in ONE pass over the flat buffers: every gradient is overwritten with zero right after it has been read (4 more bytes written per parameter instead of a separate fill launch over the 1.1-GB gradient buffer). [replaces optim.step(); optim.zero_grad() at scripts/CTCLIPTrainer.py:259-264] */
+int ctclip_adam_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float weight_decay, const float* clip, const uint8_t* decay_mask4, hipStream_t s);
+
 /* scripts/data.py:92-162 (CTReportDataset.nii_img_to_tensor) without the file decode: src = the (H, W, D) voxel array as nibabel returns it (src_dtype 0 int16, 1 f32, 2 f64, device memory) -> HU = slope * v + intercept, trilinear resample to target_xy / target_z mm (F.interpolate align_corners=False, new size int(n * spacing / target)), clip to [hu_lo, hu_hi], / hu_div, centre crop / pad with pad_value -> out (out_d, out_h, out_w) f32 = (240, 480, 480). */
 int ctclip_preprocess_volume(const void* src, int src_dtype, int H, int W, int D, double slope, double intercept, double xy_spacing, double z_spacing, double target_xy, double target_z, float* out, int out_h, int out_w, int out_d, double hu_lo, double hu_hi, double hu_div, float pad_value, hipStream_t stream);
 

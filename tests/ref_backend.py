@@ -674,7 +674,7 @@ class RefBackend:
         coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) if max_norm else torch.ones_like(norm)
         return torch.stack([norm, coef])
 
-    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None, decay_mask4=None):
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, clip=None, decay_mask4=None, zero_grad=False):
         gg = g * (clip[1] if clip is not None else 1.0)
         if weight_decay:
             if decay_mask4 is None:
@@ -687,3 +687,5 @@ class RefBackend:
         bc1 = 1 - beta1 ** step
         bc2 = 1 - beta2 ** step
         p.addcdiv_(m, v.sqrt() / (bc2 ** 0.5) + eps, value=-lr / bc1)
+        if zero_grad:
+            g.zero_()

@@ -210,12 +210,13 @@ def test_graphed_step_mixed_with_eager_forwards_and_failed_capture(golden, tmp_p
     for _ in range(3):
         eager(tr)
     boom = RuntimeError("injected")
-    real = tr.optim.zero_grad      # (the last call of the recorded step: every side stream has been joined, optim.step() has bumped its counter)
-    monkeypatch.setattr(tr.optim, "zero_grad", lambda *a, **k: (_ for _ in ()).throw(boom))
+    from ct_clip_amd import functional as Fn
+    real = Fn.refresh_shadows      # (the last call of the recorded step: every side stream has been joined, optim.step() has bumped its counter)
+    monkeypatch.setattr(Fn, "refresh_shadows", lambda *a, **k: (_ for _ in ()).throw(boom))
     gs = GraphedStep(tr)
     with pytest.raises(RuntimeError):
         gs.capture(video, text)
-    monkeypatch.setattr(tr.optim, "zero_grad", real)
+    monkeypatch.setattr(Fn, "refresh_shadows", real)
     assert gs.state is None and tr.optim.step_count == 3
     tr.optim.zero_grad()
     for _ in range(2):

@@ -1010,6 +1010,13 @@ def test_grad_norm_and_adam(hip, ref):
         hip.adam_step(p, g, m, v, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clip)
         ref.adam_step(pr, g, mr, vr, 1.25e-6, 0.9, 0.99, 1e-8, step, 0.0, clipr)
     close(p, pr, rtol=1e-6, atol=1e-7); close(m, mr, rtol=1e-4, atol=1e-9); close(v, vr, rtol=1e-4, atol=1e-12)
+    # step + zero_grad in one pass (ctclip_adam_step_zero_grad): the same update bit for bit, the gradient buffer cleared -- tail elements included
+    p2, m2, v2, g2 = p.clone(), m.clone(), v.clone(), g.clone()
+    clip = hip.grad_norm_clip(g, 0.5)
+    hip.adam_step(p, g, m, v, 1.25e-6, 0.9, 0.99, 1e-8, 4, 0.01, clip)
+    hip.adam_step(p2, g2, m2, v2, 1.25e-6, 0.9, 0.99, 1e-8, 4, 0.01, clip, zero_grad=True)
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert float(g2.abs().max()) == 0.0 and float(g.abs().max()) > 0.0
 
 
 # ---------------------------------------------------------------- batched weight-shadow refresh (csrc/shadow.hip)
