@@ -761,8 +761,8 @@ class PatchEmbedFn(Function):
         dz = be.layernorm_bwd(dy.contiguous(), z, g2.detach(), mean, rstd, dg2, db2)
         dbp = torch.zeros(N, dtype=torch.float32, device=dz.device)
         be.colsum(dz, dbp)
-        G = torch.zeros((N, K), dtype=torch.float32, device=dz.device)
-        be.gemm(dz, xhat[:, :K], a_kc=False, b_kc=False, out=G, accumulate=True,
+        G = torch.empty((N, K), dtype=torch.float32, device=dz.device)       # (overwritten: no 8-MB fill in front of the GEMM)
+        be.gemm(dz, xhat[:, :K], a_kc=False, b_kc=False, out=G, accumulate=False,
                 split_k=0, M=N, N=K, K=dz.shape[0])
         # parameter-space epilogue (N x K elementwise + two column reductions, one launch): straight into the flat gradient buffer
         def sink_or_zeros(param):
