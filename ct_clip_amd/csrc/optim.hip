@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   // ADAM_U float4 groups per thread and trip, all 4 * ADAM_U 16-byte loads issued before the first use, non-temporal both ways: 28 bytes per
   // parameter stream through once (7.95 GB for CT-CLIP's 284 M parameters) and nothing of it is read again before the next step.
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  constexpr int ADAM_U = 4;
+#ifndef ADAM_UNROLL
+#define ADAM_UNROLL 4
+#endif
+  constexpr int ADAM_U = ADAM_UNROLL;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += ADAM_U * stride) {
     int64_t idx[ADAM_U];
     f32x4 pv[ADAM_U], mv[ADAM_U], vv[ADAM_U], gv[ADAM_U];
@@ -80,7 +83,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p) + i);
       __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m) + i);
       __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v) + i);
-      if (ZERO_G) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g) + i);
+#ifndef ADAM_ZERO_NT
+#define ADAM_ZERO_NT 1      // 1 = the zeros bypass the caches like the three state streams; 0 = ordinary stores (A/B: profiles/r05_ab_experiments.md)
+#endif
+      if (ZERO_G) {
+        if (ADAM_ZERO_NT) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g) + i);
+        else reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   if (blockIdx.x == 0)
