@@ -427,7 +427,7 @@ def finetune_bench(args, device, dtype, world, rank):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_finetune_cpu_bounded(args)
-        print(json.dumps(out), flush=True)
+        emit_line(out)
 
 
 def finetune_cpu_worker(args):
@@ -518,6 +518,18 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+_LINE_FD = None
+
+
+def emit_line(obj):
+    """The contract line: to the process's ORIGINAL stdout (see main())."""
+    data = (json.dumps(obj) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,9 +594,17 @@ def main():
         gemm_probe(args.gemm_probe)
         return
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout when its first communicator comes up
+    # (seen on the MI355X box: "RCCL version : 2.26.6 ... Librccl path : ..."), and a library may do the same tomorrow: from here on file descriptor 1
+    # is the process's stderr, and the line is written to the saved descriptor by emit_line().  (The worker modes above keep their stdout:
+    # their parent reads it through a pipe, and the self-launching parent hands its stdout to the ranks.)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (rank 0 prints the line)
         sys.exit(self_launch(args.gpus))
+    global _LINE_FD
+    sys.stdout.flush()
+    _LINE_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -596,7 +616,15 @@ def main():
         local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    # CTCLIP_DIST_SINGLE_RANK=1 with --gpus 1: a process group of ONE rank, under which the data-parallel branches are taken and every collective
+    # is issued (each the identity) -- RCCL's kernels, the communication stream and the `comm` diagnostics on a 1-GPU box; NOT the headline run
+    single_rank_dp = world == 1 and os.environ.get("CTCLIP_DIST_SINGLE_RANK", "") == "1"
+    if single_rank_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if (world > 1 or single_rank_dp) and not dist.is_initialized():
         if backend_name == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -687,7 +715,7 @@ def main():
                 graphed.close()
                 graphed, step = None, eager_step
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or single_rank_dp:
             dist.barrier()
             trainer.reducer.start_timing()        # event pairs on the communication stream (no host synchronisation): `comm` of the JSON line
         torch.cuda.synchronize()
@@ -699,7 +727,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        run_config.comm = trainer.reducer.stop_timing() if world > 1 else None
+        run_config.comm = trainer.reducer.stop_timing() if (world > 1 or single_rank_dp) else None
         run_config.graphed = graphed is not None
         if graphed is not None:
             graphed.close()
@@ -760,10 +788,14 @@ def main():
         "mfma_fraction_whole_step": round(train_flops * args.batch / (ms / 1e3) / 2.5e15, 4),
         "peak_mem_gib": round(peak_mem, 1),
     }
+    from ct_clip_amd import streams as _streams
+    out["side_streams"] = _streams.report()      # how each side stream was found (probed for running beside the default stream: ct_clip_amd/streams.py)
     if getattr(run_config, "comm", None):
         # rank 0's view of the gradient all-reduce: how long the buckets occupied the communication stream and how much of that the compute
         # stream had to WAIT for at the end of backward (the rest was hidden under backward); diagnoses the first multi-GPU run
         out["comm"] = dict(run_config.comm, backend=dist.get_backend(), vq_stats="fused buffer on the communication stream, EMA applied at finish()")
+        if single_rank_dp:
+            out["comm"]["note"] = "ONE rank (CTCLIP_DIST_SINGLE_RANK=1): every collective issued, each the identity -- stream plumbing and RCCL launch cost, no xGMI traffic"
     if timing:
         timing["traffic"] = None
         if rank == 0 and world == 1 and not args.no_pmc:
@@ -833,8 +865,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline_bounded(args, sdepth, tdepth)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit_line(out)
+    if world > 1 or single_rank_dp:
         dist.barrier()
         dist.destroy_process_group()
 

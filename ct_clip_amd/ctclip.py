@@ -181,7 +181,7 @@ class CTCLIP(nn.Module):
             return Fn.LatentSimilarityFn.apply(text_lat, image_lat, self.temperature)
         assert Bt == Bi, "contrastive loss needs as many texts as volumes"
         replicas = 1
-        if self.gather_negatives and _dist.world_size() > 1:
+        if self.gather_negatives and _dist.collectives_on():
             text_lat, image_lat = _dist.all_gather_latents(text_lat, image_lat)
             replicas = _dist.world_size()
         return Fn.ClipLossFn.apply(text_lat, image_lat, self.temperature, replicas)

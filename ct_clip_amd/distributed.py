@@ -10,6 +10,8 @@ over xGMI on ROCm; "gloo" in the CPU tests).
   (xGMI is 7 point-to-point links per GPU: few, large messages).
 * ``sync_vq_stats``: all-reduce(SUM) of the VQ EMA statistics so every rank applies the global-batch codebook update.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,6 +26,13 @@ def world_size():
 
 def rank():
     return dist.get_rank() if is_on() else 0
+
+
+def collectives_on():
+    """True when this process takes the data-parallel branches: a process group of more than one rank -- or of ONE rank with
+    CTCLIP_DIST_SINGLE_RANK=1, where every collective is the identity but is still issued (how the RCCL branch of GradReducer / VqStatSync /
+    the latent all-gather is executed on a 1-GPU box: tests/test_ddp_gpu.py)."""
+    return is_on() and (dist.get_world_size() > 1 or os.environ.get("CTCLIP_DIST_SINGLE_RANK", "") == "1")
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -58,7 +67,7 @@ def _fused_stats(bins, esum):
 
 def sync_vq_stats(bins, esum, *_):
     """Immediate form (VqFn.stat_sync hook): all-reduce(SUM) in place on the caller's stream, the EMA update follows in the forward."""
-    if world_size() > 1:
+    if collectives_on():
         flat = _fused_stats(bins, esum)
         if flat is not None:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -87,7 +96,7 @@ class VqStatSync:
             self.flush()
 
     def __call__(self, bins, esum, cluster_size, embed, decay):
-        if world_size() == 1:
+        if not collectives_on():
             return False
         self.before_forward(embed)
         flat = _fused_stats(bins, esum)
@@ -141,7 +150,13 @@ class GradReducer:
         self.op, self.comm_dtype, self.overlap = op, comm_dtype, overlap
         self.min_elems = max(1, min_bucket_bytes // 4)
         self.max_elems = max(1, max_bucket_bytes // 4)
-        self.comm_stream = torch.cuda.Stream(device=self.flat.device) if self.flat.is_cuda else None
+        self.comm_stream = None
+        if self.flat.is_cuda:
+            # hardware queues are handed out in the order of asking (streams.py): the streams that carry kernels first, then this one, whose
+            # event waits must not sit in the main stream's queue
+            from . import functional as Fn, streams
+            Fn.reserve_side_streams(self.flat.device)
+            self.comm_stream = streams.concurrent_stream(self.flat.device, "comm")
         self.stage = torch.empty(self.flat.numel(), dtype=comm_dtype, device=self.flat.device) if comm_dtype != torch.float32 else None
         self.ranges = {}          # tag key -> (start, end)
         self.pending = []         # ready, not yet launched: sorted list of [start, end)
@@ -194,7 +209,7 @@ class GradReducer:
         self.register(("bert_embeddings", id(emb.word_embeddings.weight)), emb.parameters())
         self.register(model.to_text_latent, model.to_text_latent.parameters())
         self.register(model.to_visual_latent, model.to_visual_latent.parameters())
-        if world_size() > 1 and self.overlap:
+        if collectives_on() and self.overlap:
             self._prev_hook = Fn.set_grad_ready_hook(self.ready)
             self._hooked = True
         return self
@@ -218,7 +233,7 @@ class GradReducer:
 
     def ready(self, tag):
         r = self.ranges.get(self._key(tag))
-        if r is None or world_size() == 1:
+        if r is None or not collectives_on():
             return
         a, b = r
         # the events travel WITH the segment: a segment announced on stream A and merged into a run launched from a notification on
@@ -263,10 +278,16 @@ class GradReducer:
     def _reduce_slice(self, s, e):
         piece = self.flat[s:e]
         if self.stage is None:
+            if dist.get_backend() == "nccl" and os.environ.get("CTCLIP_NCCL_ASYNC", "0") != "1":
+                # RCCL, synchronous form: the collective is launched ON the communication stream (the current stream here) and is ordered like
+                # any kernel of it -- the host does not block.  The asynchronous form + wait() goes through the process group's internal
+                # stream: one more stream competing for four hardware queues (streams.py) and two event hops per bucket.
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                return
             w = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=self.comm_stream is not None)
             if w is not None and self.comm_stream is not None:
                 if dist.get_backend() == "nccl":
-                    w.wait()              # RCCL: stream-ordered (the COMMUNICATION stream waits for the collective; the host does not block)
+                    w.wait()              # stream-ordered (the communication stream waits for the internal stream; the host does not block)
                 else:
                     self.works.append(w)  # gloo: wait() blocks the host -- deferred to finish() so that backward keeps being enqueued
             return
@@ -280,7 +301,7 @@ class GradReducer:
     def finish(self):
         """Reduce every range not yet reduced this step, then make the compute stream wait for the communication stream."""
         W = world_size()
-        if W == 1:
+        if not collectives_on():
             return
         self.vq_sync.flush()            # (joins the communication stream for the statistics' all-reduce, then the EMA update on the compute stream)
         if self.comm_stream is not None:

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from . import backend as _be
+from . import streams as _streams
 
 
 def B():
@@ -225,8 +226,17 @@ def shared_side_stream(device, name):
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), name)
     st = _SHARED_STREAMS.get(key)
     if st is None:
-        st = _SHARED_STREAMS[key] = register_side_stream(torch.cuda.Stream(device=device))
+        # (round 5) ... and the stream is PROBED for running beside the default stream: see streams.py
+        st = _SHARED_STREAMS[key] = register_side_stream(_streams.concurrent_stream(device, name))
     return st
+
+
+def reserve_side_streams(device):
+    """Create the streams that carry kernels (text tower, weight gradients) NOW: hardware queues are handed out in the order of asking, and
+    whoever sets up a communication stream should ask after these."""
+    if torch.device(device).type == "cuda":
+        shared_side_stream(device, "text")
+        _wgrad_stream(torch.device(device))
 
 
 def join_side_streams():
@@ -253,9 +263,14 @@ def _wgrad_side(t):
     dev = t.device
     if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
         return None            # the text tower's backward already runs on its own side stream
-    st = _WG["streams"].get(dev.index)
+    return _wgrad_stream(dev)
+
+
+def _wgrad_stream(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _WG["streams"].get(idx)
     if st is None:
-        st = _WG["streams"][dev.index] = torch.cuda.Stream(device=dev)
+        st = _WG["streams"][idx] = _streams.concurrent_stream(dev, "wgrad")
     return st
 
 

@@ -68,7 +68,8 @@ class VolumeUploader:
 
     def __init__(self, device=None, max_voxels=512 * 512 * 640, slots=2, target_shape=TARGET_SHAPE):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.Stream(self.device)
+        from . import streams
+        self.stream = streams.concurrent_stream(self.device, "h2d")      # (one copy stream per device and process, probed: streams.py)
         self.target_shape = target_shape
         self.max_voxels = int(max_voxels)
         self._host = [torch.empty(self.max_voxels, dtype=torch.int16).pin_memory() for _ in range(slots)]

@@ -1,0 +1,118 @@
+"""Side streams that really run beside the main stream.
+
+HIP multiplexes a process's streams onto a handful of hardware queues (4 by default); two streams that land on the same queue are served in
+order -- a kernel, or an event wait, of one holds back the other.  Which queue a new `torch.cuda.Stream` gets depends on everything the process
+created before it: measured on the MI355X box (`profiles/r05_stream_queues.md`), the text tower's stream sat on its own queue in a
+single-process run and on the MAIN stream's queue as soon as a process group existed (RCCL's streams and the communication stream came
+first): the text tower then ran serialised behind the image tower and the step was 5.5 ms longer, with not one kernel added.
+
+There is no API that names a stream's queue, so the streams handed out here are PROBED: a candidate is accepted when a small kernel launched
+on it completes while a long-running single-thread spin kernel occupies the default stream and every side stream handed out before.  A few
+milliseconds once per purpose and device.  `CTCLIP_STREAM_PROBE=0` returns the first stream torch offers (the behaviour up to round 4).
+
+Order matters when the queues run out: ask for the streams that carry kernels first (text tower, weight gradients), for the communication
+stream last."""
+import os
+
+import torch
+
+_TAKEN = {}        # device index -> [default stream, side streams handed out so far]
+_BY_PURPOSE = {}   # (device index, purpose) -> stream
+_REPORT = {}       # (device index, purpose) -> dict(tries=..., concurrent_with_default=..., concurrent_with_all=...)
+_SCRATCH = {}
+_CYCLES = {}
+MAX_TRIES = 24     # torch's pool has 32 streams per device and priority
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def _scratch(idx):
+    t = _SCRATCH.get(idx)
+    if t is None:
+        t = _SCRATCH[idx] = torch.zeros(64, dtype=torch.float32, device=torch.device("cuda", idx))
+    return t
+
+
+def _spin_cycles(idx):
+    """Argument of torch.cuda._sleep for about 2 ms on this device (its clock is not specified: calibrated once)."""
+    c = _CYCLES.get(idx)
+    if c is None:
+        dev = torch.device("cuda", idx)
+        st = torch.cuda.default_stream(dev)
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1000)      # (first launch: module load)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            torch.cuda._sleep(200_000)
+            b.record(st)
+        b.synchronize()
+        ms = max(a.elapsed_time(b), 1e-3)
+        c = _CYCLES[idx] = int(min(max(200_000 * 2.0 / ms, 10_000), 400_000_000))
+    return c
+
+
+def runs_beside(cand, busy):
+    """True when a kernel on `cand` completes while every stream of `busy` (busy[0] = the reference clock) is held by a spin kernel."""
+    idx = cand.device.index
+    dev = torch.device("cuda", idx)
+    x, n = _scratch(idx), _spin_cycles(idx)
+    with torch.cuda.stream(cand):
+        x.add_(1.0)      # the first launch on a new stream may create its hardware queue (milliseconds): not part of the measurement
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(busy[0])
+    ends = []
+    for s in busy:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(n)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(s)
+            ends.append(e)
+    with torch.cuda.stream(cand):
+        x.add_(1.0)
+        ec = torch.cuda.Event(enable_timing=True)
+        ec.record(cand)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(ec) < 0.5 * min(e0.elapsed_time(e) for e in ends)
+
+
+def concurrent_stream(device, purpose):
+    """The process-wide side stream for (device, purpose): created once, chosen so that it shares a hardware queue neither with the default
+    stream nor -- while queues last -- with the side streams handed out before."""
+    idx = _dev_index(device)
+    key = (idx, purpose)
+    st = _BY_PURPOSE.get(key)
+    if st is not None:
+        return st
+    dev = torch.device("cuda", idx)
+    if os.environ.get("CTCLIP_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        st = torch.cuda.Stream(device=dev)
+        _REPORT[key] = dict(tries=0, probed=False)
+    else:
+        taken = _TAKEN.setdefault(idx, [torch.cuda.default_stream(dev)])
+        tried, fallback = [], None
+        for _ in range(MAX_TRIES):
+            cand = torch.cuda.Stream(device=dev)
+            if any(cand == t for t in tried):
+                break                            # the pool wrapped around
+            tried.append(cand)
+            if runs_beside(cand, taken):
+                st = cand
+                break
+            if fallback is None and len(taken) > 1 and runs_beside(cand, taken[:1]):
+                fallback = cand                  # at least not on the main stream's queue
+        _REPORT[key] = dict(tries=len(tried), probed=True, concurrent_with_all=st is not None,
+                            concurrent_with_default=st is not None or fallback is not None)
+        if st is None:
+            st = fallback if fallback is not None else tried[0]
+        taken.append(st)
+    _BY_PURPOSE[key] = st
+    return st
+
+
+def report():
+    """{purpose@device: how the stream was found} -- bench.py prints it with the multi-rank line."""
+    return {f"{p}@cuda:{i}": dict(v) for (i, p), v in _REPORT.items()}

@@ -111,7 +111,8 @@ class FusedAdam:
             return
         dev = self.flat_grad.device
         if getattr(self, "_zero_stream", None) is None:
-            self._zero_stream = torch.cuda.Stream(device=dev)
+            from . import streams
+            self._zero_stream = streams.concurrent_stream(dev, "zero_grad")
         self.wait_zero()
         self._zero_stream.wait_stream(torch.cuda.current_stream(dev))      # behind Adam (which reads the gradients) and the shadow refresh
         with torch.cuda.stream(self._zero_stream):

@@ -60,7 +60,8 @@ def _worker(rank, world, port, backend_name, single_device, name, out, comm, dty
     if rank == 0:
         grads = {n: p.grad.detach().float().cpu() for n, p in hot_path_parameters(clip)}
         vq = {k: v.cpu() for k, v in clip.state_dict().items() if "vq._codebook" in k}
-        torch.save(dict(loss=loss.detach().cpu(), grads=grads, vq=vq, launches=len(log)), out)
+        torch.save(dict(loss=loss.detach().cpu(), grads=grads, vq=vq, launches=len(log), backend=dist.get_backend(),
+                        vq_collectives=trainer.reducer.vq_sync.calls), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,6 +100,21 @@ def test_four_ranks_one_device_gloo_match_golden(golden, tmp_path):
     _check(golden, torch.load(out, weights_only=False), "tiny4", "f32")
 
 
+@pytest.mark.parametrize("comm", ["f32", "bf16"])
+def test_one_rank_nccl_issues_every_collective_and_matches_golden(golden, tmp_path, monkeypatch, comm):
+    """The RCCL branch on the 1-GPU box: a process group of ONE rank through backend "nccl" with CTCLIP_DIST_SINGLE_RANK=1, under which the
+    data-parallel branches are taken although every collective is the identity -- RCCL's all_reduce kernels run on the communication stream
+    (stream-ordered wait, record_stream, per-segment events, the staged bf16 wire format), the latent all-gather and its backward slice run
+    on the compute stream, the quantiser's statistics go through the deferred fused all-reduce -- and the step must still be the single-process
+    golden step.  (What it cannot show is xGMI traffic: that needs the driver's multi-GPU run.)"""
+    monkeypatch.setenv("CTCLIP_DIST_SINGLE_RANK", "1")
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(1, _free_port(), "nccl", True, "tiny", out, comm, "f32"), nprocs=1, join=True)
+    res = torch.load(out, weights_only=False)
+    assert res["backend"] == "nccl" and res["vq_collectives"] >= 1
+    _check(golden, res, "tiny", comm)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 4, reason="needs four GPUs (RCCL over xGMI)")
 def test_four_ranks_four_devices_nccl_match_golden(golden, tmp_path):
     out = str(tmp_path / "rank0.pt")
@@ -117,8 +133,8 @@ def test_two_ranks_two_devices_nccl_match_golden(golden, tmp_path, comm):
 def _bench_line(args, env, cwd):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env, cwd=cwd)
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}"
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"the contract: ONE JSON line and nothing else on stdout, got {lines[:6]}"
     return json.loads(lines[0])
 
 
@@ -135,6 +151,21 @@ def test_bench_self_launches_without_a_launcher(tmp_path):
     assert abs(rec["loss"] - 1.386) < 0.2          # ln 4 for random towers: the loss saw the gathered batch
     c = rec["comm"]                                # per-step communication diagnostics of the N > 1 line
     assert c["collectives_per_step"] >= 1 and c["MB_per_step"] > 100 and c["comm_stream_busy_ms_per_step"] > 0 and c["exposed_wait_ms_per_step"] >= 0
+
+
+def test_bench_single_rank_rccl_line_is_alone_on_stdout(tmp_path):
+    """bench.py with a ONE-rank "nccl" process group (CTCLIP_DIST_SINGLE_RANK=1): RCCL comes up on the 1-GPU box -- it prints a version banner
+    on C stdout, which must not reach the process's stdout next to the contract line -- and the `comm` diagnostics are filled from the
+    communication stream's events."""
+    env = dict(os.environ, CTCLIP_DIST_SINGLE_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(_free_port())
+    rec = _bench_line(["--steps", "2", "--warmup", "1", "--batch", "2", "--spatial-depth", "1", "--temporal-depth", "1", "--no-attn-block",
+                       "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc", "--no-reference-depth", "--no-text512"], env, str(tmp_path))
+    c = rec["comm"]
+    assert rec["n_gpus"] == 1 and c["backend"] == "nccl" and c["collectives_per_step"] >= 1 and c["MB_per_step"] > 100
+    assert abs(rec["loss"] - 0.693) < 0.2          # ln 2 for random towers at batch 2
 
 
 @pytest.mark.parametrize("workload,cfgi", [("lipro", 4), ("vocabfine", 3)])

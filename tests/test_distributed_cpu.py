@@ -71,12 +71,15 @@ def _worker(rank, world, port, name, out, mode="overlap", vq_mode="deferred", bu
     ("tiny4", 4, "overlap", "deferred", 1),          # one sample per rank at W = 4: rank slices of the gathered latents, 4-way sums
     ("tiny4", 4, "overlap", "immediate", 2000000),   # buckets of >= 2 MB: neighbouring blocks coalesce before they are launched
     ("tiny4", 2, "serial", "deferred", 1),           # two samples per rank
+    ("tiny", 1, "overlap", "deferred", 1),           # ONE rank with CTCLIP_DIST_SINGLE_RANK=1: every collective issued, each the identity
 ])
-def test_ranks_match_single_process_global_batch(golden, tmp_path, name, world, mode, vq_mode, bucket_bytes):
+def test_ranks_match_single_process_global_batch(golden, tmp_path, monkeypatch, name, world, mode, vq_mode, bucket_bytes):
     """overlap: the all-reduce of a layer's gradients is launched from inside backward as soon as they are final; serial: one
     reduction after backward.  Both must give the single-process global-batch gradients (bf16 buckets: to bf16 rounding)."""
     from tests.helpers import check_grad
     out = str(tmp_path / "rank0.pt")
+    if world == 1:      # (the switch tests/test_ddp_gpu.py uses to run the RCCL branch on a 1-GPU box)
+        monkeypatch.setenv("CTCLIP_DIST_SINGLE_RANK", "1")
     mp.spawn(_worker, args=(world, _free_port(), name, out, mode, vq_mode, bucket_bytes), nprocs=world, join=True)
     res = torch.load(out, weights_only=False)
     g = golden(name)
