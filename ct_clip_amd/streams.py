@@ -88,8 +88,8 @@ def concurrent_stream(device, purpose):
     if st is not None:
         return st
     dev = torch.device("cuda", idx)
-    if os.environ.get("CTCLIP_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing():
-        st = torch.cuda.Stream(device=dev)
+    if os.environ.get("CTCLIP_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
+        st = torch.cuda.Stream(device=dev)      # (no spin kernel in this torch build / inside a graph capture: no way to probe)
         _REPORT[key] = dict(tries=0, probed=False)
     else:
         taken = _TAKEN.setdefault(idx, [torch.cuda.default_stream(dev)])
