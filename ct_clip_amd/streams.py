@@ -113,6 +113,15 @@ def concurrent_stream(device, purpose):
     return st
 
 
+def forget(device, purpose):
+    """Hand a purpose's stream back (tests): it no longer counts as occupied when later streams are probed."""
+    idx = _dev_index(device)
+    st = _BY_PURPOSE.pop((idx, purpose), None)
+    _REPORT.pop((idx, purpose), None)
+    if st is not None and idx in _TAKEN:
+        _TAKEN[idx] = [t for t in _TAKEN[idx] if t is not st]
+
+
 def report():
     """{purpose@device: how the stream was found} -- bench.py prints it with the multi-rank line."""
     return {f"{p}@cuda:{i}": dict(v) for (i, p), v in _REPORT.items()}

@@ -23,6 +23,10 @@ def test_side_streams_run_beside_the_default_stream():
         y = x * 2
     torch.cuda.current_stream(dev).wait_stream(a)
     assert float(y.sum()) == 2.0 * (1 << 20)
+    streams.forget(dev, "test_a")
+    streams.forget(dev, "test_b")
+    assert "test_a@cuda:0" not in streams.report() and streams.concurrent_stream(dev, "test_a") is not None
+    streams.forget(dev, "test_a")
 
 
 def test_the_models_streams_are_probed():
