@@ -50,7 +50,7 @@ def _spin_cycles(idx):
             b.record(st)
         b.synchronize()
         ms = max(a.elapsed_time(b), 1e-3)
-        c = _CYCLES[idx] = int(min(max(200_000 * 2.0 / ms, 10_000), 400_000_000))
+        c = _CYCLES[idx] = int(min(max(200_000 * 2.0 / ms, 10_000), 10_000_000))      # (bounded: a mis-timed calibration must not turn into seconds of spinning)
     return c
 
 
