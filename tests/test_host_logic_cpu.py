@@ -477,3 +477,48 @@ def test_linear_backward_fused_weight_and_bias_gradient(ref_backend):
         assert w2.grad is None and b2.grad is None
         torch.testing.assert_close(w2._ctclip_grad_sink, 1 + gb.t() @ xb, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(b2._ctclip_grad_sink, 1 + gb.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_side_stream_selection_logic(monkeypatch):
+    """ct_clip_amd/streams.py without a device: candidates that share a queue with an occupied stream are skipped; when the queues run out the
+    stream that at least stays off the DEFAULT stream's queue is taken; one stream per purpose; forget() frees it."""
+    from ct_clip_amd import streams
+
+    class FakeStream:
+        n = 0
+
+        def __init__(self, device=None):
+            FakeStream.n += 1
+            self.id = FakeStream.n
+            self.queue = self.id % 3          # three "hardware queues": 0 = the default stream's
+
+        def __eq__(self, other):
+            return isinstance(other, FakeStream) and other.id == self.id
+
+        __hash__ = object.__hash__
+
+    default = FakeStream()
+    default.queue = 0
+    monkeypatch.setattr(streams, "_TAKEN", {})
+    monkeypatch.setattr(streams, "_BY_PURPOSE", {})
+    monkeypatch.setattr(streams, "_REPORT", {})
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "default_stream", lambda dev=None: default)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(streams, "runs_beside", lambda cand, busy: all(cand.queue != b.queue for b in busy))
+    monkeypatch.delenv("CTCLIP_STREAM_PROBE", raising=False)
+    a = streams.concurrent_stream("cuda:0", "text")
+    b = streams.concurrent_stream("cuda:0", "wgrad")
+    assert a.queue != 0 and b.queue != 0 and a.queue != b.queue
+    assert streams.concurrent_stream("cuda:0", "text") is a
+    c = streams.concurrent_stream("cuda:0", "comm")          # no queue left: shares one, but never the default stream's
+    rep = streams.report()
+    assert c.queue != 0 and rep["comm@cuda:0"]["concurrent_with_all"] is False and rep["comm@cuda:0"]["concurrent_with_default"] is True
+    assert rep["text@cuda:0"]["concurrent_with_all"] and rep["wgrad@cuda:0"]["concurrent_with_all"]
+    streams.forget("cuda:0", "wgrad")
+    d = streams.concurrent_stream("cuda:0", "wgrad2")        # the freed queue is found again
+    assert d.queue == b.queue and streams.report()["wgrad2@cuda:0"]["concurrent_with_all"]
+    monkeypatch.setenv("CTCLIP_STREAM_PROBE", "0")
+    e = streams.concurrent_stream("cuda:0", "unprobed")
+    assert streams.report()["unprobed@cuda:0"] == dict(tries=0, probed=False) and e is not None
