@@ -67,7 +67,7 @@ def main():
         with gzip.open(sys.argv[3], "wt") as f:
             f.write("name,queue,stream,start_us,dur_us\n")
             for r in step:
-                f.write(f"{r[4]},{r[2]},{r[3]},{(r[0] - t0) / 1e3:.1f},{(r[1] - r[0]) / 1e3:.1f}\n")
+                f.write(f"\"{r[4]}\",{r[2]},{r[3]},{(r[0] - t0) / 1e3:.1f},{(r[1] - r[0]) / 1e3:.1f}\n")      # (kernel names contain commas)
 
 
 if __name__ == "__main__":
