@@ -360,7 +360,7 @@ def finetune_setup(args, device, dtype, rank):
         what = (f"CT-LiPro / ClassFine step (ct_lipro_train.py:92-107): frozen CTViT {args.image}x{args.image}x{args.frames} "
                 f"{args.spatial_depth}+{args.temporal_depth} layers in train mode (VQ EMA on) -> image latents -> ReLU/Dropout(0.3)/Linear(512,18), "
                 f"BCEWithLogits(pos_weight), clip 1.0, AdamW on the 9 234 head parameters; batch {args.batch}/GPU; text tower skipped")
-        return step, args.batch, what
+        return step, args.batch, what, trainer
     clip = build_towers(args, device, dtype, args.bert_dropout)
     clip.train()
     npath = len(FT.PATHOLOGIES)
@@ -379,18 +379,20 @@ def finetune_setup(args, device, dtype, rank):
             + ("the reference's loop literally: 18 full CTCLIP forwards, 3 backwards" if args.vocabfine_literal else
                "same numbers from ONE pass of each tower per volume (the 18 forwards share weights and volume: image transformer once, 36 prompts as one "
                "BERT batch, the quantiser's EMA sequence + pooling + latents re-applied per pathology, one backward of the summed group losses)"))
-    return step, 1, what
+    return step, 1, what, trainer
 
 
 def finetune_bench(args, device, dtype, world, rank):
     from ct_clip_amd import backend
     be = backend.get()
-    step, units, what = finetune_setup(args, device, dtype, rank)
+    step, units, what, trainer = finetune_setup(args, device, dtype, rank)
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if trainer.reducer is not None:
+        trainer.reducer.start_timing()            # the trainers of ct_clip_amd/finetune.py all-reduce (mean) their gradients when a process group is up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -400,6 +402,7 @@ def finetune_bench(args, device, dtype, world, rank):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm = trainer.reducer.stop_timing() if trainer.reducer is not None else None
     timing = None
     if args.profile_steps > 0:
         be.start_gemm_timing()
@@ -419,9 +422,13 @@ def finetune_bench(args, device, dtype, world, rank):
            "config": {"workload": what, "global_batch": world * units, "text_len": args.text_len, "parallelism": f"dp{world}",
                       "layers": f"{args.spatial_depth}+{args.temporal_depth}"},
            "loss": round(float(loss), 5), "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}
-    if world > 1:
-        out["config"]["note"] = ("every rank runs its own volumes; the head / model replicas are NOT gradient-synchronised in this workload line "
-                                 "(the reference uses nn.DataParallel here): throughput of independent replicas")
+    if trainer.reducer is not None:
+        out["config"]["note"] = ("one process per GPU, every rank on its own volumes; the trainable parameters' gradients are all-reduced (mean) before the clip "
+                                 "and the AdamW step and the quantiser's EMA statistics are all-reduced (sum) -- the reference's nn.DataParallel "
+                                 "(ct_lipro_train.py:75, ct_vocabfine_train.py:62) as data-parallel ranks")
+        if comm:
+            out["comm"] = dict(comm, backend=dist.get_backend(), op="mean",
+                               reduced=("the 9 234 head parameters (one collective)" if args.workload == "lipro" else "every trainable parameter, bucketed under backward"))
     if timing:
         out["roofline"] = timing
     if rank == 0:
@@ -552,6 +559,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc companion passes that measure roofline.traffic")
     ap.add_argument("--no-attn-block", action="store_true", help="skip the attention-block MFMA utilisation measurement")
     ap.add_argument("--profile-steps", type=int, default=10, help="extra steps after the timed region in which every GEMM launch is event-timed (roofline)")
+    ap.add_argument("--comm-sweep-steps", type=int, default=3, help="N > 1: steps per row of the wire-format x bucket-size sweep printed as `comm_sweep` (0 = off)")
     ap.add_argument("--gemm-probe", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-reference-depth", action="store_true", help=argparse.SUPPRESS)      # (default on since round 3; kept for old command lines)
@@ -728,6 +736,35 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         run_config.comm = trainer.reducer.stop_timing() if (world > 1 or single_rank_dp) else None
+        run_config.comm_sweep = None
+        if (world > 1 or single_rank_dp) and profile_gemm and args.comm_sweep_steps > 0 and graphed is None:
+            # The first multi-GPU record must be able to DECIDE the reducer's defaults: the same step re-timed, back to back in this process, with
+            # f32 and bf16 buckets at two bucket thresholds (the timed region above ran the first row's settings unless overridden by the
+            # environment).  Per row: one untimed step, then `--comm-sweep-steps` steps between barriers, MAX over ranks.
+            sweep = []
+            red = trainer.reducer
+            default = (red.comm_dtype, red.min_elems * 4)
+            for wire, bucket in ((torch.float32, 16 << 20), (torch.bfloat16, 16 << 20), (torch.float32, 64 << 20), (torch.bfloat16, 64 << 20)):
+                red.reconfigure(wire, bucket)
+                step()
+                torch.cuda.synchronize()
+                dist.barrier()
+                red.start_timing()
+                torch.cuda.synchronize()
+                s0 = time.perf_counter()
+                for _ in range(args.comm_sweep_steps):
+                    step()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                ts = torch.tensor([time.perf_counter() - s0], device=device, dtype=torch.float64)
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                row = red.stop_timing() or {}
+                row["ms_per_step"] = round(float(ts[0]) / args.comm_sweep_steps * 1e3, 3)
+                row["steps"] = args.comm_sweep_steps
+                sweep.append(row)
+            red.reconfigure(*default)
+            run_config.comm_sweep = sweep
         run_config.graphed = graphed is not None
         if graphed is not None:
             graphed.close()
@@ -796,6 +833,8 @@ def main():
         out["comm"] = dict(run_config.comm, backend=dist.get_backend(), vq_stats="fused buffer on the communication stream, EMA applied at finish()")
         if single_rank_dp:
             out["comm"]["note"] = "ONE rank (CTCLIP_DIST_SINGLE_RANK=1): every collective issued, each the identity -- stream plumbing and RCCL launch cost, no xGMI traffic"
+        if getattr(run_config, "comm_sweep", None):
+            out["comm_sweep"] = run_config.comm_sweep
     if timing:
         timing["traffic"] = None
         if rank == 0 and world == 1 and not args.no_pmc:

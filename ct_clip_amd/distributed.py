@@ -166,6 +166,17 @@ class GradReducer:
         self.timing = None        # start_timing(): [(event before, event after)] per collective on the communication stream + exposed waits
         self.vq_sync = VqStatSync(self.comm_stream)      # the quantiser's EMA statistics ride the same communication stream (install it as VqFn.stat_sync)
 
+    def reconfigure(self, comm_dtype=None, min_bucket_bytes=None):
+        """Change the wire format and / or the bucket threshold between steps (bench.py's sweep: the first multi-GPU record decides the
+        defaults from ONE invocation).  Must be called on every rank with the same arguments, outside a step."""
+        assert not self.pending and not self.launched, "reconfigure between steps, not inside one"
+        if comm_dtype is not None and comm_dtype != self.comm_dtype:
+            self.comm_dtype = comm_dtype
+            self.stage = torch.empty(self.flat.numel(), dtype=comm_dtype, device=self.flat.device) if comm_dtype != torch.float32 else None
+        if min_bucket_bytes is not None:
+            self.min_elems = max(1, min_bucket_bytes // 4)
+        return self
+
     # ---- diagnostics: where does the step's communication time go?  (bench.py --gpus N prints it with the throughput line)
     def start_timing(self):
         self.timing = dict(coll=[], exposed=[], bytes=0, steps=0)

@@ -11,16 +11,78 @@
   volume.  Every parameter trains ("Fine-tuning end-to-end", ct_vocabfine_train.py:44-51).
 
 The heads run on HIP kernels (csrc/finetune.hip) behind the same C ABI as the rest of the path.
+
+Data parallelism (BASELINE.json configs[3] "8 GPUs", configs[4] "grad all-reduce only").  The reference scripts wrap the model in
+``nn.DataParallel`` (ct_lipro_train.py:75, ct_vocabfine_train.py:62): ONE process scatters the batch over the visible GPUs, gathers the
+outputs, evaluates the loss on the gathered batch and sums the replicas' gradients into the master parameters -- the gradient of the
+GLOBAL-batch loss.  Here it is one process per GPU (``torch.distributed``, RCCL): every rank evaluates the mean loss of ITS shard, and the
+trainers all-reduce the flat gradient buffer with op = mean (equal shards: mean of the shard gradients = gradient of the global-batch mean
+loss) before the clip and the AdamW step -- 9 234 head parameters for LiPro (one 37-KB collective), every parameter for VocabFine
+(bucketed on the communication stream under backward, like the main trainer).  The vector quantiser runs in train mode in both loops
+(``model.train()``, ct_lipro_train.py:76): its EMA statistics are all-reduced (SUM) as in the main trainer so that every rank applies the
+global-batch codebook update and the replicas' codebooks stay identical (under nn.DataParallel only replica 0's buffer update survives
+the next scatter; a one-process run on the global batch -- the parity oracle of SURVEY.md section 8(e) -- sees the whole batch).
+``data_parallel_loader`` shards a dataset across the ranks with a DistributedSampler.
 """
 import math
+import os
 
 import torch
 from torch import nn
 from torch.autograd import Function
 
 from . import backend as _be
+from . import distributed as _dist
 from . import functional as Fn
 from .trainer import FusedAdam
+
+
+def data_parallel_loader(dataset, batch_size, shuffle=True, seed=0, num_workers=0, drop_last=True):
+    """-> (DataLoader, sampler or None): with a process group of W > 1 ranks every rank draws a disjoint 1/W of each epoch's permutation
+    (call ``sampler.set_epoch(epoch)`` per epoch); without one it is the reference's plain shuffled loader (ct_lipro_train.py:67,
+    ct_vocabfine_train.py:54).  drop_last: equal shard sizes on every rank, which is what makes mean-of-shard-gradients the global-batch
+    gradient."""
+    from torch.utils.data import DataLoader
+    sampler = None
+    if _dist.world_size() > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=_dist.world_size(), rank=_dist.rank(), shuffle=shuffle, seed=seed, drop_last=drop_last)
+    dl = DataLoader(dataset, num_workers=num_workers, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                    drop_last=drop_last)
+    return dl, sampler
+
+
+def _comm_dtype(arg):
+    if arg is not None:
+        return arg
+    env = os.environ.get("CTCLIP_GRAD_COMM_DTYPE", "").lower()
+    return torch.bfloat16 if env in ("bf16", "bfloat16") else torch.float32
+
+
+class _DataParallelMixin:
+    """Gradient all-reduce (mean) + VQ-statistic all-reduce (sum) of a fine-tuning trainer; inert without a process group."""
+    reducer = None
+
+    def _setup_data_parallel(self, optim, model=None, comm_dtype=None, bucket_bytes=16 << 20, overlap=True, sync_vq=True):
+        if not _dist.collectives_on():
+            return
+        self.reducer = _dist.GradReducer(optim, op="mean", comm_dtype=_comm_dtype(comm_dtype), min_bucket_bytes=bucket_bytes, overlap=overlap)
+        if model is not None:
+            self.reducer.install(model)        # per-layer buckets announced from inside backward (VocabFine: every parameter trains)
+        if sync_vq:
+            Fn.VqFn.stat_sync = staticmethod(self.reducer.vq_sync)
+
+    def _finish_data_parallel(self):
+        if self.reducer is not None:
+            self.reducer.finish()              # remaining buckets, join the communication stream, apply the deferred codebook update, / W
+
+    def close(self):
+        """Detach from the process-global hooks (grad-ready hook, VqFn.stat_sync) after flushing a pending codebook update."""
+        if self.reducer is not None:
+            self.reducer.uninstall()
+            self.reducer.vq_sync.flush()
+            if getattr(Fn.VqFn, "stat_sync", None) is self.reducer.vq_sync:
+                Fn.VqFn.stat_sync = None
 
 PATHOLOGIES = ['Medical material', 'Arterial wall calcification', 'Cardiomegaly', 'Pericardial effusion',
                'Coronary artery wall calcification', 'Hiatal hernia', 'Lymphadenopathy', 'Emphysema', 'Atelectasis', 'Lung nodule',
@@ -130,10 +192,12 @@ class ImageLatentsClassifier(nn.Module):
         self.load_state_dict(torch.load(file_path))
 
 
-class LiProTrainer:
-    """One optimisation step of scripts/ct_lipro_train.py:92-107 on device-resident tensors."""
+class LiProTrainer(_DataParallelMixin):
+    """One optimisation step of scripts/ct_lipro_train.py:92-107 on device-resident tensors.  In a process group every rank passes its shard
+    of the global batch (data_parallel_loader); the head's gradients are averaged over the ranks before the clip (module docstring)."""
 
-    def __init__(self, classifier, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pos_weight=None, max_grad_norm=1.0):
+    def __init__(self, classifier, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pos_weight=None, max_grad_norm=1.0,
+                 grad_comm_dtype=None, sync_vq=True):
         self.model = classifier
         dev = classifier.classifier.weight.device
         pw = LIPRO_POS_WEIGHT if pos_weight is None else pos_weight
@@ -143,6 +207,8 @@ class LiProTrainer:
         self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
         self.max_grad_norm = max_grad_norm
         self.step = 0
+        # "grad all-reduce only" (BASELINE configs[4]): the 9 234 head parameters are ONE collective after backward -- nothing to overlap with
+        self._setup_data_parallel(self.optim, None, grad_comm_dtype, overlap=False, sync_vq=sync_vq)
 
     def forward_backward(self, text_tokens, volumes, labels):
         """logits, BCEWithLogitsLoss(pos_weight), backward into the head's gradients (ct_lipro_train.py:103-105)."""
@@ -152,6 +218,7 @@ class LiProTrainer:
         loss = BceLogitsFn.apply(logits, labels.to(device=dev, dtype=torch.float32), self.pos_weight)
         self.optim.zero_grad()
         loss.backward()
+        self._finish_data_parallel()
         return loss, logits
 
     def train_step(self, text_tokens, volumes, labels):
@@ -175,11 +242,13 @@ def vocabfine_prompts(pathology, label):
     return [f"{pathology} is not present. ", f"{pathology} is present. "]
 
 
-class VocabFineTrainer:
-    """scripts/ct_vocabfine_train.py:77-123 for one volume per step.  `tokenize(list_of_two_strings)` must return an object with
-    .input_ids / .attention_mask on the model's device (the reference pads to 512 tokens)."""
+class VocabFineTrainer(_DataParallelMixin):
+    """scripts/ct_vocabfine_train.py:77-123 for one volume per step and rank.  `tokenize(list_of_two_strings)` must return an object with
+    .input_ids / .attention_mask on the model's device (the reference pads to 512 tokens).  In a process group every rank steps on its own
+    volume; the gradients of ALL parameters are averaged over the ranks in buckets launched from inside backward (module docstring)."""
 
-    def __init__(self, model, tokenize, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pathologies=None, group_size=6):
+    def __init__(self, model, tokenize, lr=1e-5, wd=0.1, warmup_length=500, total_steps=10000, pathologies=None, group_size=6,
+                 grad_comm_dtype=None, grad_bucket_bytes=16 << 20, overlap_grad_reduce=True, sync_vq=True):
         from .trainer import hot_path_parameters
         self.model, self.tokenize = model, tokenize
         self.pathologies = list(pathologies or PATHOLOGIES)
@@ -187,8 +256,21 @@ class VocabFineTrainer:
         self.optim = FusedAdam(hot_path_parameters(model), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, group_wd_params=False)
         self.scheduler = cosine_lr(self.optim, lr, warmup_length, total_steps)
         self.step = 0
+        self._setup_data_parallel(self.optim, model, grad_comm_dtype, grad_bucket_bytes, overlap_grad_reduce, sync_vq)
 
     def forward_backward(self, volume, token_pairs, fused=True):
+        # the literal loop runs one backward per group INTO THE SAME gradients: a bucket reduced from inside the first backward would be added
+        # to afterwards -- buckets are launched from inside backward only in the fused form (one backward), otherwise all at finish()
+        prev = Fn.set_grad_ready_hook(None) if (self.reducer is not None and not fused) else None
+        try:
+            losses, sims = self._forward_backward(volume, token_pairs, fused)
+        finally:
+            if prev is not None:
+                Fn.set_grad_ready_hook(prev)
+        self._finish_data_parallel()
+        return losses, sims
+
+    def _forward_backward(self, volume, token_pairs, fused=True):
         """token_pairs: one (true prompt, false prompt) token batch per pathology.  Returns (losses per group, similarities per group);
         the gradients of all groups accumulate in the parameters' .grad as in ct_vocabfine_train.py:88-121.
 

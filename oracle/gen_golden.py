@@ -31,6 +31,8 @@ CASES = {
 # BASELINE configs[0] geometry with a batch of FOUR (round 5): the global batch of the world_size-4 data-parallel tests (one sample per rank;
 # rank slices, bucket coalescing and the latent all-gather at W = 4) and of the 2-ranks x 2-samples layout
 CASES["tiny4"] = dict(CASES["tiny"], seed=5, batch=4)
+# ... and a batch of EIGHT (round 6): the global batch of the world_size-8 test -- the target machine is one node of 8 GPUs, one sample per rank
+CASES["tiny8"] = dict(CASES["tiny"], seed=6, batch=8)
 
 
 def synth_inputs(c):

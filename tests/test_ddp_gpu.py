@@ -151,6 +151,31 @@ def test_bench_self_launches_without_a_launcher(tmp_path):
     assert abs(rec["loss"] - 1.386) < 0.2          # ln 4 for random towers: the loss saw the gathered batch
     c = rec["comm"]                                # per-step communication diagnostics of the N > 1 line
     assert c["collectives_per_step"] >= 1 and c["MB_per_step"] > 100 and c["comm_stream_busy_ms_per_step"] > 0 and c["exposed_wait_ms_per_step"] >= 0
+    # one invocation decides the reducer's defaults: f32 / bf16 buckets x two bucket thresholds, re-timed back to back
+    sw = rec["comm_sweep"]
+    assert [(r["wire_dtype"], r["min_bucket_MB"]) for r in sw] == [("float32", 16.0), ("bfloat16", 16.0), ("float32", 64.0), ("bfloat16", 64.0)]
+    assert all(r["ms_per_step"] > 0 and r["collectives_per_step"] >= 1 for r in sw)
+    assert sw[1]["MB_per_step"] < 0.6 * sw[0]["MB_per_step"]
+
+
+@pytest.mark.parametrize("workload", ["lipro", "vocabfine"])
+def test_bench_finetune_workloads_synchronise_gradients_across_ranks(tmp_path, workload):
+    """`python bench.py --workload lipro|vocabfine --gpus 2` (BASELINE.json configs[4] / configs[3] are multi-GPU configurations): the ranks are
+    data-parallel -- a `comm` object with the gradient all-reduce (mean) -- not independent replicas."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env.update(CTCLIP_BENCH_BACKEND="gloo", CTCLIP_BENCH_SINGLE_DEVICE="1")
+    rec = _bench_line(["--gpus", "2", "--workload", workload, "--image", "120", "--frames", "60", "--spatial-depth", "1", "--temporal-depth", "1", "--batch", "2",
+                       "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "0", "--text-len", "32"], env, str(tmp_path))
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and "all-reduced (mean)" in rec["config"]["note"]
+    c = rec["comm"]
+    assert c["op"] == "mean" and c["collectives_per_step"] >= 1
+    if workload == "lipro":
+        assert c["collectives_per_step"] == 1 and c["MB_per_step"] < 0.1          # "grad all-reduce only": 9 234 head parameters
+    else:
+        assert c["MB_per_step"] > 100
 
 
 def test_bench_single_rank_rccl_line_is_alone_on_stdout(tmp_path):

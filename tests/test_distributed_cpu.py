@@ -1,6 +1,6 @@
-"""Data-parallel logic on CPU with the gloo backend, world_size 2 and 4: gathered-negatives loss, gradient all-reduce(SUM), VQ-statistic
+"""Data-parallel logic on CPU with the gloo backend, world_size 2, 4 and 8: gathered-negatives loss, gradient all-reduce(SUM), VQ-statistic
 all-reduce.  Parity oracle for W ranks = the single-process REAL reference on the concatenated global batch, i.e.
-exactly the golden fixture: rank r gets its contiguous slice of the tiny (B = 2) / tiny4 (B = 4) case; loss, summed gradients and VQ
+exactly the golden fixture: rank r gets its contiguous slice of the tiny (B = 2) / tiny4 (B = 4) / tiny8 (B = 8) case; loss, summed gradients and VQ
 buffers must match the golden ones."""
 import os
 import socket
@@ -72,6 +72,8 @@ def _worker(rank, world, port, name, out, mode="overlap", vq_mode="deferred", bu
     ("tiny4", 4, "overlap", "immediate", 2000000),   # buckets of >= 2 MB: neighbouring blocks coalesce before they are launched
     ("tiny4", 2, "serial", "deferred", 1),           # two samples per rank
     ("tiny", 1, "overlap", "deferred", 1),           # ONE rank with CTCLIP_DIST_SINGLE_RANK=1: every collective issued, each the identity
+    ("tiny8", 8, "overlap", "deferred", 1),          # the target machine: one node of EIGHT ranks, one sample of the B = 8 reference run each
+    ("tiny8", 8, "overlap_bf16", "deferred", 2000000),   # bf16 wire format with coalesced buckets at eight ranks (8-way sums in bf16)
 ])
 def test_ranks_match_single_process_global_batch(golden, tmp_path, monkeypatch, name, world, mode, vq_mode, bucket_bytes):
     """overlap: the all-reduce of a layer's gradients is launched from inside backward as soon as they are final; serial: one
@@ -94,12 +96,23 @@ def test_ranks_match_single_process_global_batch(golden, tmp_path, monkeypatch, 
     for k, rec in g["grads"].items():
         if rec["value"].numel() == 0 or k not in res["grads"]:
             continue
-        if mode == "overlap_bf16":
+        if mode == "overlap_bf16" and world > 4:
+            # eight bf16 addends per element: where the ranks' terms cancel (LayerNorm gains, biases) single elements lose up to ~10 % of the
+            # tensor's scale -- the price of the bf16 wire format at 8 ranks, and why f32 buckets are the default -- so the bound is per tensor
+            m = res["grads"][k] if rec["full"] else res["grads"][k].reshape(-1)[::rec["stride"]]
+            if float(rec["norm"]) < 1e-6 * float(g["grad_norm"]):      # mathematically zero (e.g. the bias behind the softmax rows): rounding noise both sides
+                continue
+            err = float((m.float().reshape(-1) - rec["value"].reshape(-1)).norm() / rec["value"].norm())
+            worst_bf16 = max(locals().get("worst_bf16", 0.0), err)
+            assert err < 8e-2, (k, err)          # measured 3.7e-2 (tiny8, gloo)
+        elif mode == "overlap_bf16":
             check_grad(rec, res["grads"][k], rtol=2e-2, atol_rel=1e-2, floor=1e-9 * float(g["grad_norm"]))
         else:
             check_grad(rec, res["grads"][k], rtol=2e-3, atol_rel=2e-4, floor=1e-9 * float(g["grad_norm"]))
         n += 1
     assert n > 40
+    if mode == "overlap_bf16" and world > 4:
+        print(f"[bf16 buckets at {world} ranks] worst relative Frobenius error of a gradient tensor: {worst_bf16:.2e}")
     for k, v in g["vq_after"].items():
         torch.testing.assert_close(res["vq"][k], v, rtol=1e-4, atol=1e-5)
 
