@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libctclip_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 # MFMA results that are post-processed by VALU (softmax) stay in VGPRs: the AGPR form costs a copy per register and tile
 FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-              "attn2_slab.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn2_bwd1.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_short.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+              "attn2_slab.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn2_bwd1.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn2_bwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_short.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():

@@ -849,8 +849,20 @@ extern "C" int ctclip_attn2_bwd_fused(const void* qh, const void* kh, const void
   float* park = (float*)w; w += a256((int64_t)pl.nwg * NW1 * 64 * 32 * 4);
   static const bool stamp = getenv("CTCLIP_BWD1_STAMPS") != nullptr;          // the last 4 KB of the workspace: phase clocks of workgroup 0
   X1 x{qinv, (bf16_t*)dq, lddq, qpart, tabadj, dtab ? dtpart : nullptr, park, pl.P, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
+  int rc;
+  if (attn2_bwd2_eligible(nseq, H, L, bias_gh, bias_gw, tab != nullptr)) {
+    // the four-wave form (attn2_bwd2.hip: dQ^T in registers, tables in LDS); same partial layouts, the two sum launches below are shared
+    const ctclip_attn2::Bwd2Args x2{qinv, (bf16_t*)dq, lddq, qpart, dtab ? dtpart : nullptr, pl.ipw, pl.wph, stamp ? (unsigned long long*)w : nullptr};
+    rc = attn2_bwd2_launch(p, x2, pl.nwg, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd1_scale_sum_kernel, dim3(2), dim3(1024), 0, stream, (const float*)p.kpart, (const float*)qpart, pl.nwg, dk_scale, dq_scale);
+    rc = ctclip_check_launch("attn2_bwd_fused (scale sums)");
+    if (rc || !dtab) return rc;
+    hipLaunchKernelGGL(bwd1_dtab_sum_kernel, dim3((unsigned)cdiv((int64_t)pl.ncls * H, 64)), dim3(256), 0, stream, (const float*)dtpart, nseq, dtab, H, pl.ncls);
+    return ctclip_check_launch("attn2_bwd_fused (table sum)");
+  }
   hipLaunchKernelGGL(bwd1_stage_kernel, dim3((unsigned)H), dim3(256), 0, stream, p, tabadj, pl.ncls);
-  int rc = ctclip_check_launch("attn2_bwd_fused (stage)");
+  rc = ctclip_check_launch("attn2_bwd_fused (stage)");
   if (rc) return rc;
   static bool raised_dev[MAXDEV1] = {};                         // the attribute is per device
   bool& raised = raised_dev[cur_dev1()];

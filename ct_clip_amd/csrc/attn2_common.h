@@ -26,6 +26,14 @@ struct Params {
   // kpart = per-workgroup partial sums [gridDim][32] of the k_scale gradient (summed in workgroup order by the host's reduce launch)
   bf16_t* dk_tok; bf16_t* dv_tok; int64_t ldk_tok, ldv_tok; const float* kinv; float* kpart;
 };
+// arguments of the four-wave one-pass backward (attn2_bwd2.hip) beyond Params; partial layouts as in attn2_bwd1.hip
+struct Bwd2Args {
+  const float* qinv; bf16_t* dq_tok; int64_t lddq;
+  float* qpart;                            // [nwg][32] q_scale gradient partials (k: Params::kpart)
+  float* dtpart;                           // [nseq][H][ncls] table-gradient partials, one per (workgroup, item), or null
+  int ipw, wph;                            // items per workgroup, workgroups per head
+  unsigned long long* stamps;              // profiling aid (tools/bench_attn2_bwd.py --stamps): 100-MHz clock at the phase boundaries of workgroup 0, or null
+};
 }  // namespace ctclip_attn2
 
 namespace {
@@ -213,3 +221,6 @@ int attn2_slab_fwd(const ctclip_attn2::Params& p, hipStream_t stream);
 int attn2_slab_bwd_dq(const ctclip_attn2::Params& p, hipStream_t stream);
 int attn2_slab_bwd_dkv(const ctclip_attn2::Params& p, hipStream_t stream, int* nwg_out = nullptr);
 int attn2_slab_bwd_dbias(const ctclip_attn2::Params& p, hipStream_t stream);
+// the four-wave form of the one-pass backward (attn2_bwd2.hip): L = 576 (24 x 24 tokens) only
+bool attn2_bwd2_eligible(int nseq, int H, int L, int gh, int gw, bool tab);
+int attn2_bwd2_launch(const ctclip_attn2::Params& p, const ctclip_attn2::Bwd2Args& x, int nwg, hipStream_t stream);

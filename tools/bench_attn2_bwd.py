@@ -59,6 +59,20 @@ def main():
     if stamps:      # phase clocks (100 MHz) of workgroup 0, wave 0: see BWD1_STAMP in csrc/attn2_bwd1.hip
         n = be.lib.ctclip_attn2_bwd_fused_workspace(nseq, H, L, gh, gw)
         st = be.workspace(dev, n)[n - 4096:n].view(torch.int64).cpu().reshape(-1, 16)
+        if os.environ.get("CTCLIP_ATTN_BWD2", "1") != "0":      # the four-wave form (csrc/attn2_bwd2.hip): its own phase boundaries
+            spans2 = [("loads consumed + barrier", 0, 1), ("triples + barrier (load phase end)", 1, 2), ("tile loop (wave 0)", 2, 3), ("barrier", 3, 4),
+                      ("dQ hand-over + barrier", 4, 5), ("q un-prep", 5, 6), ("table flush + barrier", 6, 7)]
+            rows = []
+            for it in range(6):
+                t = st[it].tolist()
+                row = {nm: round((t[b] - t[a]) / 100.0, 2) for nm, a, b in spans2}
+                bs = st.reshape(-1)[128 + it * 32:128 + it * 32 + 27].tolist()
+                row["sweep_us_per_block"] = [round((bs[3 * k + 1] - bs[3 * k]) / 100.0, 2) for k in range(9)]
+                row["block_end_us"] = [round((bs[3 * k + 2] - bs[3 * k + 1]) / 100.0, 2) for k in range(9)]
+                rows.append(row)
+            out["phases_us_per_item"] = rows
+            print(json.dumps(out))
+            return
         spans = [("loads issued+consumed", 0, 1), ("dO'' written (load phase end)", 1, 2), ("tile steps", 2, 3), ("parked stores drained + barrier", 3, 4),
                  ("dq un-prep + next item's L2 touches", 4, 7), ("table flush + barrier", 7, 8)]
         rows = []

@@ -17,7 +17,7 @@ for d in ("pmc1", "pmc2", "pmc3"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(f"gpurun_out/pmc_attn2/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            m = re.search(r"(bwd1_kernel|\w+_slab_kernel|dbias_\w+|attn_unprep_kernel|bwd1_\w+_kernel)", r["Kernel_Name"])
+            m = re.search(r"(bwd1_kernel|bwd2_kernel|\w+_slab_kernel|dbias_\w+|attn_unprep_kernel|bwd1_\w+_kernel)", r["Kernel_Name"])
             if not m: continue
             n = m.group(1)
             acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
