@@ -110,6 +110,11 @@ __device__ __forceinline__ void gstore8(bf16_t* ptr, const float (&v)[8]) {
 #ifndef BWD2_ABL
 #define BWD2_ABL 0
 #endif
+// BWD2_TSTAMPS (variant builds only): shader-clock stamps of wave 0 at the phase boundaries of the nine tiles of key block 1 of item 0 (every stamp
+// drains the LDS queue: an SMEM read is counted on lgkmcnt -- the durations are upper bounds of the undisturbed ones)
+#ifndef BWD2_TSTAMPS
+#define BWD2_TSTAMPS 0
+#endif
 
 struct Steps2 {
   const bf16_t *k, *v, *q;                   // the item's K^ / V / Q~ slabs (head-planar, global)
@@ -212,13 +217,14 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+  uint32_t touch = 0u;
   for (int kbi = 0; kbi < HT; ++kbi) {
     const int kb = kh * HT + kbi;
     BWD2_BST(3 * kbi);
     const Frag kf = kn, vf = vn;
     const float ik = ikn;
+    asm volatile("" :: "v"(touch));                              // (the previous block's touch: its destination register stays reserved until it has landed)
     if (kbi + 1 < HT) load_kv(kb + 1);                           // a block ahead (consumed at the top of the next block)
-    uint32_t touch;
     {   // L2 touch of the next item: line kbi * 256 + tid of  Q~ | V | K^ (288 lines each) | dout rows | o rows (576 each: 64 B of a row) | lse2 (18)
       int li = kbi * NTH2 + tid;
       li = li < 2034 ? li : 2033;
@@ -265,13 +271,18 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
     m1(o0, sc, dp);
 
 #define BWD2_SB() __builtin_amdgcn_sched_barrier(0)
-    // Three phases per tile, pinned by scheduling barriers (left alone, the machine scheduler sinks every LDS read to its consumer to save registers
-    // and the single wave of a SIMD then stalls a full LDS round trip six times per tile):
+    // Three phases per tile, pinned by scheduling barriers.  Why: ONE wave per SIMD issues an instruction every ~5 cycles at best
+    // (tools/ubench/issue_rates.hip: v_fma 5.06, v_exp 8.75 cycles; a matrix instruction occupies its pipe for 32), it is in-order, and left
+    // alone the machine scheduler sinks every LDS read to its consumer to save registers: a full LDS round trip six times per tile.
     //   A  issue the transposing reads this tile's dV / dK / dQ^T products need (they land under phase B);
     //   B  S / dP of tile T + 1 on the matrix pipe UNDER this tile's exponentials, products and class-table atomics; row operands of tile T + 2 requested;
     //   C  packs, then dV^T, dK^T of tile T and dQ^T of tile T - 1; dS of tile T into the scratch.
+    // (Prescribing the instruction mix of B and C with sched_group_barrier -- one matrix instruction per six vector and five LDS instructions --
+    // measured 3-5 % SLOWER than leaving the order inside a phase to the scheduler: profiles/r06_attn_bwd2.md.)
+#define BWD2_TST(i) do { if (BWD2_TSTAMPS && a.bstamps && kbi == 1 && a.seq0 == 0 && threadIdx.x == 0) *GLB(unsigned long long, a.bstamps + 192 + (i)) = __builtin_readcyclecounter(); } while (0)
 #define BWD2_TILE(T, OCUR, ONEXT)                                                                                                  \
     {                                                                                                                              \
+      BWD2_TST(3 * (T));                                                                                                           \
       Frag dotf, qtf, dstf;                                                                                                        \
       if (!(BWD2_ABL & 16)) { dotf = cols2(dyn + OFF_DOS + (T) * TILE, ln.trq); qtf = cols2(dyn + OFF_QS + (T) * TILE, ln.trq); }   \
       if (!(BWD2_ABL & 2) && (T) > 0) dstf = cols2(scr, ln.tr);                                                                    \
@@ -279,7 +290,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       f32x16 sc2, dp2;                                                                                                             \
       if ((T) + 1 < HT) m1(ONEXT, sc2, dp2);                                                                                       \
       float pr[16], ds[16];                                                                                                        \
-      f32x2 fx[8];                                                 /* packed f32 arithmetic: the single wave of a SIMD is ISSUE-bound (5 cycles per VALU) */ \
+      f32x2 fx[8];                                                 /* packed f32 arithmetic: the single wave of a SIMD is ISSUE-bound */ \
       _Pragma("unroll") for (int r2 = 0; r2 < 8; ++r2) {                                                                           \
         const f32x2 p2 = {(BWD2_ABL & 4) ? sc[2 * r2] : __builtin_amdgcn_exp2f(sc[2 * r2]),                                        \
                           (BWD2_ABL & 4) ? sc[2 * r2 + 1] : __builtin_amdgcn_exp2f(sc[2 * r2 + 1])};                                \
@@ -298,6 +309,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       }                                                                                                                            \
       if ((T) + 2 < HT) req_rows<((T) + 2 < HT ? (T) + 2 : 0), TAB>(dyn, ln, tbA, tbB, OCUR);                                      \
       BWD2_SB();                                                                                                                   \
+      BWD2_TST(3 * (T) + 1);                                                                                                       \
       const Frag pf = pack(pr), dsf = pack(ds);                                                                                    \
       if (!(BWD2_ABL & 16)) {                                                                                                      \
         dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);                                       \
@@ -313,6 +325,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
         *reinterpret_cast<bf16x8*>(scr + swz(c, 2 + half)) = dsf.v[1];                                                             \
       }                                                                                                                            \
       BWD2_SB();                                                                                                                   \
+      BWD2_TST(3 * (T) + 2);                                                                                                       \
       if ((T) + 1 < HT) { sc = sc2; dp = dp2; }                                                                                    \
     }
     BWD2_TILE(0, o0, o1)
@@ -403,9 +416,9 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
         gstore8(dK + 16 * gq + 8 * half, a8);
       }
     }
-    asm volatile("" :: "v"(touch));                              // (keeps the touch's destination register reserved until it has landed)
     BWD2_BST(3 * kbi + 2);
   }
+  asm volatile("" :: "v"(touch));
   BWD2_ST(3);
 
   // this item's k_scale-gradient sums: the 32 lanes of a half by an xor tree, then added to the wave's row of the LDS accumulator
@@ -499,6 +512,99 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   BWD2_ST(6);
 }
 
+struct Load2 {
+  const bf16_t *qsl, *vsl, *dsl, *osl; const float* lsl;       // the item's Q~ / V slabs (head-planar), dout / o rows at this head, lse2
+  int64_t lddo, ldo;
+  unsigned long long* stp;
+};
+
+// Load phase of one item: Q~ and dO slabs -> LDS (plain copies), -delta = -sum_d dO O and log2 K - lse2 per query as bf16 triples, and K -- the
+// fixed-point scale of the item, a power of two from the rigorous bound |dS| <= 2 max|dO_q| max|v_k|.  Returns 1 / K.  A call of its own: inlined,
+// its 36 + 9 loads per thread shared the kernel function's register allocation with everything that lives across the 512-register tile call,
+// and in some builds the allocator spilled the loads (load phase 20 us instead of 6).
+__device__ __noinline__ float bwd2_load(Load2 a_) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  Load2 a = a_;
+  a.qsl = uni2(a.qsl); a.vsl = uni2(a.vsl); a.dsl = uni2(a.dsl); a.osl = uni2(a.osl); a.lsl = uni2(a.lsl); a.lddo = uni2(a.lddo); a.ldo = uni2(a.ldo);
+  a.stp = uni2(a.stp);
+  const bf16_t *qsl = a.qsl, *vsl = a.vsl, *dsl = a.dsl, *osl = a.osl; const float* lsl = a.lsl;
+  char* qs = dyn + OFF_QS;
+  char* dos = dyn + OFF_DOS;
+  uint32_t* trip = reinterpret_cast<uint32_t*>(dyn + OFF_TRIP);
+  float* misc = reinterpret_cast<float*>(dyn + OFF_MISC);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float invK = 1.f;
+    auto split3 = [](float v, uint32_t& w0, uint32_t& w1) {      // 24 mantissa bits as three bf16 terms
+      const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
+      const float r1 = v - __uint_as_float(hi << 16);
+      const uint32_t lo = pack2bf(r1, 0.f) & 0xffffu;
+      const float r2 = r1 - __uint_as_float(lo << 16);
+      w0 = hi | (lo << 16); w1 = pack2bf(r2, 0.f) & 0xffffu;
+    };
+    float mxd = 0.f, mxv = 0.f;
+    float ols[NP2];
+    // three batches of three pieces (twelve 16-byte loads in flight per thread): with all 36 in flight the allocator of this kernel -- whose
+    // budget is what the 512-register tile function leaves -- spilled them, and the load phase took 20 us instead of 7 in some builds
+#pragma unroll
+    for (int k0 = 0; k0 < NP2; k0 += 3) {
+      u32x4 oq[3], ov_[3], od[3], oo[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int pc = (k0 + k) * NTH2 + tid, row = pc >> 2, ch = pc & 3;
+        oq[k] = *reinterpret_cast<const u32x4*>(qsl + row * D + ch * 8);
+        ov_[k] = *reinterpret_cast<const u32x4*>(vsl + row * D + ch * 8);
+        od[k] = *reinterpret_cast<const u32x4*>(dsl + (int64_t)row * a.lddo + ch * 8);
+        oo[k] = *reinterpret_cast<const u32x4*>(osl + (int64_t)row * a.ldo + ch * 8);
+        ols[k0 + k] = lsl[row];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int pc = (k0 + k) * NTH2 + tid, row = pc >> 2, ch = pc & 3;
+        *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = oq[k];
+        *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = od[k];
+        float x8[8], b[8], v8[8];
+        unpack8v(od[k], x8); unpack8v(oo[k], b); unpack8v(ov_[k], v8);
+        float ds = 0.f, dn = 0.f, vnn = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ds += x8[e] * b[e]; dn += x8[e] * x8[e]; vnn += v8[e] * v8[e]; }
+        ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
+        dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
+        vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
+        uint32_t w0, w1;
+        split3(-ds, w0, w1);
+        if (ch < 2) trip[row * 4 + ch] = ch ? w1 : w0;              // (the four chunk threads of a row hold the same value)
+        mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mxd = wave_max(mxd); mxv = wave_max(mxv);
+    if (lane == 0) { misc[wave] = mxd; misc[4 + wave] = mxv; }
+    __syncthreads();
+    if (a.stp && tid == 0) a.stp[1] = wall_clock64();
+    float bd = 0.f, bv = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < NW2; ++w4) { bd = fmaxf(bd, misc[w4]); bv = fmaxf(bv, misc[4 + w4]); }
+    const float B = 2.f * sqrtf(bd) * sqrtf(bv);                  // |dS| <= P 2 |dO_q| |v_k| with the probability P <= 1
+    int kk = 0;
+    if (B > 0.f && B < 3.0e38f) {
+      int e; (void)frexpf(B, &e);
+      kk = FIX_BITS2 - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
+      invK = ldexpf(1.f, -kk);
+    } else if (!(B < 3.0e38f)) {
+      invK = __builtin_nanf("");
+    }
+    const float lgK = (float)kk;
+#pragma unroll
+    for (int k = 0; k < NP2; ++k) {
+      const int pc = k * NTH2 + tid, row = pc >> 2, ch = pc & 3;
+      uint32_t w0, w1;
+      split3(lgK - ols[k], w0, w1);
+      if (ch >= 2) trip[row * 4 + ch] = (ch & 1) ? w1 : w0;
+    }
+  return invK;
+}
+
 template <bool TAB, bool DTAB>
 __global__ __launch_bounds__(NTH2) void bwd2_kernel(Params p, ctclip_attn2::Bwd2Args x) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -537,75 +643,8 @@ __global__ __launch_bounds__(NTH2) void bwd2_kernel(Params p, ctclip_attn2::Bwd2
 #define BWD2_KST(i) do { if (stp && tid == 0) stp[i] = wall_clock64(); } while (0)
     BWD2_KST(0);
     // ---------------------------------------------------------------------------------------------- load phase: the item's operands -> LDS
-    float invK = 1.f;
-    {
-      const bf16_t* qsl = p.qh + so;
-      const bf16_t* vsl = p.vh + so;
-      const bf16_t* dsl = p.dout + tok0 * p.lddo + h * D;
-      const bf16_t* osl = p.o + tok0 * p.ldo + h * D;
-      const float* lsl = p.lse2 + (int64_t)h * p.M + tok0;
-      u32x4 oq[NP2], ov_[NP2], od[NP2], oo[NP2];
-      float ols[NP2];
-#pragma unroll
-      for (int k = 0; k < NP2; ++k) {
-        const int pc = k * NTH2 + tid, row = pc >> 2, ch = pc & 3;
-        oq[k] = *reinterpret_cast<const u32x4*>(qsl + row * D + ch * 8);
-        ov_[k] = *reinterpret_cast<const u32x4*>(vsl + row * D + ch * 8);
-        od[k] = *reinterpret_cast<const u32x4*>(dsl + (int64_t)row * p.lddo + ch * 8);
-        oo[k] = *reinterpret_cast<const u32x4*>(osl + (int64_t)row * p.ldo + ch * 8);
-        ols[k] = lsl[row];
-      }
-      auto split3 = [](float v, uint32_t& w0, uint32_t& w1) {      // 24 mantissa bits as three bf16 terms
-        const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
-        const float r1 = v - __uint_as_float(hi << 16);
-        const uint32_t lo = pack2bf(r1, 0.f) & 0xffffu;
-        const float r2 = r1 - __uint_as_float(lo << 16);
-        w0 = hi | (lo << 16); w1 = pack2bf(r2, 0.f) & 0xffffu;
-      };
-      float mxd = 0.f, mxv = 0.f;
-#pragma unroll
-      for (int k = 0; k < NP2; ++k) {
-        const int pc = k * NTH2 + tid, row = pc >> 2, ch = pc & 3;
-        *reinterpret_cast<u32x4*>(qs + (row >> 5) * TILE + swz(row & 31, ch)) = oq[k];
-        *reinterpret_cast<u32x4*>(dos + (row >> 5) * TILE + swz(row & 31, ch)) = od[k];
-        float x8[8], b[8], v8[8];
-        unpack8v(od[k], x8); unpack8v(oo[k], b); unpack8v(ov_[k], v8);
-        float ds = 0.f, dn = 0.f, vnn = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ds += x8[e] * b[e]; dn += x8[e] * x8[e]; vnn += v8[e] * v8[e]; }
-        ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
-        dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
-        vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
-        uint32_t w0, w1;
-        split3(-ds, w0, w1);
-        if (ch < 2) trip[row * 4 + ch] = ch ? w1 : w0;                // (the four chunk threads of a row hold the same value)
-        mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);
-      }
-      mxd = wave_max(mxd); mxv = wave_max(mxv);
-      if (lane == 0) { misc[wave] = mxd; misc[4 + wave] = mxv; }
-      __syncthreads();
-      BWD2_KST(1);
-      float bd = 0.f, bv = 0.f;
-#pragma unroll
-      for (int w4 = 0; w4 < NW2; ++w4) { bd = fmaxf(bd, misc[w4]); bv = fmaxf(bv, misc[4 + w4]); }
-      const float B = 2.f * sqrtf(bd) * sqrtf(bv);                  // |dS| <= P 2 |dO_q| |v_k| with the probability P <= 1
-      int kk = 0;
-      if (B > 0.f && B < 3.0e38f) {
-        int e; (void)frexpf(B, &e);
-        kk = FIX_BITS2 - e; kk = kk > 100 ? 100 : (kk < -100 ? -100 : kk);
-        invK = ldexpf(1.f, -kk);
-      } else if (!(B < 3.0e38f)) {
-        invK = __builtin_nanf("");
-      }
-      const float lgK = (float)kk;
-#pragma unroll
-      for (int k = 0; k < NP2; ++k) {
-        const int pc = k * NTH2 + tid, row = pc >> 2, ch = pc & 3;
-        uint32_t w0, w1;
-        split3(lgK - ols[k], w0, w1);
-        if (ch >= 2) trip[row * 4 + ch] = (ch & 1) ? w1 : w0;
-      }
-    }
+    const float invK = bwd2_load(Load2{p.qh + so, p.vh + so, p.dout + tok0 * p.lddo + h * D, p.o + tok0 * p.ldo + h * D, p.lse2 + (int64_t)h * p.M + tok0,
+                                       p.lddo, p.ldo, stp});
     __syncthreads();
     BWD2_KST(2);
     // ---------------------------------------------------------------------------------------------- tile steps, exchanges, un-preps

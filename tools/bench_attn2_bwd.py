@@ -33,10 +33,10 @@ def main():
     dqs, dks = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
 
     def old():
-        return be.attn2_bwd_tok(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, True)
+        return be.attn2_bwd_tok(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, os.environ.get("BENCH_NO_DTAB") is None)
 
     def new():
-        return be.attn2_bwd_fused(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, True)
+        return be.attn2_bwd_fused(qh, kh, vh, tab, (gh, gw), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq, dkv[:, :HD], dkv[:, HD:], dqs, dks, nseq, L, os.environ.get("BENCH_NO_DTAB") is None)
 
     out = {}
     for name, fn in (("three_pass_us", old), ("one_pass_us", new)):
@@ -71,6 +71,9 @@ def main():
                 row["block_end_us"] = [round((bs[3 * k + 2] - bs[3 * k + 1]) / 100.0, 2) for k in range(9)]
                 rows.append(row)
             out["phases_us_per_item"] = rows
+            ts = st.reshape(-1)[128 + 192:128 + 192 + 27].tolist()      # BWD2_TSTAMPS builds: shader clocks at tile start / after phase B / after phase C
+            if any(ts):
+                out["tile_phase_cycles_block1"] = [[ts[3 * k + 1] - ts[3 * k], ts[3 * k + 2] - ts[3 * k + 1], (ts[3 * k + 3] - ts[3 * k + 2]) if k < 8 else 0] for k in range(9)]
             print(json.dumps(out))
             return
         spans = [("loads issued+consumed", 0, 1), ("dO'' written (load phase end)", 1, 2), ("tile steps", 2, 3), ("parked stores drained + barrier", 3, 4),

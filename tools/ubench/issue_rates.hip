@@ -20,7 +20,7 @@ __global__ void stream(float* out, uint64_t* cycles, int iters) {
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = i;
   bf16x8 fa, fb;
   for (int i = 0; i < 8; ++i) { fa[i] = (short)(0x3f80 + i); fb[i] = (short)(0x3f00 + threadIdx.x); }
-  f32x16 acc0 = {}, acc1 = {};
+  f32x16 acc0 = {}, acc1 = {}, acc2 = {};
   const float m = 1.0001f, c = 0.5f;
   uint32_t* ldsu = reinterpret_cast<uint32_t*>(lds);
   const int lane = threadIdx.x & 63;
@@ -53,13 +53,19 @@ __global__ void stream(float* out, uint64_t* cycles, int iters) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) (void)__hip_atomic_fetch_add(ldsu + 2048 + ((lane + i * 64 + r * 128) & 2047), (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         a[8] += v[0][0] + v[1][0];
       }
+      if (OP >= 12 && OP <= 14) {      // dependent accumulation chains over 1 / 2 / 3 accumulators, 4 fma between matrix instructions
+        if (OP == 12) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+        if (OP == 13) { if (r & 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0); else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0); }
+        if (OP == 14) { if (r % 3 == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0); else if (r % 3 == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0); else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0); }
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+      }
       if (OP == 10) { _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<double*>(&a[2 * i])) : "v"(*reinterpret_cast<const double*>(&a[(2 * i + 2) & 15]))); }
       if (OP == 11) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c)); asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i])); } }
     }
   }
   const uint64_t t1 = __builtin_readcyclecounter();
   float s = 0.f;
-  for (int i = 0; i < 16; ++i) s += a[i] + acc0[i] + acc1[i];
+  for (int i = 0; i < 16; ++i) s += a[i] + acc0[i] + acc1[i] + acc2[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + lds[threadIdx.x];
   if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
@@ -89,6 +95,7 @@ void run(const char* name, int instr_per_r) {
 int main() {
   run<0>("v_fma_f32 x8", 8); run<1>("v_exp_f32 x8", 8); run<2>("v_cvt_pk_bf16_f32 x8", 8); run<10>("v_pk_mul_f32 x8", 8); run<11>("fma + exp alternating x4", 8);
   run<6>("mfma 32x32x16 only", 1); run<3>("1 mfma + 4 fma", 5); run<4>("1 mfma + 8 fma", 9); run<5>("1 mfma + 12 fma", 13);
+  run<12>("1 mfma (ONE accumulator chain) + 4 fma", 5); run<13>("1 mfma (two chains) + 4 fma", 5); run<14>("1 mfma (three chains, r % 3) + 4 fma", 5);
   run<7>("4 ds_read_b128 + 4 fma", 8); run<8>("ds_add_u32 x8", 8); run<9>("1 mfma + 4 fma + 2 ds_read_b128 + 2 ds_add + 1 add", 10);
   return 0;
 }
