@@ -110,6 +110,7 @@ SIGNATURES = {
     "ctclip_grad_norm_clip": (_I, [_P, _L, _P, _F, _P, _P, _L, _P]),
     "ctclip_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "ctclip_adam_step_zero_grad": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
+    "ctclip_spin": (_I, [_L, _P]),
 }
 
 _lib = None

@@ -506,3 +506,19 @@ extern "C" int ctclip_patch_embed_param_bwd(const float* G, const float* W, cons
   hipLaunchKernelGGL(patch_param_bwd_kernel, dim3((unsigned)cdiv(K, 64)), dim3(512), 0, s, G, W, gamma1, beta1, dbp, dW, dgamma1, dbeta1, N, K, accumulate);
   return ctclip_check_launch("patch_embed_param_bwd");
 }
+
+// One thread spinning on the 100-MHz wall clock for `microseconds`: holds a hardware queue busy without touching memory.  ct_clip_amd/streams.py
+// probes with it whether a side stream runs BESIDE the default stream (it used torch.cuda._sleep, a private API, up to round 5).
+namespace {
+__global__ void spin_kernel(unsigned long long ticks, unsigned int* sink) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned int n = 0;
+  while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); ++n; }
+  if (sink && ticks == ~0ull) *sink = n;      // (never true: keeps the loop observable)
+}
+}  // namespace
+extern "C" int ctclip_spin(int64_t microseconds, hipStream_t s) {
+  if (microseconds < 0 || microseconds > 1000000) { ctclip_set_error("spin: 0 .. 1 000 000 microseconds"); return CTCLIP_EBADARG; }
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (unsigned long long)microseconds * 100ull, (unsigned int*)nullptr);
+  return ctclip_check_launch("spin");
+}

@@ -7,12 +7,17 @@ single-process run and on the MAIN stream's queue as soon as a process group exi
 first): the text tower then ran serialised behind the image tower and the step was 5.5 ms longer, with not one kernel added.
 
 There is no API that names a stream's queue, so the streams handed out here are PROBED: a candidate is accepted when a small kernel launched
-on it completes while a long-running single-thread spin kernel occupies the default stream and every side stream handed out before.  A few
-milliseconds once per purpose and device.  `CTCLIP_STREAM_PROBE=0` returns the first stream torch offers (the behaviour up to round 4).
+on it completes while a long-running single-thread spin kernel (`ctclip_spin`, csrc/misc.hip: the library's own -- up to round 5 this leaned on
+the private `torch.cuda._sleep`) occupies the default stream and every side stream handed out before.  A few milliseconds once per purpose and
+device.  `CTCLIP_STREAM_PROBE=0` returns the first stream torch offers (the behaviour up to round 4).
+
+When NO candidate runs beside the default stream the overlap the caller wanted is lost (the step is still correct): that is reported ONCE per
+purpose on stderr and as `concurrent_with_default: False` in `report()` (bench.py prints it in the `side_streams` object of its line).
 
 Order matters when the queues run out: ask for the streams that carry kernels first (text tower, weight gradients), for the communication
 stream last."""
 import os
+import sys
 
 import torch
 
@@ -20,7 +25,6 @@ _TAKEN = {}        # device index -> [default stream, side streams handed out so
 _BY_PURPOSE = {}   # (device index, purpose) -> stream
 _REPORT = {}       # (device index, purpose) -> dict(tries=..., concurrent_with_default=..., concurrent_with_all=...)
 _SCRATCH = {}
-_CYCLES = {}
 MAX_TRIES = 24     # torch's pool has 32 streams per device and priority
 
 
@@ -36,29 +40,20 @@ def _scratch(idx):
     return t
 
 
-def _spin_cycles(idx):
-    """Argument of torch.cuda._sleep for about 2 ms on this device (its clock is not specified: calibrated once)."""
-    c = _CYCLES.get(idx)
-    if c is None:
-        dev = torch.device("cuda", idx)
-        st = torch.cuda.default_stream(dev)
-        with torch.cuda.stream(st):
-            torch.cuda._sleep(1000)      # (first launch: module load)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(st)
-            torch.cuda._sleep(200_000)
-            b.record(st)
-        b.synchronize()
-        ms = max(a.elapsed_time(b), 1e-3)
-        c = _CYCLES[idx] = int(min(max(200_000 * 2.0 / ms, 10_000), 10_000_000))      # (bounded: a mis-timed calibration must not turn into seconds of spinning)
-    return c
+SPIN_US = 2000     # how long the probe's spin kernels hold their queues
+
+
+def _spin(stream):
+    """The library's spin kernel (ctclip_spin) on `stream`."""
+    from . import _lib
+    _lib.check(_lib.load().ctclip_spin(SPIN_US, stream.cuda_stream), "ctclip_spin")
 
 
 def runs_beside(cand, busy):
     """True when a kernel on `cand` completes while every stream of `busy` (busy[0] = the reference clock) is held by a spin kernel."""
     idx = cand.device.index
     dev = torch.device("cuda", idx)
-    x, n = _scratch(idx), _spin_cycles(idx)
+    x = _scratch(idx)
     with torch.cuda.stream(cand):
         x.add_(1.0)      # the first launch on a new stream may create its hardware queue (milliseconds): not part of the measurement
     torch.cuda.synchronize(dev)
@@ -66,11 +61,10 @@ def runs_beside(cand, busy):
     e0.record(busy[0])
     ends = []
     for s in busy:
-        with torch.cuda.stream(s):
-            torch.cuda._sleep(n)
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(s)
-            ends.append(e)
+        _spin(s)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(s)
+        ends.append(e)
     with torch.cuda.stream(cand):
         x.add_(1.0)
         ec = torch.cuda.Event(enable_timing=True)
@@ -79,35 +73,59 @@ def runs_beside(cand, busy):
     return e0.elapsed_time(ec) < 0.5 * min(e0.elapsed_time(e) for e in ends)
 
 
+_WARNED = set()
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        print(f"ct_clip_amd.streams: {msg}", file=sys.stderr)
+
+
 def concurrent_stream(device, purpose):
     """The process-wide side stream for (device, purpose): created once, chosen so that it shares a hardware queue neither with the default
     stream nor -- while queues last -- with the side streams handed out before."""
     idx = _dev_index(device)
     key = (idx, purpose)
     st = _BY_PURPOSE.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if st is not None:
-        return st
+        # a purpose first asked for INSIDE a graph capture got an unprobed stream: probe it the first time it is asked for outside one
+        if _REPORT.get(key, {}).get("probed") is False and _REPORT[key].get("why") == "capture" and not capturing:
+            forget(device, purpose)
+        else:
+            return st
     dev = torch.device("cuda", idx)
-    if os.environ.get("CTCLIP_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
-        st = torch.cuda.Stream(device=dev)      # (no spin kernel in this torch build / inside a graph capture: no way to probe)
-        _REPORT[key] = dict(tries=0, probed=False)
+    if os.environ.get("CTCLIP_STREAM_PROBE", "1") == "0" or capturing:
+        st = torch.cuda.Stream(device=dev)      # (inside a graph capture nothing can be launched to probe with)
+        _REPORT[key] = dict(tries=0, probed=False, why="capture" if capturing else "CTCLIP_STREAM_PROBE=0")
     else:
         taken = _TAKEN.setdefault(idx, [torch.cuda.default_stream(dev)])
-        tried, fallback = [], None
+        tried, fallback, st = [], None, None
         for _ in range(MAX_TRIES):
             cand = torch.cuda.Stream(device=dev)
             if any(cand == t for t in tried):
                 break                            # the pool wrapped around
             tried.append(cand)
+            if any(cand == t for t in taken):
+                continue                         # torch's pool is process-wide and wraps: this one already serves another purpose
             if runs_beside(cand, taken):
                 st = cand
                 break
             if fallback is None and len(taken) > 1 and runs_beside(cand, taken[:1]):
                 fallback = cand                  # at least not on the main stream's queue
+        free = [t for t in tried if not any(t == u for u in taken)]
         _REPORT[key] = dict(tries=len(tried), probed=True, concurrent_with_all=st is not None,
                             concurrent_with_default=st is not None or fallback is not None)
         if st is None:
-            st = fallback if fallback is not None else tried[0]
+            st = fallback if fallback is not None else (free[0] if free else torch.cuda.Stream(device=dev))
+            if fallback is None:
+                _warn_once(key, f"no stream for '{purpose}' on cuda:{idx} runs beside the default stream (all {len(tried)} candidates share its "
+                                "hardware queue): work on it will be SERIALISED with the main stream -- correct, but the overlap is lost "
+                                "(see GPU_MAX_HW_QUEUES / profiles/r05_stream_queues.md)")
+            else:
+                _warn_once(key, f"the stream for '{purpose}' on cuda:{idx} runs beside the default stream but shares a hardware queue with "
+                                "another side stream")
         taken.append(st)
     _BY_PURPOSE[key] = st
     return st

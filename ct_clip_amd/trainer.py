@@ -194,6 +194,11 @@ class GraphedStep:
         self.text = type(text)(self.ids, self.mask) if not hasattr(text, "_replace") else text._replace(input_ids=self.ids, attention_mask=self.mask)
         torch.cuda.synchronize(dev)
         _be._lib.check(be.lib.ctclip_set_step_state(self.state.data_ptr()), "ctclip_set_step_state")
+        GraphedStep._state_owner = self
+        # Every lazily rebuilt weight shadow (the stacked q | k | v bias, non-2D weights, everything under CTCLIP_SHADOW_BATCH=0) must be STALE at
+        # capture time so that its maker is recorded in the graph: after an eager forward with no optimiser step in between (validation, then
+        # capture) they were fresh, their makers were not captured, and every replay read the capture-time values while Adam moved the f32 parameter
+        Fn.bump_weight_epoch(t.optim.params)
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -205,6 +210,7 @@ class GraphedStep:
             # a failed capture must leave the process as it found it: the library's step-state pointer (every later EAGER Adam launch and
             # dropout seed would read a device counter nobody advances) and the host step counter the recorded optim.step() bumped
             be.lib.ctclip_set_step_state(None)
+            GraphedStep._state_owner = None
             t.optim.step_count = step0
             self.state = None
             raise
@@ -232,9 +238,15 @@ class GraphedStep:
         Fn.restamp_shadows(t.optim.params)
         return self.loss
 
+    _state_owner = None      # the instance whose device counters the library's process-global step-state pointer refers to
+
     def close(self):
         if self.state is not None:
-            _be.get().lib.ctclip_set_step_state(None)
+            # only the OWNER clears the library's pointer: in the re-capture flow (gs = GraphedStep(t).capture(...) assigned over an old instance) the
+            # old object is finalised AFTER the new capture installed its own state
+            if GraphedStep._state_owner is self:
+                _be.get().lib.ctclip_set_step_state(None)
+                GraphedStep._state_owner = None
             self.state = None
         self.graph = None
 
@@ -320,6 +332,10 @@ class CTClipTrainer(nn.Module):
 
     # -- reference surface
     def save(self, path):
+        # a deferred codebook update (distributed.VqStatSync: applied in reducer.finish() or at the next quantiser call) must be in the buffers
+        # that are written -- a custom loop that bypasses forward_backward could otherwise checkpoint a codebook one EMA step behind.  flush()
+        # issues no collective: calling it on every rank (or on rank 0 only) is safe.
+        self.reducer.vq_sync.flush()
         if not self.is_main:
             return
         # CTCLIPTrainer.py:205-213 keeps {model, optim}; `steps` is additive so that a resumed run continues its counters
@@ -328,6 +344,7 @@ class CTClipTrainer(nn.Module):
     def load(self, path):
         path = Path(path)
         assert path.exists()
+        self.reducer.vq_sync.pending = []      # statistics of the run that is being replaced must not be applied to the loaded codebook
         pkg = torch.load(path, weights_only=False)
         self.CTClip.load_state_dict(pkg["model"])      # in place: the parameters stay views of the optimiser's flat buffer
         self.optim.load_state_dict(pkg["optim"])

@@ -308,6 +308,9 @@ int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* x, int64_t 
 /* Batched refresh of the bf16 weight shadows after the optimiser step (replaces the per-parameter `.to(bf16)` / `.t().contiguous()` / re-layout copies a torch module makes when its weights change; scripts/CTCLIPTrainer.py:259-263 is followed by nothing of the kind because torch computes from the f32 weights): jobs = DEVICE array of njobs records of 12 int64 {src, dst, src_ld, dst_ld, src_rows, src_cols, dst_rows, dst_cols, map, aux, transposed, tile0} sorted by tile0 (tile0 of job i = sum over the jobs before it of ceil(dst_rows / 64) * ceil(dst_cols / 64)), ntiles = the total.  src f32 (src_rows, src_cols), dst bf16 (dst_rows, dst_cols); plain: dst[r][c] = src[map(r)][c], transposed: dst[r][c] = src[map(c)][r], 0 outside the source.  map 0: identity; 1: GEGLU [x | pad | gate | pad] split (aux = inner, half = mapped extent / 2); 2: ctclip_geglu_weight_interleave's row order (aux = inner). */
 int ctclip_shadow_refresh(const void* jobs, int njobs, int64_t ntiles, hipStream_t stream);
 
+/* One thread spins for `microseconds` (0 .. 1 000 000) on stream s without touching memory: the busy kernel with which ct_clip_amd/streams.py probes whether a side stream runs beside the default stream (HIP multiplexes streams onto a few hardware queues). [no reference counterpart: the reference has one stream (scripts/CTCLIPTrainer.py:249-264)] */
+int ctclip_spin(int64_t microseconds, hipStream_t s);
+
 #ifdef __cplusplus
 }
 #endif

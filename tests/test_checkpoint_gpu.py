@@ -224,3 +224,53 @@ def test_graphed_step_mixed_with_eager_forwards_and_failed_capture(golden, tmp_p
     torch.cuda.synchronize()
     assert tr.optim.step_count == 5 and torch.equal(tr.optim.flat_param, want)
     tr.close()
+
+
+def test_graphed_step_captured_behind_an_eval_forward_and_recaptured(golden, tmp_path):
+    """ADVICE r05.  (1) capture() right behind an EAGER forward with no optimiser step in between (validation, then capture): the lazily rebuilt
+    weight shadows (the stacked q | k | v bias of the text tower, non-2D weights) were fresh then, their makers were not recorded and every replay
+    read the capture-time values -- capture() now makes them stale first; eval + capture + three replays must equal eval + three eager steps bit for
+    bit.  (2) Re-capture: an old GraphedStep finalised AFTER a new capture must not clear the step-state pointer the new one installed -- the new
+    graph's replays and an eager step behind them still follow the eager sequence."""
+    import gc
+    import ct_clip_amd
+    from ct_clip_amd.trainer import GraphedStep
+    g = golden("tiny")
+    c = g["config"]
+    text = TextBatch(g["input_ids"].to(DEV), g["attention_mask"].to(DEV))
+    video = g["video"].to(DEV)
+
+    def run(mode):
+        clip = build_model(c, g["state_dict"], DEV, torch.bfloat16)
+        clip.train()
+        tr = ct_clip_amd.CTClipTrainer(clip, num_train_steps=10, batch_size=2, tokenizer=object(), lr=1e-3, train_dataset=[0], evaluate=False,
+                                       checkpoint=False, results_folder=str(tmp_path / mode), num_workers=0)
+
+        def eager():
+            loss = tr.forward_backward(video, text)
+            tr.optim.step(tr.max_grad_norm)
+            tr.optim.zero_grad()
+            return float(loss)
+        losses = [eager() for _ in range(3)]
+        clip.eval()
+        with torch.no_grad():
+            clip(text, video, return_latents=True, device=DEV)      # every lazy shadow is FRESH behind this forward
+        clip.train()
+        if mode == "eager":
+            losses += [eager() for _ in range(6)]
+        else:
+            gs = GraphedStep(tr).capture(video, text)
+            losses += [float(gs.run()) for _ in range(3)]
+            gs = GraphedStep(tr).capture(video, text)          # re-capture over the old instance: the old one is finalised after the new capture
+            gc.collect()
+            assert GraphedStep._state_owner is gs
+            losses += [float(gs.run()) for _ in range(2)]
+            gs.close()
+            assert GraphedStep._state_owner is None
+            losses.append(eager())
+        torch.cuda.synchronize()
+        return losses, tr.optim.flat_param.clone()
+    la, pa = run("eager")
+    lb, pb = run("graph")
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)

@@ -521,4 +521,52 @@ def test_side_stream_selection_logic(monkeypatch):
     assert d.queue == b.queue and streams.report()["wgrad2@cuda:0"]["concurrent_with_all"]
     monkeypatch.setenv("CTCLIP_STREAM_PROBE", "0")
     e = streams.concurrent_stream("cuda:0", "unprobed")
-    assert streams.report()["unprobed@cuda:0"] == dict(tries=0, probed=False) and e is not None
+    assert streams.report()["unprobed@cuda:0"] == dict(tries=0, probed=False, why="CTCLIP_STREAM_PROBE=0") and e is not None
+    monkeypatch.delenv("CTCLIP_STREAM_PROBE")
+    # (round 6) a purpose first asked for INSIDE a graph capture is handed an unprobed stream -- and is probed the first time it is asked for outside one
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    f = streams.concurrent_stream("cuda:0", "late")
+    assert streams.report()["late@cuda:0"]["probed"] is False and streams.concurrent_stream("cuda:0", "late") is f
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    f2 = streams.concurrent_stream("cuda:0", "late")
+    assert streams.report()["late@cuda:0"]["probed"] is True and streams.concurrent_stream("cuda:0", "late") is f2
+
+
+def test_side_stream_without_a_free_queue_warns_once(monkeypatch, capsys):
+    """(round 6) when EVERY candidate shares the default stream's hardware queue the overlap is lost: one warning per purpose on
+    stderr, `concurrent_with_default: False` in the report; a pool that wraps around never hands the same stream to two purposes."""
+    from ct_clip_amd import streams
+
+    class FakeStream:
+        n = 0
+
+        def __init__(self, device=None):
+            FakeStream.n += 1
+            self.id = (FakeStream.n - 1) % 4 + 1      # a pool of four that wraps around
+
+        def __eq__(self, other):
+            return isinstance(other, FakeStream) and other.id == self.id
+
+        __hash__ = object.__hash__
+
+    default = FakeStream()
+    default.id = 0
+    for name in ("_TAKEN", "_BY_PURPOSE", "_REPORT"):
+        monkeypatch.setattr(streams, name, {})
+    monkeypatch.setattr(streams, "_WARNED", set())
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "default_stream", lambda dev=None: default)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(streams, "runs_beside", lambda cand, busy: False)          # one hardware queue for everything
+    monkeypatch.delenv("CTCLIP_STREAM_PROBE", raising=False)
+    a = streams.concurrent_stream("cuda:0", "text")
+    b = streams.concurrent_stream("cuda:0", "comm")
+    assert a != b, "two purposes must not share one stream because the pool wrapped"
+    rep = streams.report()
+    assert rep["text@cuda:0"]["concurrent_with_default"] is False and rep["comm@cuda:0"]["concurrent_with_default"] is False
+    err = capsys.readouterr().err
+    assert err.count("no stream for 'text'") == 1 and err.count("no stream for 'comm'") == 1 and "SERIALISED" in err
+    streams.forget("cuda:0", "text")
+    streams.concurrent_stream("cuda:0", "text")
+    assert capsys.readouterr().err == "", "once per purpose"
