@@ -45,6 +45,17 @@ def bump_weight_epoch(params=None):
         p.__dict__["_ctclip_epoch"] = p.__dict__.get("_ctclip_epoch", 0) + 1
 
 
+def invalidate_lazy_shadows(params):
+    """Drop the cached shadows of `params` that have NO batched-refresh recipe (the stacked q | k | v bias, non-2D weights, everything under
+    CTCLIP_SHADOW_BATCH=0): their makers run again at the next use.  GraphedStep.capture() calls this so that those makers are RECORDED in the graph
+    whatever ran before the capture (shadows with a recipe are rewritten in place by the captured refresh_shadows launch and keep their storage)."""
+    for p in params:
+        cache = p.__dict__.get("_ctclip_shadow")
+        if cache:
+            for key in [k for k in cache if (id(p), k) not in _SHADOW_PLAN]:
+                del cache[key]
+
+
 def _stamp(tensors):
     return (_WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr(), t.__dict__.get("_ctclip_epoch", 0)) for t in tensors)
 

@@ -198,7 +198,7 @@ class GraphedStep:
         # Every lazily rebuilt weight shadow (the stacked q | k | v bias, non-2D weights, everything under CTCLIP_SHADOW_BATCH=0) must be STALE at
         # capture time so that its maker is recorded in the graph: after an eager forward with no optimiser step in between (validation, then
         # capture) they were fresh, their makers were not captured, and every replay read the capture-time values while Adam moved the f32 parameter
-        Fn.bump_weight_epoch(t.optim.params)
+        Fn.invalidate_lazy_shadows(t.optim.params)
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
