@@ -146,10 +146,11 @@ class Transformer(nn.Module):
         # bf16 inference (or CTCLIP_RESIDUAL_COMP=1): the residual stream is the bf16 pair (x, e) -- x what the consumers read, e the rounding
         # residue of the last add, added back in f32 by the next one (functional.residual_comp_enabled: the 72 roundings of a 24-layer stream
         # stop accumulating)
-        comp = Fn.residual_comp_enabled(x)
         e = None
+        kind, nl = self.__dict__.get("kind"), len(self.layers)
         for i, layer in enumerate(self.layers):
             peg, attn, _, ff = layer
+            comp = Fn.residual_comp_enabled(x, kind, i, nl)      # (may switch ON at a later layer -- CTCLIP_RESIDUAL_COMP=lastN: the pair then starts with e = None)
             if tap is not None:
                 tap(i, x if e is None else x.float() + e.float())
             x = Fn.grad_ready(x, layer)     # backward passing this point = the layer's parameter gradients are final
@@ -241,6 +242,7 @@ class CTViT(nn.Module):
                   peg_causal=True)
         self.enc_spatial_transformer = Transformer(depth=spatial_depth, **kw)
         self.enc_temporal_transformer = Transformer(depth=temporal_depth, **kw)
+        self.enc_spatial_transformer.__dict__["kind"], self.enc_temporal_transformer.__dict__["kind"] = "spatial", "temporal"
         self.vq = VectorQuantize(dim=dim, codebook_size=codebook_size, use_cosine_sim=True)
 
         self.to_pixels_first_frame = nn.Sequential(nn.Linear(dim, channels * patch_width * patch_height), nn.Identity())

@@ -555,7 +555,55 @@ def run_preprocess_case():
     print(f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def run_autocast_probe(name, c):
+    """the REFERENCE's own reduced-precision numbers -- its modules under torch.autocast('cpu', bfloat16), train-mode forward,
+    against its own f32 forward on the same weights and inputs: loss, VQ code agreement, latent cosines.  What the product's free-running bf16 lines
+    (profiles/r06_full_size_parity.log) are to be read next to.  Prints one line; writes nothing."""
+    import time
+    t0 = time.time()
+    clip, t, hw = build(c)
+    video, ids, mask = synth_inputs(c)
+    text = ref_shim.TextBatch(ids, mask)
+    sd0 = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    vt = clip.visual_transformer
+    got = {}
+
+    def vq_hook(_m, _i, o):
+        got["idx"] = o[1].detach().clone()
+    h = vt.vq.register_forward_hook(vq_hook)
+    res = {}
+    for mode in ("f32", "autocast"):
+        clip.load_state_dict(sd0)
+        clip.train()
+        with torch.no_grad():
+            if mode == "autocast":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    loss = clip(text, video, return_loss=True, device=torch.device("cpu"))
+            else:
+                loss = clip(text, video, return_loss=True, device=torch.device("cpu"))
+        idx = got["idx"].reshape(-1).clone()
+        clip.load_state_dict(sd0)
+        clip.eval()
+        with torch.no_grad():
+            if mode == "autocast":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    tl, il, _ = clip(text, video, return_latents=True, device=torch.device("cpu"))
+            else:
+                tl, il, _ = clip(text, video, return_latents=True, device=torch.device("cpu"))
+        res[mode] = (float(loss), idx, tl.float(), il.float())
+        print(f"[{name}] reference {mode} done ({time.time() - t0:.0f} s)", flush=True)
+    h.remove()
+    (l0, i0, t0_, v0), (l1, i1, t1_, v1) = res["f32"], res["autocast"]
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a, b, dim=-1).min())
+    print(f"[{name} REFERENCE under torch.autocast(cpu, bfloat16) vs its own f32] loss rel {abs(l1 - l0) / abs(l0):.2e}, training-forward code agreement "
+          f"{float((i0 == i1).float().mean()):.4f}, latent cosine image {cos(v0, v1):.6f} text {cos(t0_, t1_):.6f}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "autocast":
+        for name in sys.argv[2:]:
+            run_autocast_probe(name, {"full1": FULL_CASE, "full2": FULL2_CASE, "tiny": CASES["tiny"]}[name])
+        sys.exit(0)
     which = sys.argv[1:] or list(CASES)
     for name in which:
         if name == "preprocess":
