@@ -280,6 +280,18 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
     // (Prescribing the instruction mix of B and C with sched_group_barrier -- one matrix instruction per six vector and five LDS instructions --
     // measured 3-5 % SLOWER than leaving the order inside a phase to the scheduler: profiles/r06_attn_bwd2.md.)
 #define BWD2_TST(i) do { if (BWD2_TSTAMPS && a.bstamps && kbi == 1 && a.seq0 == 0 && threadIdx.x == 0) *GLB(unsigned long long, a.bstamps + 192 + (i)) = __builtin_readcyclecounter(); } while (0)
+#ifndef BWD2_SPLIT_ATOMICS
+#define BWD2_SPLIT_ATOMICS 0       // 1: the 16 class-table atomics of a tile are issued 8 in phase B, 8 in phase C (measured 456 against 449 us); 0: all 16 in phase B
+#endif
+#define BWD2_ATOMICS(T, PART)                                                                                                      \
+      if (DTAB && !(BWD2_ABL & 1)) {                                                                                               \
+        _Pragma("unroll") for (int gq = (PART); gq < (BWD2_SPLIT_ATOMICS ? (PART) + 1 : ((PART) == 0 ? 2 : 0)); ++gq) {             \
+          const int q0 = 32 * (T) + 16 * gq;                                                                                       \
+          uint32_t* b = ((q0 % GW) == 16 ? dbB : dbA) + U56(q0);                                                                   \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                            \
+            (void)__hip_atomic_fetch_add(b + e, __float_as_uint(fx[4 * gq + (e >> 1)][e & 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        }                                                                                                                          \
+      }
 #define BWD2_TILE(T, OCUR, ONEXT)                                                                                                  \
     {                                                                                                                              \
       BWD2_TST(3 * (T));                                                                                                           \
@@ -299,18 +311,12 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
         fx[r2] = __builtin_elementwise_fma(p2, d2, f32x2{MAGIC2, MAGIC2});                                                         \
         pr[2 * r2] = p2[0]; pr[2 * r2 + 1] = p2[1]; ds[2 * r2] = s2[0]; ds[2 * r2 + 1] = s2[1];                                     \
       }                                                                                                                            \
-      if (DTAB && !(BWD2_ABL & 1)) {                                                                                               \
-        _Pragma("unroll") for (int gq = 0; gq < 2; ++gq) {                                                                         \
-          const int q0 = 32 * (T) + 16 * gq;                                                                                       \
-          uint32_t* b = ((q0 % GW) == 16 ? dbB : dbA) + U56(q0);                                                                   \
-          _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                            \
-            (void)__hip_atomic_fetch_add(b + e, __float_as_uint(fx[4 * gq + (e >> 1)][e & 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        }                                                                                                                          \
-      }                                                                                                                            \
+      BWD2_ATOMICS(T, 0)                                           /* first half of the class-table scatter here, second half in phase C */ \
       if ((T) + 2 < HT) req_rows<((T) + 2 < HT ? (T) + 2 : 0), TAB>(dyn, ln, tbA, tbB, OCUR);                                      \
       BWD2_SB();                                                                                                                   \
       BWD2_TST(3 * (T) + 1);                                                                                                       \
       const Frag pf = pack(pr), dsf = pack(ds);                                                                                    \
+      BWD2_ATOMICS(T, 1)                                                                                                           \
       if (!(BWD2_ABL & 16)) {                                                                                                      \
         dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf.v[0], pf.v[0], dvacc, 0, 0, 0);                                       \
         dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf.v[0], dsf.v[0], dkacc, 0, 0, 0);                                       \
@@ -434,7 +440,29 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   }
 
   // ---- dQ: the two key halves combine through LDS (the slabs are dead: everybody is past the tile loop after this barrier).  Of the nine
-  // tiles of a query half the kh = 0 wave finishes the even ones, the kh = 1 wave the odd ones: each wave hands over the tiles it does not finish
+  // tiles of a query half the kh = 0 wave finishes the even ones, the kh = 1 wave the odd ones: each wave hands over the tiles it does not finish.
+  // The global operands of the q un-prep (q~ rows, inverse norms, q_scale) are requested HERE, in front of the two barriers, not behind them.
+  u32x4 pqa[5], pqb[5];
+  float piq[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int j = kh + 2 * m < HT ? kh + 2 * m : kh;             // (kh = 1 finishes four tiles: the fifth slot re-reads its first)
+    const int qrow = (qh * HT + j) * 32 + ar;
+    const bf16_t* qp = a.q + (int64_t)qrow * D;
+    pqa[m] = *GLB(const u32x4, qp + 8 * half); pqb[m] = *GLB(const u32x4, qp + 16 + 8 * half);
+    piq[m] = *GLB(const float, a.qinv + (int64_t)qrow * a.H);
+  }
+  float qsv[16], rqv[16], qsacc[16];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float qs_ = *GLB(const float, a.q_scale + 16 * gq + 8 * half + e);
+      const float qc = qs_ * a.c;
+      qsv[8 * gq + e] = qs_;
+      rqv[8 * gq + e] = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
+      qsacc[8 * gq + e] = 0.f;
+    }
   __syncthreads();
   BWD2_ST(4);
   char* red = dyn + OFF_RED;
@@ -450,17 +478,6 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   BWD2_ST(5);
   // un-prep of q (attn_unprep_kernel of attn2.hip / bwd1_unprep_q): u = q~ / (q_scale c), g = dq^ q_scale, dq = qinv (g - u (u . g)), dscale += dq^ u on
   // the bf16-rounded dq^.  Lane n of the transposed product holds query pi32(n & 31), registers = head dims 16 gq + 8 half + e.
-  float qsv[16], rqv[16], qsacc[16];
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float qs_ = *GLB(const float, a.q_scale + 16 * gq + 8 * half + e);
-      const float qc = qs_ * a.c;
-      qsv[8 * gq + e] = qs_;
-      rqv[8 * gq + e] = fabsf(qc) > 1e-30f ? 1.f / qc : 0.f;
-      qsacc[8 * gq + e] = 0.f;
-    }
   const float scq = a.c * LN2 * a.invK;
 #pragma unroll
   for (int j = 0; j < HT; ++j) {
@@ -468,9 +485,8 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       const int tq = qh * HT + j;
       const float* src = reinterpret_cast<const float*>(red + tq * 4096) + lane * 4;
       const int qrow = tq * 32 + ar;
-      const float iq = *GLB(const float, a.qinv + (int64_t)qrow * a.H);
-      const bf16_t* qp = a.q + (int64_t)qrow * D;
-      const u32x4 qa = *GLB(const u32x4, qp + 8 * half), qb = *GLB(const u32x4, qp + 16 + 8 * half);
+      const float iq = piq[j >> 1];                                // (j = kh + 2 m: slot m = j >> 1 for either parity)
+      const u32x4 qa = pqa[j >> 1], qb = pqb[j >> 1];
       float qx[16], g16[16];
       unpack8v(qa, qx); unpack8v(qb, qx + 8);
       float part[2] = {0.f, 0.f};
@@ -544,8 +560,9 @@ __device__ __noinline__ float bwd2_load(Load2 a_) {
     };
     float mxd = 0.f, mxv = 0.f;
     float ols[NP2];
-    // three batches of three pieces (twelve 16-byte loads in flight per thread): with all 36 in flight the allocator of this kernel -- whose
-    // budget is what the 512-register tile function leaves -- spilled them, and the load phase took 20 us instead of 7 in some builds
+    // three batches of three pieces (twelve 16-byte loads in flight per thread).  All 36 in flight at once measured SLOWER (6.8-8.8 us against
+    // 4.6-5.2: `profiles/r06_attn_bwd2.md`); inlined into the kernel, whose allocator has what the 512-register tile function leaves, they were
+    // spilled in some builds (20 us) -- hence a function of its own.
 #pragma unroll
     for (int k0 = 0; k0 < NP2; k0 += 3) {
       u32x4 oq[3], ov_[3], od[3], oo[3];
@@ -658,13 +675,16 @@ __global__ __launch_bounds__(NTH2) void bwd2_kernel(Params p, ctclip_attn2::Bwd2
     // ---------------------------------------------------------------------------------------------- flush the class table
     if (DTAB) {
       float* dst = x.dtpart + (((int64_t)wgh * x.ipw + it) * p.H + h) * NCLS;
-      for (int i = tid; i < NCLS; i += NTH2) {
-        const int dyi = i / TROWS, dxi = i - dyi * TROWS, pi = dyi * TS + dxi;
-        const int ady = dyi - (GW - 1), adx = dxi - (GW - 1);
-        const uint32_t cnt = (uint32_t)((GW - (ady < 0 ? -ady : ady)) * (GW - (adx < 0 ? -adx : adx)));
-        const int32_t v = (int32_t)(dtab[pi] - cnt * MAGIC2_BITS);
-        dst[i] = (float)v * invK;
-        dtab[pi] = 0u;
+      for (int dyi = wave; dyi < TROWS; dyi += NW2) {                 // a wave per table row, a lane per column: no integer division
+        const int dxi = lane;
+        if (dxi < TROWS) {
+          const int pi = dyi * TS + dxi;
+          const int ady = dyi - (GW - 1), adx = dxi - (GW - 1);
+          const uint32_t cnt = (uint32_t)((GW - (ady < 0 ? -ady : ady)) * (GW - (adx < 0 ? -adx : adx)));
+          const int32_t v = (int32_t)(dtab[pi] - cnt * MAGIC2_BITS);
+          dst[dyi * TROWS + dxi] = (float)v * invK;
+          dtab[pi] = 0u;
+        }
       }
     }
     __syncthreads();
