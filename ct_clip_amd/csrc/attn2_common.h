@@ -117,6 +117,21 @@ __device__ __forceinline__ Frag lds_cols(const char* tile, const TrOff& tr) {
 }
 
 
+// The same transposed fragment through the compiler's builtin (round 6): the loads are visible to the scheduler and to the wait-count insertion --
+// no full `lgkmcnt(0)` drain in front of the consumer, and the reads can be hoisted above unrelated work.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Frag lds_cols_b(const char* tile, const TrOff& tr) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + tr.o[0]));
+  const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + tr.o[1]));
+  const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + 1024 + tr.o[0]));
+  const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + 1024 + tr.o[1]));
+  Frag f;
+  f.v[0] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+  f.v[1] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+  return f;
+}
+
 // ---- per-workgroup preamble: stage the bias table of head h (log2 domain) and the token -> offset-class index, and derive the
 // logit bound.  All threads of the workgroup must call it.  Returns M2 (log2-domain bound folded into the staged table when safe).
 template <int NC, int NL>

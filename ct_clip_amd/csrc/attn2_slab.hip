@@ -27,6 +27,9 @@
 #ifndef ATTN2_ABL
 #define ATTN2_ABL 0
 #endif
+#ifndef ATTN2_FWD_TRB
+#define ATTN2_FWD_TRB 1      // 1: the forward reads V^T through the builtin transposing read (compiler-counted waits); 0: the inline-asm form + lgkmcnt(0)
+#endif
 
 namespace {
 
@@ -196,13 +199,24 @@ __device__ __forceinline__ void fwd_unit(const Params& p, const SRel& rel, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[ch][r] = 0.f;
   }
+#ifndef ATTN2_FWD_PIPE
+#define ATTN2_FWD_PIPE 0     // 1: K^ / V^T fragments and the bias tile of key tile t + 1 are requested behind the Q K^T products of tile t (round 6: measured 145-149 against 143.6-145 us, 256 registers + 12 B of scratch -- off)
+#endif
+  Frag kf_n, vf_n;
+  f32x16 s_n[NCH];
+  if (ATTN2_FWD_PIPE) {
+    kf_n = lds_rows(kslab, ar, half);
+    vf_n = lds_cols_b(vslab, tr);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) s_n[ch] = sbias<true, TAB && !(ATTN2_ABL & 16)>(rel, g, ucol[ch], 0, half);
+  }
   for (int t = 0; t < nkb; ++t) {
     const char* ktile = kslab + t * TILE;
     const char* vtile = vslab + t * TILE;
-    const Frag kf = lds_rows(ktile, ar, half);
+    const Frag kf = ATTN2_FWD_PIPE ? kf_n : lds_rows(ktile, ar, half);
     f32x16 s[NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) s[ch] = sbias<true, TAB && !(ATTN2_ABL & 16)>(rel, g, ucol[ch], t * 32, half);
+    for (int ch = 0; ch < NCH; ++ch) s[ch] = ATTN2_FWD_PIPE ? s_n[ch] : sbias<true, TAB && !(ATTN2_ABL & 16)>(rel, g, ucol[ch], t * 32, half);
     if (!(ATTN2_ABL & 8)) {     // the chains' dependent MFMA pairs interleaved: a0 b0 a1 b1
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) s[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v[0], qf[ch].v[0], s[ch], 0, 0, 0);
@@ -212,7 +226,15 @@ __device__ __forceinline__ void fwd_unit(const Params& p, const SRel& rel, const
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) s[ch][0] += __builtin_bit_cast(float, (uint32_t)kf.v[0][0] << 16) * 1e-30f;
     }
-    const Frag vf = lds_cols(vtile, tr);
+    const Frag vf = ATTN2_FWD_PIPE ? vf_n : (ATTN2_FWD_TRB ? lds_cols_b(vtile, tr) : lds_cols(vtile, tr));
+    if (ATTN2_FWD_PIPE) {                                        // the next key tile's operands (the last tile re-reads itself: no branch)
+      const int tn = t + 1 < nkb ? t + 1 : t;
+      kf_n = lds_rows(kslab + tn * TILE, ar, half);
+      vf_n = lds_cols_b(vslab + tn * TILE, tr);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) s_n[ch] = sbias<true, TAB && !(ATTN2_ABL & 16)>(rel, g, ucol[ch], tn * 32, half);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     Frag pf[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
