@@ -61,7 +61,7 @@
 // instructions of that epilogue).  Measured +1..3 % on the GEMMs (profiles/r02_gemm_epilogue_experiments.md) and bit-identical results in
 // 60 of 60 full-geometry training steps -- but it needs loads and stores to RETIRE IN ISSUE ORDER RELATIVE TO EACH OTHER (the panels it
 // waits for are OLDER than the stores it no longer waits for), which the old vmcnt(GL) does not.  OFF until that order is settled (a rare
-// run-to-run difference of the bf16 step is open).
+// run-to-run difference of the bf16 step was open then; located and fixed in round 3: HISTORY.md section 4).
 #define NT_COUNTED_EPI 0
 #endif
 

@@ -12,7 +12,7 @@
 //     stages = 80 KB.  192 divides the token counts of the image tower (13 824 per volume); N = 128 keeps the "lane owns eight
 //     consecutive columns" epilogue (one 16-byte store per row and lane).  Per 256 x 256-equivalent of work a CU loads 1.67x the operand
 //     bytes of the first form (both from L2 in the steady state); whether the vector-memory port carries that was argued on paper for two
-//     rounds -- this kernel is the measurement.
+//     rounds (HISTORY.md section 8) -- this kernel is the measurement.
 //   * waves 4 x 1: wave w owns rows [48 w, 48 w + 48) x all 128 columns = 3 x 8 fragments of mfma_f32_16x16x32_bf16 (96 accumulators).
 //   * double buffering with ONE barrier per k-step, placed after the first third of the step's second sub-step: the remaining 16 MFMAs
 //     cover the fragment reads of the next step and the issue of the step after next's LDS-DMA pieces.  The panel stream is continuous

@@ -3,7 +3,7 @@
 // HF BertModel at batch 8 / 128 tokens is 72 forward GEMMs of 1.2 - 4.8 GFLOP (M = 1 024, N in {768, 2 304, 3 072}, K in {768, 3 072}) and
 // twice that backward.  gemm_nt.hip / gemm_tn.hip decline them (a handful of 256 x 256 tiles does not fill 256 CUs) and the generic 128 x 128
 // kernel of gemm.hip ran them at 27 - 107 TFLOP/s: 45 - 80 us per launch, 11.4 ms of kernel time per step on the text tower's side stream,
-// where they take CUs and L2 away from the image tower for most of the step.  This kernel is built for THAT
+// where they take CUs and L2 away from the image tower for most of the step (HISTORY.md section 8 item 6).  This kernel is built for THAT
 // size: one tile per workgroup, no persistence, 4 waves (2 x 2), tile 128 x 128 when that still gives >= 120 workgroups, else 64 x 64
 // (so that N = 768 at M = 1 024 is 192 workgroups, not 48), operands by LDS-DMA into a ring of 3 (128 x 128: 96 KB) or 4 (64 x 64: 64 KB)
 // stages of one k-step (64 bf16 = one 128-byte line per row), ONE barrier per k-step, fragment reads through inline asm with explicit

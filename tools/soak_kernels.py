@@ -115,7 +115,7 @@ soak("attn2_bwd_tok + unprep_q (round 3: key pass writes row-major dk / dv)",
                                       dks2.zero_(), nseq, L, True))[:1] + [dq_t, dkv_t, dqs2, dks2])
 dq_f, dkv_f = torch.empty(nseq * L, 256, dtype=bf, device=dev), torch.empty(nseq * L, 512, dtype=bf, device=dev)
 dqs3, dks3 = torch.zeros(Dh, device=dev), torch.zeros(Dh, device=dev)
-soak("attn2_bwd_fused (round 4: one pass, LDS tile counters, fixed-point table scatter)",
+soak("attn2_bwd_fused (round 6: four-wave form attn2_bwd2 at L = 576; fixed-point table scatter)",
      lambda: as_list(be.attn2_bwd_fused(qh, kh, vh, tab, (24, 24), qs, ks, 8.0, o, do, lse2, qinv, kinv, dq_f, dkv_f[:, :256], dkv_f[:, 256:], dqs3.zero_(),
                                         dks3.zero_(), nseq, L, True)) + [dq_f, dkv_f, dqs3, dks3])
 w_qn, w_kvn = rnd(256, 512, scale=0.05), rnd(512, 512, scale=0.05)
