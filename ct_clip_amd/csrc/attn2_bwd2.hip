@@ -218,6 +218,40 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   uint32_t touch = 0u;
+  // this lane's key: class offsets.  Bias / class entry of (query q, key k) = U56(q) - U56(k) + C0; for the 8 consecutive queries of register
+  // group gq of tile T: U56(32 T + 16 gq) + half * (8, or 8 + 32 when the eight sit behind an image-row end) + e  -- immediates on two bases
+  const float *tbA, *tbB;
+  uint32_t *dbA, *dbB;
+  auto block_bases = [&](int kb_) {
+    const int tk = kb_ * 32 + c;
+    const int trow = (tk * 2731) >> 16;                          // tk / 24 (tk < 576)
+    const int ucol = trow * TS + (tk - trow * GW);
+    const int cbase = C0 - ucol + qh * (HT * 32 / GW) * TS;      // (+ the query half: 288 tokens = 12 image rows)
+    const float* tb0 = reinterpret_cast<const float*>(dyn + ((cbase & 1) ? OFF_TAB1 : OFF_TAB));     // (all of a lane's gather indices have the parity of cbase)
+    tbA = tb0 + (TAB ? cbase + half * 8 : 0);
+    tbB = tb0 + (TAB ? cbase + half * 40 : 0);
+    dbA = reinterpret_cast<uint32_t*>(dyn + OFF_DTAB) + cbase + half * 8;
+    dbB = reinterpret_cast<uint32_t*>(dyn + OFF_DTAB) + cbase + half * 40;
+  };
+  Ops2 o0, o1;                                                   // row operands of the next two tiles (alternating)
+  f32x16 sc, dp;                                                 // S and dP of the CURRENT tile (computed one tile ahead)
+  auto m1 = [&](Ops2& o, const Frag& kf_, const Frag& vf_, f32x16& s_, f32x16& d_) {      // S = Q~ K^^T + bias + (log2 K - lse2), dP = dO V^T - delta
+    f32x16 cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.trp, ln.onesA, zero16, 0, 0, 0);
+    f32x16 cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.trp, ln.onesB, o.cb, 0, 0, 0);
+    cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.qf.v[0], kf_.v[0], cs, 0, 0, 0);
+    cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.dof.v[0], vf_.v[0], cd, 0, 0, 0);
+    s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.qf.v[1], kf_.v[1], cs, 0, 0, 0);
+    d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.dof.v[1], vf_.v[1], cd, 0, 0, 0);
+  };
+  // The PROLOGUE of a key block -- row operands of its first two tiles, S / dP of its first tile -- is issued at the END of the previous block, in
+  // front of that block's park / merge code (two LDS round trips and six matrix instructions that nothing else covered: ~0.2 us per block)
+  auto block_prologue = [&](int kb_) {
+    block_bases(kb_);
+    req_rows<0, TAB>(dyn, ln, tbA, tbB, o0);
+    req_rows<1, TAB>(dyn, ln, tbA, tbB, o1);
+    m1(o0, kn, vn, sc, dp);
+  };
+  block_prologue(kh * HT);
   for (int kbi = 0; kbi < HT; ++kbi) {
     const int kb = kh * HT + kbi;
     BWD2_BST(3 * kbi);
@@ -235,17 +269,6 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       const int64_t stride = sg == 3 ? a.lddo * 2 : (sg == 4 ? a.ldo * 2 : 128);
       touch = *GLB(const uint32_t, base + (int64_t)r * stride);
     }
-    // this lane's key: class offsets.  Bias / class entry of (query q, key k) = U56(q) - U56(k) + C0; for the 8 consecutive queries of register
-    // group gq of tile T: U56(32 T + 16 gq) + half * (8, or 8 + 32 when the eight sit behind an image-row end) + e  -- immediates on two bases
-    const int tk = kb * 32 + c;
-    const int trow = (tk * 2731) >> 16;                          // tk / 24 (tk < 576)
-    const int ucol = trow * TS + (tk - trow * GW);
-    const int cbase = C0 - ucol + qh * (HT * 32 / GW) * TS;      // (+ the query half: 288 tokens = 12 image rows)
-    const float* tb0 = reinterpret_cast<const float*>(dyn + ((cbase & 1) ? OFF_TAB1 : OFF_TAB));     // (all of a lane's gather indices have the parity of cbase)
-    const float* tbA = tb0 + (TAB ? cbase + half * 8 : 0);
-    const float* tbB = tb0 + (TAB ? cbase + half * 40 : 0);
-    uint32_t* dbA = reinterpret_cast<uint32_t*>(dyn + OFF_DTAB) + cbase + half * 8;
-    uint32_t* dbB = reinterpret_cast<uint32_t*>(dyn + OFF_DTAB) + cbase + half * 40;
     // K^T of the block (A operand of dQ^T = K^T dS^T): through the wave's scratch
     Frag ktf;
     if (!(BWD2_ABL & 2)) {
@@ -255,20 +278,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
     }
     f32x16 dkacc = zero16, dvacc = zero16;
 
-    // ---- the sweep over the nine query tiles of this wave, software-pipelined (see the file header)
-    Ops2 o0, o1;                                                 // row operands of the next two tiles (alternating)
-    f32x16 sc, dp;                                               // S and dP of the CURRENT tile (computed one tile ahead)
-    req_rows<0, TAB>(dyn, ln, tbA, tbB, o0);
-    req_rows<1, TAB>(dyn, ln, tbA, tbB, o1);
-    auto m1 = [&](Ops2& o, f32x16& s_, f32x16& d_) {             // S = Q~ K^^T + bias + (log2 K - lse2), dP = dO V^T - delta
-      f32x16 cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.trp, ln.onesA, zero16, 0, 0, 0);
-      f32x16 cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.trp, ln.onesB, o.cb, 0, 0, 0);
-      cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.qf.v[0], kf.v[0], cs, 0, 0, 0);
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.dof.v[0], vf.v[0], cd, 0, 0, 0);
-      s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.qf.v[1], kf.v[1], cs, 0, 0, 0);
-      d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.dof.v[1], vf.v[1], cd, 0, 0, 0);
-    };
-    m1(o0, sc, dp);
+    // ---- the sweep over the nine query tiles of this wave, software-pipelined (see the file header); o0, o1, sc, dp were prepared by block_prologue
 
 #define BWD2_SB() __builtin_amdgcn_sched_barrier(0)
     // Three phases per tile, pinned by scheduling barriers.  Why: ONE wave per SIMD issues an instruction every ~5 cycles at best
@@ -300,7 +310,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       if (!(BWD2_ABL & 2) && (T) > 0) dstf = cols2(scr, ln.tr);                                                                    \
       BWD2_SB();                                                                                                                   \
       f32x16 sc2, dp2;                                                                                                             \
-      if ((T) + 1 < HT) m1(ONEXT, sc2, dp2);                                                                                       \
+      if ((T) + 1 < HT) m1(ONEXT, kf, vf, sc2, dp2);                                                                               \
       float pr[16], ds[16];                                                                                                        \
       f32x2 fx[8];                                                 /* packed f32 arithmetic: the single wave of a SIMD is ISSUE-bound */ \
       _Pragma("unroll") for (int r2 = 0; r2 < 8; ++r2) {                                                                           \
@@ -349,6 +359,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       dq[HT - 1] = mma(dq[HT - 1], ktf, dstf);
     }
 
+    if (kbi + 1 < HT) block_prologue(kb + 1);                    // (kn / vn = the next block's rows, requested at the top of this block)
     BWD2_BST(3 * kbi + 1);
     // ---- end of the key block: the two query halves combine.  Blocks alternate: (kbi + kh) odd -> the qh = 1 wave parks and the qh = 0 wave
     // merges, even -> the other way round (each wave un-preps 4 or 5 of its 9 blocks)
