@@ -290,6 +290,9 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
     // (Prescribing the instruction mix of B and C with sched_group_barrier -- one matrix instruction per six vector and five LDS instructions --
     // measured 3-5 % SLOWER than leaving the order inside a phase to the scheduler: profiles/r06_attn_bwd2.md.)
 #define BWD2_TST(i) do { if (BWD2_TSTAMPS && a.bstamps && kbi == 1 && a.seq0 == 0 && threadIdx.x == 0) *GLB(unsigned long long, a.bstamps + 192 + (i)) = __builtin_readcyclecounter(); } while (0)
+#ifndef BWD2_DQ_IN_B
+#define BWD2_DQ_IN_B 0             // 1: the two dQ^T matrix instructions of tile T - 1 are issued in phase B of tile T (8 + 4 instead of 6 + 6 per phase): 480-491 against 444-445 us
+#endif
 #ifndef BWD2_SPLIT_ATOMICS
 #define BWD2_SPLIT_ATOMICS 0       // 1: the 16 class-table atomics of a tile are issued 8 in phase B, 8 in phase C (measured 456 against 449 us); 0: all 16 in phase B
 #endif
@@ -323,6 +326,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
       }                                                                                                                            \
       BWD2_ATOMICS(T, 0)                                           /* first half of the class-table scatter here, second half in phase C */ \
       if ((T) + 2 < HT) req_rows<((T) + 2 < HT ? (T) + 2 : 0), TAB>(dyn, ln, tbA, tbB, OCUR);                                      \
+      if (BWD2_DQ_IN_B && !(BWD2_ABL & 2) && (T) > 0) dq[(T) > 0 ? (T) - 1 : 0] = mma(dq[(T) > 0 ? (T) - 1 : 0], ktf, dstf);       \
       BWD2_SB();                                                                                                                   \
       BWD2_TST(3 * (T) + 1);                                                                                                       \
       const Frag pf = pack(pr), dsf = pack(ds);                                                                                    \
@@ -336,7 +340,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
         _Pragma("unroll") for (int r = 0; r < 16; ++r) { dvacc[r] += pr[r]; dkacc[r] += ds[r]; }                                   \
       }                                                                                                                            \
       if (!(BWD2_ABL & 2)) {                                                                                                       \
-        if ((T) > 0) dq[(T) > 0 ? (T) - 1 : 0] = mma(dq[(T) > 0 ? (T) - 1 : 0], ktf, dstf);                                         \
+        if (!BWD2_DQ_IN_B && (T) > 0) dq[(T) > 0 ? (T) - 1 : 0] = mma(dq[(T) > 0 ? (T) - 1 : 0], ktf, dstf);                        \
         *reinterpret_cast<bf16x8*>(scr + swz(c, half)) = dsf.v[0];                                                                 \
         *reinterpret_cast<bf16x8*>(scr + swz(c, 2 + half)) = dsf.v[1];                                                             \
       }                                                                                                                            \
