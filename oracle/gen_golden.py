@@ -502,6 +502,82 @@ def run_finetune_case(name="finetune_tiny", base="tiny"):
           f"({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def run_finetune_full_case(name="finetune_full", c=FULL_CASE, grad_limit=3000):
+    """The two fine-tuning loops at the FULL geometry (BASELINE configs[3] / configs[4]: 480 x 480 x 240, patch 20 x 20 x 10, dim 512, the
+    reference scripts' 4+4 layers, BERT-base, T = 128) on the REAL reference towers -- same seed, weights and inputs as full1.pt (the tests rebuild
+    them from the seeds and check full1's fingerprints).  LiPro: B = 2 (ct_lipro_train.py:17-38,79-107, dropout 0 for a deterministic fixture);
+    VocabFine: one volume, four pathologies in two groups (ct_vocabfine_train.py:88-121): every gradient of the end-to-end step."""
+    import time
+    import torch.nn.functional as F
+    t0 = time.time()
+    out = {"config": c}
+    video, ids, mask = synth_inputs(c)
+    dev = torch.device("cpu")
+    clip, _, _ = build(c)
+    sd0 = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    g = torch.Generator().manual_seed(17)
+    ncls = 18
+    W = torch.randn(ncls, c["dim_latent"], generator=g) * 0.2
+    bvec = torch.randn(ncls, generator=g) * 0.1
+    labels = (torch.rand(c["batch"], ncls, generator=g) < 0.3).float()
+    pos_weight = torch.rand(ncls, generator=g) * 8 + 1
+    blank = ref_shim.TextBatch(ids[:1], mask[:1])
+    for prm in clip.parameters():
+        prm.requires_grad = False
+    Wp, bp = W.clone().requires_grad_(True), bvec.clone().requires_grad_(True)
+    clip.train()
+    _, lat, _ = clip(blank, video, device=dev, return_latents=True)
+    logits = F.linear(F.dropout(F.relu(lat), 0.0), Wp, bp)
+    loss = F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pos_weight)
+    loss.backward()
+    sd1 = clip.state_dict()
+    out["lipro"] = dict(W=W, b=bvec, labels=labels, pos_weight=pos_weight, latents=lat.detach().clone(), logits=logits.detach().clone(),
+                        loss=loss.detach().clone(), dW=Wp.grad.clone(), db=bp.grad.clone(),
+                        vq_after={"visual_transformer.vq._codebook.cluster_size": sd1["visual_transformer.vq._codebook.cluster_size"].detach().clone(),
+                                  "visual_transformer.vq._codebook.embed": subsample(sd1["visual_transformer.vq._codebook.embed"], 50000)})
+    print(f"[{name}] lipro done, loss {float(loss):.6f} ({time.time() - t0:.0f} s)", flush=True)
+
+    # ---- VocabFine (fresh weights: the LiPro forward moved the VQ buffers)
+    clip.load_state_dict(sd0)
+    for prm in clip.parameters():
+        prm.requires_grad = True
+    clip.zero_grad(set_to_none=True)
+    clip.train()
+    npath, group = 4, 2
+    T = c["T"]
+    pid = torch.randint(3, c["vocab"], (npath, 2, T), generator=g)
+    plen = torch.randint(T // 2, T + 1, (npath, 2), generator=g)
+    pmask = (torch.arange(T)[None, None, :] < plen[..., None]).long()
+    pid = pid * pmask
+    pid[..., 0] = 1
+    vol = video[:1]
+    losses, sims_all = [], []
+    for k in range(0, npath, group):
+        sims = []
+        for l in range(k, k + group):
+            sims.append(clip(ref_shim.TextBatch(pid[l], pmask[l]), vol, device=dev))     # ct_vocabfine_train.py:110
+        probs = [F.softmax(o, dim=0) for o in sims]
+        target = torch.tensor([1.0, 0.0]).repeat(len(probs))
+        loss = F.mse_loss(torch.cat(probs, dim=0), target)
+        loss.backward()
+        losses.append(loss.detach().clone())
+        sims_all.append(torch.stack([o.detach() for o in sims]))
+        print(f"[{name}] vocabfine group {k // group} done ({time.time() - t0:.0f} s)", flush=True)
+    grads = {k: subsample(p.grad, grad_limit) for k, p in clip.named_parameters() if p.grad is not None}
+    for k, p in clip.named_parameters():
+        if p.grad is not None:
+            grads[k]["norm"] = p.grad.detach().norm().clone()
+    grad_sq = sum(float((p.grad.double() ** 2).sum()) for p in clip.parameters() if p.grad is not None)
+    sd1 = clip.state_dict()
+    out["vocabfine"] = dict(prompt_ids=pid, prompt_mask=pmask, group=group, sims=sims_all, losses=losses, grads=grads,
+                            grad_norm=torch.tensor(grad_sq).sqrt().float(),
+                            vq_after={"visual_transformer.vq._codebook.cluster_size": sd1["visual_transformer.vq._codebook.cluster_size"].detach().clone()})
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(out, path)
+    print(f"{name}: lipro loss {float(out['lipro']['loss']):.6f}, vocabfine losses {[round(float(x), 6) for x in losses]}, grad norm "
+          f"{float(out['vocabfine']['grad_norm']):.6f} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 PREPROCESS_CASES = {
     # name: (seed, (H, W, D), source dtype, slope, intercept, XYSpacing, ZSpacing)
     "pad": (11, (200, 180, 90), "int16", 1.0, -1024.0, 1.1, 2.5),          # resampled (293, 264, 150): padded on every axis
@@ -619,5 +695,7 @@ if __name__ == "__main__":
             run_full8_bwd_case()
         elif name == "finetune_tiny":
             run_finetune_case()
+        elif name == "finetune_full":
+            run_finetune_full_case()
         else:
             run_case(name, CASES[name])
