@@ -123,11 +123,71 @@ __device__ __forceinline__ void rel_stage(RelLds& rel, const AttnParams& p, int 
   __syncthreads();
 }
 
-// multiplier of attention probability (seq, h, qi, kj) under dropout: a pure function of the seed and the linear index
-// (ctclip_attn_dropout_mask materialises the same values), so forward, dQ and dK/dV regenerate identical masks
-__device__ __forceinline__ float attn_drop(const AttnParams& p, int seq, int h, int qi, int kj) {
-  const uint64_t lin = (((uint64_t)seq * p.H + h) * p.L + qi) * p.L + kj;
-  return dropout_mult(philox4x32(p.drop_seed + (p.drop_state ? p.drop_state[0] : 0ull), lin, 0u)[0], p.drop_p, p.drop_inv_keep);
+// multipliers of the attention probabilities under dropout (common.h attn_drop_block: one Philox call per 2 queries x 4 keys; ctclip_attn_dropout_mask
+// materialises the same values), so forward, dQ and dK / dV regenerate identical masks.
+// Every block is needed by several lanes of a quad: each lane draws its share and the words travel by DPP quad permutes (a Philox call is ~40
+// quarter-rate multiplies, a permute one vector move).
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+// drop_keys: lane = ONE query qi (clamped; lane c <-> query block * 32 + c), registers = keys kb * 32 + slot_index(r, half).  The tile has four
+// key quads per lane; the two lanes of a query PAIR (c, c ^ 1) need the same four blocks: each draws two (quads 2 s + (c & 1)) and swaps: 2 calls per tile.
+__device__ __forceinline__ void drop_keys(float (&dm)[16], const AttnParams& p, int seq, int h, int qi, int kb, int half) {
+  const uint64_t seed = p.drop_seed + (p.drop_state ? p.drop_state[0] : 0ull);
+  const uint32_t thr = attn_drop_threshold(p.drop_p);
+  const int64_t sh = (int64_t)seq * p.H + h;
+  const int par = (int)(threadIdx.x & 1);          // = qi & 1 for unclamped rows (a clamped row is never stored)
+  u32x4 own[2], oth[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    const int g = 2 * s_ + par;                    // key quad 16 (g >> 1) + 8 half + 4 (g & 1) of the tile
+    int k0 = kb * 32 + 16 * (g >> 1) + 8 * half + 4 * (g & 1);
+    k0 = k0 < p.L ? k0 : ((p.L - 1) & ~3);         // (keys past L are masked by the callers: any block in range will do)
+    own[s_] = attn_drop_block(seed, sh, p.L, qi, k0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) oth[s_][w] = quad_perm<0xB1>(own[s_][w]);      // the neighbour's block: quad 2 s + (1 - par)
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int s_ = g >> 1;
+    const bool mine = (g & 1) == par;
+    // this query's two words of block g: (qi & 1) * 2 + {0, 1}
+    const uint32_t lo = mine ? (par ? own[s_][2] : own[s_][0]) : (par ? oth[s_][2] : oth[s_][0]);
+    const uint32_t hi = mine ? (par ? own[s_][3] : own[s_][1]) : (par ? oth[s_][3] : oth[s_][1]);
+    const int r0 = 8 * (g >> 1) + 4 * (g & 1);
+    dm[r0 + 0] = (lo & 0xffffu) >= thr ? p.drop_inv_keep : 0.f;
+    dm[r0 + 1] = (lo >> 16) >= thr ? p.drop_inv_keep : 0.f;
+    dm[r0 + 2] = (hi & 0xffffu) >= thr ? p.drop_inv_keep : 0.f;
+    dm[r0 + 3] = (hi >> 16) >= thr ? p.drop_inv_keep : 0.f;
+  }
+}
+// drop_queries: lane = ONE key kj (clamped; lane c <-> key block * 32 + c), registers = queries qb * 32 + slot_index(r, half).  The tile has eight
+// query pairs per lane; the four lanes of a key QUAD need the same eight blocks: each draws two (pairs 2 (c & 3) + s) and broadcasts: 2 calls per tile.
+__device__ __forceinline__ void drop_queries(float (&dm)[16], const AttnParams& p, int seq, int h, int kj, int qb, int half) {
+  const uint64_t seed = p.drop_seed + (p.drop_state ? p.drop_state[0] : 0ull);
+  const uint32_t thr = attn_drop_threshold(p.drop_p);
+  const int64_t sh = (int64_t)seq * p.H + h;
+  const int cq = (int)(threadIdx.x & 3);           // = kj & 3 for unclamped keys
+  u32x4 own[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    const int g = 2 * cq + s_;                     // query pair 16 (g >> 2) + 8 half + 2 (g & 3) of the tile
+    int q0 = qb * 32 + 16 * (g >> 2) + 8 * half + 2 * (g & 3);
+    q0 = q0 < p.L ? q0 : ((p.L - 1) & ~1);
+    own[s_] = attn_drop_block(seed, sh, p.L, q0, kj);
+  }
+  const bool hiword = (cq >> 1) != 0, hihalf = (cq & 1) != 0;       // this key's word (kj & 3) >> 1 of a query row, its half kj & 1
+#define CTCLIP_DROPQ(G, CTRL)                                                                                         \
+  {                                                                                                                   \
+    const uint32_t a0 = quad_perm<CTRL>(own[(G) & 1][0]), a1 = quad_perm<CTRL>(own[(G) & 1][1]);                       \
+    const uint32_t b0 = quad_perm<CTRL>(own[(G) & 1][2]), b1 = quad_perm<CTRL>(own[(G) & 1][3]);                       \
+    const uint32_t w0 = hiword ? a1 : a0, w1 = hiword ? b1 : b0;       /* query row 0 / 1 of the pair */              \
+    const int r0 = 8 * ((G) >> 2) + 2 * ((G) & 3);                                                                    \
+    dm[r0] = (hihalf ? (w0 >> 16) : (w0 & 0xffffu)) >= thr ? p.drop_inv_keep : 0.f;                                   \
+    dm[r0 + 1] = (hihalf ? (w1 >> 16) : (w1 & 0xffffu)) >= thr ? p.drop_inv_keep : 0.f;                               \
+  }
+  // pair g is drawn by lane g >> 1 of the quad: quad_perm [o, o, o, o] = o * 0x55
+  CTCLIP_DROPQ(0, 0x00) CTCLIP_DROPQ(1, 0x00) CTCLIP_DROPQ(2, 0x55) CTCLIP_DROPQ(3, 0x55)
+  CTCLIP_DROPQ(4, 0xAA) CTCLIP_DROPQ(5, 0xAA) CTCLIP_DROPQ(6, 0xFF) CTCLIP_DROPQ(7, 0xFF)
+#undef CTCLIP_DROPQ
 }
 
 // scores of one 32x32 tile in "lane = column c, regs = rows slot_index(r, half)" layout -> logits
@@ -258,8 +318,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     lsum = lsum * alpha + ps;
     m = mnew;
     if (p.drop_p > 0.f) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+      float dm[16];
+      drop_keys(dm, p, seq, h, qic, kb, half);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pr[r] *= attn_drop(p, seq, h, qic, min(kb * 32 + slot_index(r, half), L - 1));
+      for (int r = 0; r < 16; ++r) pr[r] *= dm[r];
     }
     Frag<T, 32> pf;
     frag_from_regs(pf, pr);
@@ -347,11 +409,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     dp = mma(dp, vf, dof);
     float val[16], ds[16];
     tile_logits<true>(val, s, p, rel, seq, h, qi, kb * 32, half);
+    float dm[16];
+    if (p.drop_p > 0.f) drop_keys(dm, p, seq, h, qic, kb, half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kj = kb * 32 + slot_index(r, half);
       const float pr = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
-      const float dpr = p.drop_p > 0.f ? dp[r] * attn_drop(p, seq, h, qic, kj < L ? kj : L - 1) : dp[r];   // d(dropout(P)) / dP
+      const float dpr = p.drop_p > 0.f ? dp[r] * dm[r] : dp[r];   // d(dropout(P)) / dP
       ds[r] = pr * (dpr - delta);
     }
     Frag<T, 32> dsf;
@@ -523,13 +587,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     dp = mma(dp, dof, vf);
     float val[16], pr[16], ds[16];
     tile_logits<false>(val, s, p, rel, seq, h, kj, qb * 32, half);
+    float dmq[16];
+    if (p.drop_p > 0.f) drop_queries(dmq, p, seq, h, kjc, qb, half);
+    // the tile's row statistics: two runs of eight consecutive queries per lane -- four 16-byte loads each when L is a multiple of 8 (BERT: 128 / 512)
+    // instead of 32 scalar ones (round 6)
+    float lse16[16], del16[16];
+    if ((L & 7) == 0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int q0 = qb * 32 + 16 * g + 8 * half;
+        q0 = q0 < L ? q0 : L - 8;                  // (rows past L come in whole runs of eight: their probabilities are zeroed below)
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(p.lse + statbase + q0), l1 = *reinterpret_cast<const f32x4*>(p.lse + statbase + q0 + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.delta + statbase + q0), d1 = *reinterpret_cast<const f32x4*>(p.delta + statbase + q0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lse16[8 * g + e] = l0[e]; lse16[8 * g + 4 + e] = l1[e]; del16[8 * g + e] = d0[e]; del16[8 * g + 4 + e] = d1[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = qb * 32 + slot_index(r, half);
+        const int qc = qi < L ? qi : L - 1;
+        lse16[r] = p.lse[statbase + qc]; del16[r] = p.delta[statbase + qc];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = qb * 32 + slot_index(r, half);
       const int qc = qi < L ? qi : L - 1;
-      const float lse = p.lse[statbase + qc], delta = p.delta[statbase + qc];
+      const float lse = lse16[r], delta = del16[r];
       pr[r] = (qi < L && kj < L) ? __expf(val[r] - lse) : 0.f;
-      const float dm = p.drop_p > 0.f ? attn_drop(p, seq, h, qc, kjc) : 1.f;
+      const float dm = p.drop_p > 0.f ? dmq[r] : 1.f;
       ds[r] = pr[r] * (dp[r] * dm - delta);
       pr[r] *= dm;                                           // dV sees the dropped probabilities
     }

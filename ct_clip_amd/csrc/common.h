@@ -165,4 +165,22 @@ __device__ __forceinline__ u32x4 philox4x32(uint64_t seed, uint64_t index, uint3
 // keep-multiplier of one element: 0 with probability p, 1 / (1 - p) otherwise (u = top 24 bits / 2^24 >= p keeps)
 __device__ __forceinline__ float dropout_mult(uint32_t word, float p, float inv_keep) { return (float)(word >> 8) * (1.f / 16777216.f) >= p ? inv_keep : 0.f; }
 
+// Attention dropout, second form (round 6).  The first form drew ONE Philox call per probability (word 0 of philox(seed, linear index)): 40 quarter-rate
+// integer multiplies per score -- at BERT's T = 512 the three attention kernels spent > 90 % of their time in it (111 / 172 / 196 us per layer).  Now one
+// call decides a BLOCK of 2 queries x 4 keys with 16 bits each: block (sh = sequence * H + head, qi >> 1, kj >> 2) -> philox(seed, block index, stream 1);
+// element (qi & 1, kj & 3) = half (kj & 1) of word (qi & 1) * 2 + ((kj & 3) >> 1); kept when its 16 bits >= round(p * 65536).  The shape serves both
+// register layouts: a lane of the forward / dQ kernels holds runs of 8 keys of ONE query (2 blocks per run), a lane of the dK / dV kernel runs of 8
+// queries of ONE key (4 blocks per run).  A pure function of (seed, sh, qi, kj): ctclip_attn_dropout_mask and tests/ref_backend.py reproduce it.
+__device__ __forceinline__ u32x4 attn_drop_block(uint64_t seed, int64_t sh, int L, int qi, int kj) {
+  const uint64_t nq2 = (uint64_t)((L + 1) >> 1), nk4 = (uint64_t)((L + 3) >> 2);
+  return philox4x32(seed, ((uint64_t)sh * nq2 + (uint64_t)(qi >> 1)) * nk4 + (uint64_t)(kj >> 2), 1u);
+}
+__device__ __forceinline__ uint32_t attn_drop_threshold(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
+__device__ __forceinline__ float attn_drop_pick(const u32x4& w, int qi, int kj, uint32_t thr16, float inv_keep) {
+  const int wi = (qi & 1) * 2 + ((kj & 3) >> 1);
+  const uint32_t word = wi == 0 ? w[0] : (wi == 1 ? w[1] : (wi == 2 ? w[2] : w[3]));
+  const uint32_t u = (kj & 1) ? (word >> 16) : (word & 0xffffu);
+  return u >= thr16 ? inv_keep : 0.f;
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

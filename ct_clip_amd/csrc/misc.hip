@@ -258,10 +258,14 @@ __global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ re
     store4(y + i * 4, v);
   }
 }
-// the multiplier the attention kernels apply to probability (seq, h, i, j): word 0 of philox(seed, linear index, 0) -- for tests
-__global__ void attn_dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, float inv_keep, uint64_t seed) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    mask[i] = dropout_mult(philox4x32(seed, (uint64_t)i, 0u)[0], p, inv_keep);
+// the multiplier the attention kernels apply to probability (seq, h, i, j) (common.h attn_drop_block / attn_drop_pick) -- for tests
+__global__ void attn_dropout_mask_kernel(float* __restrict__ mask, int64_t n, int L, float p, float inv_keep, uint64_t seed) {
+  const uint32_t thr = attn_drop_threshold(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kj = (int)(i % L), qi = (int)((i / L) % L);
+    const int64_t sh = i / ((int64_t)L * L);
+    mask[i] = attn_drop_pick(attn_drop_block(seed, sh, L, qi, kj), qi, kj, thr, inv_keep);
+  }
 }
 
 // ---- BERT embeddings (HF BertEmbeddings): x[r] = word[ids[r]] + pos[r % T] + type[0]
@@ -441,7 +445,7 @@ extern "C" int ctclip_dropout(const void* x, const void* residual, void* y, int6
 extern "C" int ctclip_attn_dropout_mask(float* mask, int nseq, int H, int L, float p, uint64_t seed, hipStream_t s) {
   if (!mask || p < 0.f || p >= 1.f) { ctclip_set_error("attn_dropout_mask: bad args"); return CTCLIP_EBADARG; }
   const int64_t n = (int64_t)nseq * H * L * L;
-  hipLaunchKernelGGL(attn_dropout_mask_kernel, grid_for(n), dim3(256), 0, s, mask, n, p, 1.f / (1.f - p), seed);
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, grid_for(n), dim3(256), 0, s, mask, n, L, p, 1.f / (1.f - p), seed);
   return ctclip_check_launch("attn_dropout_mask");
 }
 extern "C" int ctclip_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* x, int64_t rows,

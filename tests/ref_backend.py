@@ -368,8 +368,22 @@ class RefBackend:
         return y.reshape(x.shape).to(x.dtype)
 
     def attn_dropout_mask(self, nseq, H, L, p, seed, device):
-        idx = torch.arange(nseq * H * L * L, dtype=torch.int64)
-        return self._mult(self.philox(seed, idx, 0)[0], p).reshape(nseq, H, L, L).to(device)
+        """csrc/common.h attn_drop_block / attn_drop_pick (round 6): one Philox call (stream 1) per block of 2 queries x 4 keys, 16 bits per element."""
+        import math
+        import numpy as np
+        nq2, nk4 = (L + 1) // 2, (L + 3) // 4
+        nblk = nseq * H * nq2 * nk4
+        words = torch.stack(self.philox(seed, torch.arange(nblk, dtype=torch.int64), 1), dim=0)          # (4, nblk)
+        sh = torch.arange(nseq * H, dtype=torch.int64)[:, None, None]
+        qi = torch.arange(L, dtype=torch.int64)[None, :, None]
+        kj = torch.arange(L, dtype=torch.int64)[None, None, :]
+        blk = (sh * nq2 + (qi >> 1)) * nk4 + (kj >> 2)
+        wi = (qi & 1) * 2 + ((kj & 3) >> 1) + torch.zeros_like(blk)
+        word = words.reshape(-1)[wi * nblk + blk]
+        u = (word >> (16 * (kj & 1))) & 0xFFFF
+        thr = int(math.floor(float(np.float32(np.float32(p) * np.float32(65536.0)) + np.float32(0.5))))
+        keep = torch.where(u >= thr, 1.0 / (1.0 - p), 0.0).to(torch.float32)
+        return keep.reshape(nseq, H, L, L).to(device)
 
     def attn_fwd(self, q, k, vt, bias, keymask, nseq, H, L, D, scale, want_lse=True, bias_grid=None, dropout=None):
         if bias_grid is not None:
