@@ -1008,6 +1008,342 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnParams p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// LDS-shared variants for the BERT shape (bf16, d_head 64, L % 32 == 0, optional key-padding mask and attention dropout; round 6).
+// The register-only kernels above let every lane fetch its own operand row of every tile (32 cache lines per load instruction, 64 for the
+// transposed copies) and every wave of a workgroup fetch the same tiles again: at T = 512 they ran at the L1 line rate (fwd 52 / dQ 98 /
+// dK,dV 123 us per layer for 0.8 / 2 / 2 GFLOP x 96 heads).  Here the four waves of a workgroup own four neighbouring 32-row blocks of one
+// (sequence, head) and walk the other axis in lockstep; each operand tile of a step is fetched once per workgroup with one 16-byte load
+// per thread (8 threads per 128-byte row) into a double-buffered LDS ring.  Row-major tiles (32 tokens x 128 B) are 144 B apart in LDS,
+// transposed ones (64 dims x 64 B) 80 B: 9 r and 5 r mod 16 are permutations, so the sixteen rows of a ds_read_b128 group start in
+// sixteen different 16-byte bank groups.  The key mask (x log2 e, clamped finite) and the row statistics of the backward sit in LDS for
+// the whole kernel; logits are in the log2 domain.
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int SROW64 = 144, STILE64 = 32 * SROW64, STILE64T = 64 * SROW;
+
+__device__ __forceinline__ void lds_frag64(Frag<bf16_t, 64>& f, const char* tile, int ar, int half) {
+  const char* r = tile + ar * SROW64 + half * 16;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) f.v[g] = *reinterpret_cast<const bf16x8*>(r + 32 * g);
+}
+// key mask of the sequence -> LDS, in the log2 domain; HF's mask is finfo.min: keep it finite so that a fully masked tile stays NaN-free
+__device__ __forceinline__ void stage_keymask(float* km, const AttnParams& p, int seq) {
+  if (!p.keymask) return;
+  for (int i = threadIdx.x; i < p.L; i += blockDim.x) km[i] = fmaxf(p.keymask[(int64_t)seq * p.L + i] * LOG2E, -3.0e38f);
+}
+// two runs of eight consecutive f32 (rows 16 g + 8 half of a tile) from an LDS array: four broadcast ds_read_b128
+__device__ __forceinline__ void lds_runs(float (&out)[16], const float* arr, int base, int half) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(arr + base + 16 * g + 8 * half), b = *reinterpret_cast<const f32x4*>(arr + base + 16 * g + 8 * half + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { out[8 * g + e] = a[e]; out[8 * g + 4 + e] = b[e]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn64_fwd_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 64, BUF = STILE64 + STILE64T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int L = p.L, Lp = p.Lp, nkb = L / 32;
+  __shared__ __attribute__((aligned(16))) char tiles[2 * BUF];          // [buffer][K rows | V^T rows]
+  __shared__ __attribute__((aligned(16))) float km[REL_MAXL];
+  stage_keymask(km, p, seq);
+  const float scale2 = p.scale * LOG2E;
+  const int qb_raw = blockIdx.x * 4 + wave;
+  const bool active = qb_raw < nkb;
+  const int qb = active ? qb_raw : nkb - 1;                // idle waves shadow the last block: they must keep the barriers
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  Frag<T, D> qf;
+  frag_load(qf, reinterpret_cast<const T*>(p.q) + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D);
+
+  const T* ksrc = reinterpret_cast<const T*>(p.k) + ((int64_t)seq * L + (tid >> 3)) * p.ldk + h * D + (tid & 7) * 8;
+  const T* vsrc = reinterpret_cast<const T*>(p.vt) + (((int64_t)seq * p.H + h) * D + (tid >> 2)) * Lp + (tid & 3) * 8;
+  char* kdst = tiles + (tid >> 3) * SROW64 + (tid & 7) * 16;
+  char* vdst = tiles + STILE64 + (tid >> 2) * SROW + (tid & 3) * 16;
+  const int64_t kstep = 32 * p.ldk;
+  u32x4 sk = *reinterpret_cast<const u32x4*>(ksrc), sv = *reinterpret_cast<const u32x4*>(vsrc);
+  *reinterpret_cast<u32x4*>(kdst) = sk;
+  *reinterpret_cast<u32x4*>(vdst) = sv;
+  __syncthreads();
+
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const char* buf = tiles + (kb & 1) * BUF;
+    const int kbn = kb + 1 < nkb ? kb + 1 : kb;
+    sk = *reinterpret_cast<const u32x4*>(ksrc + kbn * kstep);          // next tiles in flight under this step
+    sv = *reinterpret_cast<const u32x4*>(vsrc + kbn * 32);
+    Frag<T, D> kf;
+    Frag<T, 32> vf[2];
+    lds_frag64(kf, buf, ar, half);
+    lds_frag(vf[0], buf + STILE64, ar, half);
+    lds_frag(vf[1], buf + STILE64 + 32 * SROW, ar, half);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    s = mma(s, kf, qf);
+    float val[16];
+    if (p.keymask) {
+      float add[16];
+      lds_runs(add, km, kb * 32, half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) val[r] = fmaf(s[r], scale2, add[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) val[r] = s[r] * scale2;
+    }
+    float mx = val[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    float pr[16], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(val[r] - mnew); ps += pr[r]; }
+    lsum = lsum * alpha + ps;
+    if (p.drop_p > 0.f) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+      float dm[16];
+      drop_keys(dm, p, seq, h, qi, kb, half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] *= dm[r];
+    }
+    Frag<T, 32> pf;
+    frag_from_regs(pf, pr);
+    if (__builtin_amdgcn_ballot_w64(mnew != m) != 0) {                  // wave-uniform: skip the rescale while no maximum moved
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    m = mnew;
+    oacc[0] = mma(oacc[0], vf[0], pf);
+    oacc[1] = mma(oacc[1], vf[1], pf);
+    const int nb = ((kb & 1) ^ 1) * BUF;                                // every wave finished reading that buffer before the last barrier
+    *reinterpret_cast<u32x4*>(kdst + nb) = sk;
+    *reinterpret_cast<u32x4*>(vdst + nb) = sv;
+    __syncthreads();
+  }
+  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  if (active) {
+    const float inv = 1.f / l;
+    T* O = reinterpret_cast<T*>(p.out) + ((int64_t)seq * L + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = oacc[i][8 * g + e] * inv;
+        store8(O + i * 32 + 16 * g + 8 * half, o8);
+      }
+    if (half == 0 && p.lse_out) p.lse_out[((int64_t)seq * p.H + h) * L + qi] = (m + __log2f(l)) * LN2;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn64_bwd_dq_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 64, BUF = 2 * STILE64 + STILE64T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int L = p.L, Lp = p.Lp, nkb = L / 32;
+  __shared__ __attribute__((aligned(16))) char tiles[2 * BUF];          // [buffer][K rows | V rows | K^T rows]
+  __shared__ __attribute__((aligned(16))) float km[REL_MAXL];
+  stage_keymask(km, p, seq);
+  const float scale2 = p.scale * LOG2E;
+  const int qb_raw = blockIdx.x * 4 + wave;
+  const bool active = qb_raw < nkb;
+  const int qb = active ? qb_raw : nkb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int qi = qb * 32 + c;
+  Frag<T, D> qf, dof;
+  frag_load(qf, reinterpret_cast<const T*>(p.q) + ((int64_t)seq * L + qi) * p.ldq + h * D, half, D);
+  frag_load(dof, reinterpret_cast<const T*>(p.dout) + ((int64_t)seq * L + qi) * p.lddo + h * D, half, D);
+  const float lse2 = p.lse[((int64_t)seq * p.H + h) * L + qi] * LOG2E;
+  const float delta = p.delta[((int64_t)seq * p.H + h) * L + qi];
+
+  const T* ksrc = reinterpret_cast<const T*>(p.k) + ((int64_t)seq * L + (tid >> 3)) * p.ldk + h * D + (tid & 7) * 8;
+  const T* vsrc = reinterpret_cast<const T*>(p.v) + ((int64_t)seq * L + (tid >> 3)) * p.ldv + h * D + (tid & 7) * 8;
+  const T* tsrc = reinterpret_cast<const T*>(p.kt) + (((int64_t)seq * p.H + h) * D + (tid >> 2)) * Lp + (tid & 3) * 8;
+  char* kdst = tiles + (tid >> 3) * SROW64 + (tid & 7) * 16;
+  char* vdst = kdst + STILE64;
+  char* tdst = tiles + 2 * STILE64 + (tid >> 2) * SROW + (tid & 3) * 16;
+  const int64_t kstep = 32 * p.ldk, vstep = 32 * p.ldv;
+  u32x4 sk = *reinterpret_cast<const u32x4*>(ksrc), sv = *reinterpret_cast<const u32x4*>(vsrc), st = *reinterpret_cast<const u32x4*>(tsrc);
+  *reinterpret_cast<u32x4*>(kdst) = sk;
+  *reinterpret_cast<u32x4*>(vdst) = sv;
+  *reinterpret_cast<u32x4*>(tdst) = st;
+  __syncthreads();
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const char* buf = tiles + (kb & 1) * BUF;
+    const int kbn = kb + 1 < nkb ? kb + 1 : kb;
+    sk = *reinterpret_cast<const u32x4*>(ksrc + kbn * kstep);
+    sv = *reinterpret_cast<const u32x4*>(vsrc + kbn * vstep);
+    st = *reinterpret_cast<const u32x4*>(tsrc + kbn * 32);
+    Frag<T, D> kf, vf;
+    Frag<T, 32> ktf[2];
+    lds_frag64(kf, buf, ar, half);
+    lds_frag64(vf, buf + STILE64, ar, half);
+    lds_frag(ktf[0], buf + 2 * STILE64, ar, half);
+    lds_frag(ktf[1], buf + 2 * STILE64 + 32 * SROW, ar, half);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, kf, qf);
+    dp = mma(dp, vf, dof);
+    float ds[16], add[16];
+    if (p.keymask) lds_runs(add, km, kb * 32, half);
+    float dm[16];
+    if (p.drop_p > 0.f) drop_keys(dm, p, seq, h, qi, kb, half);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v2 = p.keymask ? fmaf(s[r], scale2, add[r]) : s[r] * scale2;
+      const float pr = __builtin_amdgcn_exp2f(v2 - lse2);
+      const float dpr = p.drop_p > 0.f ? dp[r] * dm[r] : dp[r];         // d(dropout(P)) / dP
+      ds[r] = pr * (dpr - delta);
+    }
+    Frag<T, 32> dsf;
+    frag_from_regs(dsf, ds);
+    dqacc[0] = mma(dqacc[0], ktf[0], dsf);
+    dqacc[1] = mma(dqacc[1], ktf[1], dsf);
+    const int nb = ((kb & 1) ^ 1) * BUF;
+    *reinterpret_cast<u32x4*>(kdst + nb) = sk;
+    *reinterpret_cast<u32x4*>(vdst + nb) = sv;
+    *reinterpret_cast<u32x4*>(tdst + nb) = st;
+    __syncthreads();
+  }
+  if (active) {
+    T* dQ = reinterpret_cast<T*>(p.dq) + ((int64_t)seq * L + qi) * p.lddq + h * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = dqacc[i][8 * g + e] * p.scale;
+        store8(dQ + i * 32 + 16 * g + 8 * half, o8);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn64_bwd_dkv_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int D = 64, BUF = 2 * STILE64 + 2 * STILE64T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, seq = blockIdx.z;
+  const int L = p.L, Lp = p.Lp, nqb = L / 32;
+  __shared__ __attribute__((aligned(16))) char tiles[2 * BUF];          // [buffer][Q rows | dO rows | Q^T rows | dO^T rows]
+  __shared__ __attribute__((aligned(16))) float stat[2][REL_MAXL];      // lse x log2 e, delta of every query of this (sequence, head)
+  const int64_t statbase = ((int64_t)seq * p.H + h) * L;
+  for (int i = tid; i < L; i += 256) { stat[0][i] = p.lse[statbase + i] * LOG2E; stat[1][i] = p.delta[statbase + i]; }
+  const float scale2 = p.scale * LOG2E;
+  const int jb_raw = blockIdx.x * 4 + wave;
+  const bool active = jb_raw < nqb;
+  const int jb = active ? jb_raw : nqb - 1;
+  const int c = lane & 31, half = lane >> 5, ar = pi32(c);
+  const int kj = jb * 32 + c;
+  Frag<T, D> kf, vf;
+  frag_load(kf, reinterpret_cast<const T*>(p.k) + ((int64_t)seq * L + kj) * p.ldk + h * D, half, D);
+  frag_load(vf, reinterpret_cast<const T*>(p.v) + ((int64_t)seq * L + kj) * p.ldv + h * D, half, D);
+  const float km2 = p.keymask ? fmaxf(p.keymask[(int64_t)seq * L + kj] * LOG2E, -3.0e38f) : 0.f;
+
+  const T* qsrc = reinterpret_cast<const T*>(p.q) + ((int64_t)seq * L + (tid >> 3)) * p.ldq + h * D + (tid & 7) * 8;
+  const T* osrc = reinterpret_cast<const T*>(p.dout) + ((int64_t)seq * L + (tid >> 3)) * p.lddo + h * D + (tid & 7) * 8;
+  const int64_t toff = (((int64_t)seq * p.H + h) * D + (tid >> 2)) * Lp + (tid & 3) * 8;
+  const T* qtsrc = reinterpret_cast<const T*>(p.qt) + toff;
+  const T* otsrc = reinterpret_cast<const T*>(p.dot) + toff;
+  char* qdst = tiles + (tid >> 3) * SROW64 + (tid & 7) * 16;
+  char* odst = qdst + STILE64;
+  char* qtdst = tiles + 2 * STILE64 + (tid >> 2) * SROW + (tid & 3) * 16;
+  char* otdst = qtdst + STILE64T;
+  const int64_t qstep = 32 * p.ldq, ostep = 32 * p.lddo;
+  u32x4 sq = *reinterpret_cast<const u32x4*>(qsrc), so = *reinterpret_cast<const u32x4*>(osrc);
+  u32x4 sqt = *reinterpret_cast<const u32x4*>(qtsrc), sot = *reinterpret_cast<const u32x4*>(otsrc);
+  *reinterpret_cast<u32x4*>(qdst) = sq;
+  *reinterpret_cast<u32x4*>(odst) = so;
+  *reinterpret_cast<u32x4*>(qtdst) = sqt;
+  *reinterpret_cast<u32x4*>(otdst) = sot;
+  __syncthreads();
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[i][r] = 0.f; dvacc[i][r] = 0.f; }
+  for (int qb = 0; qb < nqb; ++qb) {
+    const char* buf = tiles + (qb & 1) * BUF;
+    const int qbn = qb + 1 < nqb ? qb + 1 : qb;
+    sq = *reinterpret_cast<const u32x4*>(qsrc + qbn * qstep);
+    so = *reinterpret_cast<const u32x4*>(osrc + qbn * ostep);
+    sqt = *reinterpret_cast<const u32x4*>(qtsrc + qbn * 32);
+    sot = *reinterpret_cast<const u32x4*>(otsrc + qbn * 32);
+    Frag<T, D> qf, dof;
+    lds_frag64(qf, buf, ar, half);
+    lds_frag64(dof, buf + STILE64, ar, half);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    s = mma(s, qf, kf);     // D[query rho][key c]
+    dp = mma(dp, dof, vf);
+    float lse16[16], del16[16], pr[16], ds[16], dmq[16];
+    lds_runs(lse16, stat[0], qb * 32, half);
+    lds_runs(del16, stat[1], qb * 32, half);
+    if (p.drop_p > 0.f) drop_queries(dmq, p, seq, h, kj, qb, half);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, km2) - lse16[r]);
+      const float dm = p.drop_p > 0.f ? dmq[r] : 1.f;
+      ds[r] = pr[r] * (dp[r] * dm - del16[r]);
+      pr[r] *= dm;                                           // dV sees the dropped probabilities
+    }
+    Frag<T, 32> pf, dsf, tf[2];
+    frag_from_regs(pf, pr);
+    frag_from_regs(dsf, ds);
+    lds_frag(tf[0], buf + 2 * STILE64 + STILE64T, ar, half);
+    lds_frag(tf[1], buf + 2 * STILE64 + STILE64T + 32 * SROW, ar, half);
+    dvacc[0] = mma(dvacc[0], tf[0], pf);
+    dvacc[1] = mma(dvacc[1], tf[1], pf);
+    lds_frag(tf[0], buf + 2 * STILE64, ar, half);
+    lds_frag(tf[1], buf + 2 * STILE64 + 32 * SROW, ar, half);
+    dkacc[0] = mma(dkacc[0], tf[0], dsf);
+    dkacc[1] = mma(dkacc[1], tf[1], dsf);
+    const int nb = ((qb & 1) ^ 1) * BUF;
+    *reinterpret_cast<u32x4*>(qdst + nb) = sq;
+    *reinterpret_cast<u32x4*>(odst + nb) = so;
+    *reinterpret_cast<u32x4*>(qtdst + nb) = sqt;
+    *reinterpret_cast<u32x4*>(otdst + nb) = sot;
+    __syncthreads();
+  }
+  if (active) {
+    T* dK = reinterpret_cast<T*>(p.dk) + ((int64_t)seq * L + kj) * p.lddk + h * D;
+    T* dV = reinterpret_cast<T*>(p.dv) + ((int64_t)seq * L + kj) * p.lddv + h * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float a8[8], b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a8[e] = dkacc[i][8 * g + e] * p.scale; b8[e] = dvacc[i][8 * g + e]; }
+        store8(dK + i * 32 + 16 * g + 8 * half, a8);
+        store8(dV + i * 32 + 16 * g + 8 * half, b8);
+      }
+  }
+}
+
+
 // dBias for the CTViT shape, workgroup-shared: a workgroup of EIGHT waves owns two neighbouring query blocks and four neighbouring
 // key blocks of one head (one (query, key) tile pair per wave) and walks a strided subset of the sequences.  Per sequence the twelve
 // operand tiles (Q, dO of the two query blocks; K, V of the four key blocks) are staged once through LDS with three coalesced
@@ -1292,6 +1628,13 @@ int dispatch_attn(int which, const AttnParams& p, int D, int dtype, hipStream_t 
       else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<false>, grid, block, 0, stream, p);
     }
     return ctclip_check_launch("attention (lds)");
+  }
+  if (use_lds && dtype == DT_BF16 && D == 64 && p.L % 32 == 0 && p.L >= 64 && p.L <= REL_MAXL && p.Lp % 8 == 0 && !p.bias && !p.bias_tab && !p.dbias) {
+    dim3 grid((unsigned)cdiv(p.L / 32, 4), p.H, p.nseq), block(256);   // BERT shape: workgroup-shared operand tiles, key mask, dropout
+    if (which == 0) hipLaunchKernelGGL(attn64_fwd_kernel, grid, block, 0, stream, p);
+    else if (which == 1) hipLaunchKernelGGL(attn64_bwd_dq_kernel, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(attn64_bwd_dkv_kernel, grid, block, 0, stream, p);
+    return ctclip_check_launch("attention (lds, d_head 64)");
   }
   if (dtype == DT_BF16 && D == 32) return launch_attn<bf16_t, 32>(which, p, stream);
   if (dtype == DT_BF16 && D == 64) return launch_attn<bf16_t, 64>(which, p, stream);

@@ -487,7 +487,9 @@ def test_peg_fwd_bwd(hip, ref, dtype, shape):
                                                           (64, 2, 2, 32, False, False),
                                                           # workgroup-shared (LDS) kernels: fast path, ragged length with idle waves, bias
                                                           (2, 4, 256, 32, False, False), (3, 2, 200, 32, False, False),
-                                                          (2, 4, 160, 32, True, False), (2, 3, 136, 32, False, True)])
+                                                          (2, 4, 160, 32, True, False), (2, 3, 136, 32, False, True),
+                                                          # BERT shape (d_head 64) on the workgroup-shared kernels: four workgroups per head, idle waves, no mask
+                                                          (2, 3, 512, 64, False, True), (3, 2, 160, 64, False, True), (2, 2, 64, 64, False, False)])
 def test_attention_fwd_bwd(hip, ref, dtype, nseq, H, L, D, use_bias, use_mask):
     M, HD = nseq * L, H * D
     kv = rnd(M, 2 * HD, dtype=dtype, seed=1, scale=0.5)
@@ -571,7 +573,8 @@ def test_dropout_is_philox(hip, ref, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("nseq,H,L,D,use_mask", [(2, 12, 128, 64, True), (3, 4, 50, 64, False), (2, 4, 24, 32, False)])
+@pytest.mark.parametrize("nseq,H,L,D,use_mask", [(2, 12, 128, 64, True), (3, 4, 50, 64, False), (2, 4, 24, 32, False),
+                                                 (2, 3, 512, 64, True), (3, 2, 160, 64, True), (2, 2, 96, 64, False)])
 def test_attention_probability_dropout(hip, ref, dtype, nseq, H, L, D, use_mask):
     """HF BertSelfAttention in train mode: dropout on the softmax output, regenerated identically in forward, dQ and dK/dV."""
     M, HD = nseq * L, H * D
@@ -581,6 +584,8 @@ def test_attention_probability_dropout(hip, ref, dtype, nseq, H, L, D, use_mask)
     if use_mask:
         mask = torch.zeros(nseq, L, device=DEV)
         mask[0, L - 5:] = torch.finfo(torch.float32).min
+        if L >= 160:
+            mask[1, :40] = torch.finfo(torch.float32).min        # left padding: the first key tile of sequence 1 is masked entirely
     drop, scale = (0.1, 987654321012345), D ** -0.5
     vt = hip.head_transpose(v, nseq, H, L, D)
     o, lse = hip.attn_fwd(q, k, vt, None, mask, nseq, H, L, D, scale, dropout=drop)

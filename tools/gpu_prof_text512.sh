@@ -9,7 +9,7 @@ for path in glob.glob("gpurun_out/p512/prof/**/*kernel_trace.csv", recursive=Tru
         rows[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
 for n, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:60]:
-    if any(k in n for k in ("gemm_sm", "attn_fwd", "attn_bwd", "attn_delta", "head_transpose", "layernorm_fwd_kernel<float", "layernorm_bwd_kernel<float", "dropout", "gelu", "convert_pad", "colsum", "tn_reduce", "transpose2d", "accumulate", "gemm_kernel", "bert", "seg_")):
+    if any(k in n for k in ("gemm_sm", "attn_fwd", "attn_bwd", "attn64", "attn_delta", "head_transpose", "layernorm_fwd_kernel<float", "layernorm_bwd_kernel<float", "dropout", "gelu", "convert_pad", "colsum", "tn_reduce", "transpose2d", "accumulate", "gemm_kernel", "bert", "seg_")):
         print(f"{n[:90]:90s} calls {len(v):5d} total {sum(v)/1e3:8.2f} ms avg {sum(v)/len(v):8.1f} us max {max(v):8.1f}")
 print("total", tot/1e3)
 PY
