@@ -823,8 +823,11 @@ class HipBackend:
         N = w.shape[0]
         assert dy.dtype == torch.float32 and dy.is_contiguous()
         dx = torch.empty_like(x) if want_dx else None
-        for b0 in range(0, Bm, 8):
-            nb = min(8, Bm - b0)
+        # rows per launch: 8 (the training step's batch), 24 in f32 when there are more -- the VocabFine step's 18 pooled vectors then
+        # stream the 604-MB weight and its gradient once instead of three times
+        step = 24 if (Bm > 8 and x.dtype == torch.float32) else 8
+        for b0 in range(0, Bm, step):
+            nb = min(step, Bm - b0)
             rc = self.lib.ctclip_visual_latent_bwd(_p(dy[b0:]), _p(x[b0:]), _p(w), _p(dx[b0:]) if want_dx else None, _p(dw), nb, N,
                                                    K, int(accumulate or b0 > 0), dcode(x.dtype), _stream())
             _lib.check(rc, "ctclip_visual_latent_bwd")

@@ -9,6 +9,27 @@ namespace {
 
 constexpr int VL_MAXB = 8;    // rows of X per call (the host loops over chunks of 8 samples)
 constexpr int VL_KCH = 2048;  // k-chunk per block
+// wide form of the BACKWARD (f32 only): up to 24 rows per launch, 4 k per lane -- the VocabFine step projects its 18 pooled vectors (one per
+// pathology) and used to stream the 604-MB weight and its gradient (read + write) once per chunk of 8 rows: 3 x 440 us, now 644-655.
+// Measured and dropped: 2 k per lane (1 032 us), the weight rows split over the halves of a workgroup (668 us: 253 registers allow two
+// waves per SIMD, so twice the waves run in two rounds), a 24-row FORWARD (665-843 us against 3 x 172: the cross-lane reductions of
+// 4 x 24 partial sums per wave and chunk cost as much as the products).
+constexpr int VLW_MAXB = 24, VLW_KW = 4, VLW_THREADS = 256;
+
+template <int KW> __device__ __forceinline__ void loadk(const float* p, float (&v)[KW]);
+template <> __device__ __forceinline__ void loadk<8>(const float* p, float (&v)[8]) { load8(p, v); }
+template <> __device__ __forceinline__ void loadk<4>(const float* p, float (&v)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+template <int KW> __device__ __forceinline__ void loadk(const bf16_t* p, float (&v)[KW]) { static_assert(KW == 8, "bf16: 8 per lane"); load8(p, v); }
+template <int KW> __device__ __forceinline__ void storek(float* p, const float (&v)[KW]);
+template <> __device__ __forceinline__ void storek<8>(float* p, const float (&v)[8]) { store8(p, v); }
+template <> __device__ __forceinline__ void storek<4>(float* p, const float (&v)[4]) {
+  f32x4 a; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+template <int KW> __device__ __forceinline__ void storek(bf16_t* p, const float (&v)[KW]) { static_assert(KW == 8, "bf16: 8 per lane"); store8(p, v); }
 
 // part[chunk][b][n] = sum_{k in chunk} X[b][k] * W[n][k].  block = 4 waves x 4 weight rows; X chunk staged in LDS as f32.
 // (The k-chunks are combined by vlat_reduce_kernel in chunk order: the first version added them with f32 atomics.)
@@ -77,55 +98,55 @@ __global__ __launch_bounds__(256) void vlat_reduce_kernel(const float* __restric
   Y[i] = t;
 }
 
-// Each thread owns 8 consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
+// Each thread owns KW consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
 // The walk over n is unrolled by four with every load of the group issued first (the first version fetched W and the old dW of one
 // row per iteration, the latter behind a branch: one dependent round trip per row at 2 waves per CU -- 800 us for 1.5 GB).
-template <typename T, bool ACC, bool WANT_DW>
-__global__ __launch_bounds__(128) void vlat_bwd_kernel(const float* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ W,
-                                                       T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K) {
+template <typename T, bool ACC, bool WANT_DW, int MAXB = VL_MAXB, int KW = 8, int THREADS = 128>
+__global__ __launch_bounds__(THREADS) void vlat_bwd_kernel(const float* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ W,
+                                                           T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) float dys[];  // [Bm][N]
-  for (int i = threadIdx.x; i < Bm * N; i += 128) dys[i] = dY[i];
+  for (int i = threadIdx.x; i < Bm * N; i += THREADS) dys[i] = dY[i];
   __syncthreads();
-  const int64_t k = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 8;
+  const int64_t k = ((int64_t)blockIdx.x * THREADS + threadIdx.x) * KW;
   if (k >= K) return;
-  float xv[VL_MAXB][8], dx[VL_MAXB][8];
+  float xv[MAXB][KW], dx[MAXB][KW];
 #pragma unroll
-  for (int b = 0; b < VL_MAXB; ++b) {
+  for (int b = 0; b < MAXB; ++b) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { xv[b][e] = 0.f; dx[b][e] = 0.f; }
-    if (b < Bm) load8(X + (int64_t)b * K + k, xv[b]);
+    for (int e = 0; e < KW; ++e) { xv[b][e] = 0.f; dx[b][e] = 0.f; }
+    if (b < Bm) loadk<KW>(X + (int64_t)b * K + k, xv[b]);
   }
   constexpr int UNR = 4;
   for (int n0 = 0; n0 < N; n0 += UNR) {
-    float w[UNR][8], old[UNR][8];
+    float w[UNR][KW], old[UNR][KW];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int n = n0 + u < N ? n0 + u : N - 1;           // clamped, always issued
-      load8(W + (int64_t)n * K + k, w[u]);
-      if (ACC && WANT_DW) load8(dW + (int64_t)n * K + k, old[u]);
+      loadk<KW>(W + (int64_t)n * K + k, w[u]);
+      if (ACC && WANT_DW) loadk<KW>(dW + (int64_t)n * K + k, old[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int n = n0 + u;
       if (n >= N) break;
-      float g[8];
+      float g[KW];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = (ACC && WANT_DW) ? old[u][e] : 0.f;
+      for (int e = 0; e < KW; ++e) g[e] = (ACC && WANT_DW) ? old[u][e] : 0.f;
 #pragma unroll
-      for (int b = 0; b < VL_MAXB; ++b) {
+      for (int b = 0; b < MAXB; ++b) {
         if (b < Bm) {
           const float d = dys[b * N + n];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { dx[b][e] += d * w[u][e]; g[e] += d * xv[b][e]; }
+          for (int e = 0; e < KW; ++e) { dx[b][e] += d * w[u][e]; g[e] += d * xv[b][e]; }
         }
       }
-      if (WANT_DW) store8(dW + (int64_t)n * K + k, g);
+      if (WANT_DW) storek<KW>(dW + (int64_t)n * K + k, g);
     }
   }
   if (dX) {
 #pragma unroll
-    for (int b = 0; b < VL_MAXB; ++b)
-      if (b < Bm) store8(dX + (int64_t)b * K + k, dx[b]);
+    for (int b = 0; b < MAXB; ++b)
+      if (b < Bm) storek<KW>(dX + (int64_t)b * K + k, dx[b]);
   }
 }
 
@@ -332,12 +353,30 @@ extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, 
   hipLaunchKernelGGL(vlat_reduce_kernel, dim3((unsigned)cdiv(Bm * N, 256)), dim3(256), 0, s, (const float*)part, nchunk, Bm * N, Y);
   return ctclip_check_launch("visual_latent_fwd");
 }
-// dX (Bm, K) in `dtype` (may be null), dW (N, K) f32 overwritten or accumulated (may be null).
+// dX (Bm, K) in `dtype` (may be null), dW (N, K) f32 overwritten or accumulated (may be null).  Bm 1..8 per call, 1..24 in f32.
 extern "C" int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K,
                                         int accumulate, int dtype, hipStream_t s) {
-  if (!dY || !X || !W || Bm < 1 || Bm > VL_MAXB || K % 8 || (int64_t)Bm * N * 4 > 64 * 1024) { ctclip_set_error("visual_latent_bwd: bad args"); return CTCLIP_EBADARG; }
-  dim3 grid((unsigned)cdiv(K / 8, 128));
+  const bool wide = Bm > VL_MAXB;
+  if (!dY || !X || !W || Bm < 1 || Bm > VLW_MAXB || K % 8 || (int64_t)Bm * N * 4 > 64 * 1024 || (wide && dtype != DT_F32)) {
+    ctclip_set_error("visual_latent_bwd: batch must be 1..8 per call (1..24 in f32), K a multiple of 8, Bm x N x 4 <= 64 KiB");
+    return CTCLIP_EBADARG;
+  }
   const size_t shm = (size_t)Bm * N * sizeof(float);
+  if (wide) {
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)vlat_bwd_kernel<float, false, false, VLW_MAXB, VLW_KW, VLW_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute((const void*)vlat_bwd_kernel<float, true, true, VLW_MAXB, VLW_KW, VLW_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute((const void*)vlat_bwd_kernel<float, false, true, VLW_MAXB, VLW_KW, VLW_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      raised = true;
+    }
+    dim3 grid((unsigned)cdiv(K / VLW_KW, VLW_THREADS));
+#define VLW(ACC, WDW) hipLaunchKernelGGL((vlat_bwd_kernel<float, ACC, WDW, VLW_MAXB, VLW_KW, VLW_THREADS>), grid, dim3(VLW_THREADS), shm, s, dY, (const float*)X, (const float*)W, (float*)dX, dW, Bm, N, K)
+    if (!dW) VLW(false, false); else if (accumulate) VLW(true, true); else VLW(false, true);
+#undef VLW
+    return ctclip_check_launch("visual_latent_bwd (wide)");
+  }
+  dim3 grid((unsigned)cdiv(K / 8, 128));
 #define VLB(T, ACC, WDW) hipLaunchKernelGGL((vlat_bwd_kernel<T, ACC, WDW>), grid, dim3(128), shm, s, dY, (const T*)X, (const T*)W, (T*)dX, dW, Bm, N, K)
 #define VLB_T(T) do { if (!dW) VLB(T, false, false); else if (accumulate) VLB(T, true, true); else VLB(T, false, true); } while (0)
   if (dtype == DT_F32) VLB_T(float);

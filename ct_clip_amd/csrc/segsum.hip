@@ -7,7 +7,7 @@
 //   1. seg_hist    one workgroup per chunk of 1024 rows: integer histogram of the keys in LDS -> hist[chunk][seg]
 //   2. seg_chunkscan / seg_first   per segment, exclusive scan over the chunks (in place) and the count; then an exclusive
 //                  scan of the counts over the segments -> first[seg]
-//   3. seg_place   one workgroup per chunk: rank of a row among the EARLIER rows of its chunk with the same key (counted, not
+//   3. seg_place   one workgroup per chunk, one thread per row: rank of a row among the EARLIER rows of its chunk with the same key (counted, not
 //                  taken from an atomic's return value) -> order[first + chunk base + rank] = row      (a stable counting sort)
 //   4. seg_sum     one wave per segment walks its rows in ascending row order with 16-byte loads and f32 accumulators.
 #include "common.h"
@@ -67,25 +67,35 @@ __global__ __launch_bounds__(1024) void seg_first_kernel(const int* __restrict__
   for (int s = s0; s < s0 + per && s < nseg; ++s) { first[s] = run; run += count[s]; }
 }
 
-__global__ __launch_bounds__(256) void seg_place_kernel(const int64_t* __restrict__ keys, int mod, int64_t M, int nseg,
-                                                        const int* __restrict__ hist, const int* __restrict__ first, int* __restrict__ order) {
-  __shared__ int lk[CHUNK];
-  const int64_t r0 = (int64_t)blockIdx.x * CHUNK;
-  for (int i = threadIdx.x; i < CHUNK; i += 256) {
-    const int64_t r = r0 + i;
-    int k = -1;
-    if (r < M) { k = key_of(keys, r, mod); if (k < 0 || k >= nseg) k = -1; }
-    lk[i] = k;
-  }
+// One thread per row of the chunk.  rank = number of earlier rows of the chunk with the same key: the keys of the earlier WAVES' rows are
+// compared four at a time from broadcast ds_read_b128 (a wave-uniform trip count), the 63 rows of the own wave under a lane mask.  (The
+// first version gave a thread four rows and one dependent 4-byte LDS read per comparison: 79 us per launch with 14 workgroups on the
+// chip, 20 launches per VocabFine step.)
+__global__ __launch_bounds__(CHUNK) void seg_place_kernel(const int64_t* __restrict__ keys, int mod, int64_t M, int nseg,
+                                                          const int* __restrict__ hist, const int* __restrict__ first, int* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) int lk[CHUNK];
+  const int i = threadIdx.x;
+  const int64_t r = (int64_t)blockIdx.x * CHUNK + i;
+  int k = -1;
+  if (r < M) { k = key_of(keys, r, mod); if (k < 0 || k >= nseg) k = -1; }
+  lk[i] = k;
   __syncthreads();
-  const int* base = hist + (int64_t)blockIdx.x * nseg;
-  for (int i = threadIdx.x; i < CHUNK; i += 256) {
-    const int k = lk[i];
-    if (k < 0) continue;
-    int rank = 0;
-    for (int j = 0; j < i; ++j) rank += (lk[j] == k);
-    order[first[k] + base[k] + rank] = (int)(r0 + i);
+  if (k < 0) return;
+  const int4* lk4 = reinterpret_cast<const int4*>(lk);
+  const int wb4 = (i & ~63) >> 2;
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < wb4; ++j) {
+    const int4 v = lk4[j];
+    rank += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
   }
+  const int li = i & 63;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int4 v = lk4[wb4 + j];
+    rank += (v.x == k && 4 * j < li) + (v.y == k && 4 * j + 1 < li) + (v.z == k && 4 * j + 2 < li) + (v.w == k && 4 * j + 3 < li);
+  }
+  order[first[k] + hist[(int64_t)blockIdx.x * nseg + k] + rank] = (int)r;
 }
 
 template <typename T>
@@ -181,7 +191,7 @@ extern "C" int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* 
   hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)nseg * 4, stream, keys, key_mod, M, nseg, hist);
   hipLaunchKernelGGL(seg_chunkscan_kernel, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, stream, hist, (int)nchunks, nseg, count, counts_f);
   hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(1024), 0, stream, count, nseg, first);
-  hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, keys, key_mod, M, nseg, hist, first, order);
+  hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)nchunks), dim3(CHUNK), 0, stream, keys, key_mod, M, nseg, hist, first, order);
   if (in_dtype == DT_BF16) hipLaunchKernelGGL(seg_sum_kernel<bf16_t>, dim3((unsigned)cdiv(nseg, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, rowscale, order, first, count, out, nseg, d, accumulate);
   else if (in_dtype == DT_F32) hipLaunchKernelGGL(seg_sum_kernel<float>, dim3((unsigned)cdiv(nseg, 4)), dim3(256), 0, stream, (const float*)x, ldx, rowscale, order, first, count, out, nseg, d, accumulate);
   else return CTCLIP_EUNSUPPORTED;

@@ -260,6 +260,9 @@ int ctclip_vq_ema_update(float* cluster, float* embed, const float* bins, const 
 /* parameter-space epilogue of the patch-embedding backward (replaces the autograd of nn.LayerNorm(K) + nn.Linear(K, d), ctvit.py:172-173, with the LayerNorm affine folded into the GEMM): from G = dZ^T xhat (N x K) and dbp = colsum(dZ): dW (+)= G * gamma1 + dbp (x) beta1, dgamma1 (+)= sum_n W G, dbeta1 (+)= W^T dbp; all f32, fixed summation order. */
 int ctclip_patch_embed_param_bwd(const float* G, const float* W, const float* gamma1, const float* beta1, const float* dbp, float* dW, float* dgamma1, float* dbeta1, int N, int K, int accumulate, hipStream_t s);
 
+/* One thread spins for `microseconds` (0 .. 1 000 000) on stream s without touching memory: the busy kernel with which ct_clip_amd/streams.py probes whether a side stream runs beside the default stream (HIP multiplexes streams onto a few hardware queues). [no reference counterpart: the reference has one stream (scripts/CTCLIPTrainer.py:249-264)] */
+int ctclip_spin(int64_t microseconds, hipStream_t s);
+
 /* F.layer_norm (attention.py:28-35,47; ctvit.py:174; HF BertLayerNorm). gamma/beta may be NULL. */
 int ctclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps, int dtype, hipStream_t stream);
 
@@ -307,9 +310,6 @@ int ctclip_segment_sum(const int64_t* keys, int key_mod, const void* x, int64_t 
 
 /* Batched refresh of the bf16 weight shadows after the optimiser step (replaces the per-parameter `.to(bf16)` / `.t().contiguous()` / re-layout copies a torch module makes when its weights change; scripts/CTCLIPTrainer.py:259-263 is followed by nothing of the kind because torch computes from the f32 weights): jobs = DEVICE array of njobs records of 12 int64 {src, dst, src_ld, dst_ld, src_rows, src_cols, dst_rows, dst_cols, map, aux, transposed, tile0} sorted by tile0 (tile0 of job i = sum over the jobs before it of ceil(dst_rows / 64) * ceil(dst_cols / 64)), ntiles = the total.  src f32 (src_rows, src_cols), dst bf16 (dst_rows, dst_cols); plain: dst[r][c] = src[map(r)][c], transposed: dst[r][c] = src[map(c)][r], 0 outside the source.  map 0: identity; 1: GEGLU [x | pad | gate | pad] split (aux = inner, half = mapped extent / 2); 2: ctclip_geglu_weight_interleave's row order (aux = inner). */
 int ctclip_shadow_refresh(const void* jobs, int njobs, int64_t ntiles, hipStream_t stream);
-
-/* One thread spins for `microseconds` (0 .. 1 000 000) on stream s without touching memory: the busy kernel with which ct_clip_amd/streams.py probes whether a side stream runs beside the default stream (HIP multiplexes streams onto a few hardware queues). [no reference counterpart: the reference has one stream (scripts/CTCLIPTrainer.py:249-264)] */
-int ctclip_spin(int64_t microseconds, hipStream_t s);
 
 #ifdef __cplusplus
 }

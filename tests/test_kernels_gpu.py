@@ -940,7 +940,9 @@ def test_vq_split3_search_is_f32_grade(hip, ref):
 
 # ---------------------------------------------------------------- CLIP head
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("Bm,N,K", [(2, 64, 2048), (8, 512, 4096 + 1024), (11, 32, 1024)])
+@pytest.mark.parametrize("Bm,N,K", [(2, 64, 2048), (8, 512, 4096 + 1024), (11, 32, 1024),
+                                    # more than 8 rows in f32: the 24-row kernels (VocabFine: 18 pooled vectors), two launches at 27
+                                    (18, 512, 4096 + 1024 + 8), (27, 64, 2048 + 24)])
 def test_visual_latent(hip, ref, dtype, Bm, N, K):
     x, w = rnd(Bm, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05)
     close(hip.visual_latent_fwd(x, w), ref.visual_latent_fwd(x, w), **tol(dtype, (1e-4, 1e-3), (1e-2, 5e-2)))
