@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256) void attn64_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v2 = p.keymask ? fmaf(s[r], scale2, add[r]) : s[r] * scale2;
-      const float pr = __builtin_amdgcn_exp2f(v2 - lse2);
+      const float pr = __builtin_amdgcn_exp2f(fminf(v2 - lse2, 0.f));   // (p <= 1; the clamp keeps a fully masked sequence -- |lse| ~ 3e38 -- finite)
       const float dpr = p.drop_p > 0.f ? dp[r] * dm[r] : dp[r];         // d(dropout(P)) / dP
       ds[r] = pr * (dpr - delta);
     }
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void attn64_bwd_dkv_kernel(AttnParams p) {
     if (p.drop_p > 0.f) drop_queries(dmq, p, seq, h, kj, qb, half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, km2) - lse16[r]);
+      pr[r] = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], scale2, km2) - lse16[r], 0.f));   // (clamp: see attn64_bwd_dq_kernel)
       const float dm = p.drop_p > 0.f ? dmq[r] : 1.f;
       ds[r] = pr[r] * (dp[r] * dm - del16[r]);
       pr[r] *= dm;                                           // dV sees the dropped probabilities

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __
   float t = 0.f;
   if (c < 2 * cols) {
     const int which = c / cols, col = c % cols;
-#pragma unroll 4
-    for (int b = sl; b < nblocks; b += 16) t += part[((int64_t)b * 2 + which) * cols + col];
+#pragma unroll 16
+    for (int b = sl; b < nblocks; b += 16) t += part[((int64_t)b * 2 + which) * cols + col];      // (64 rows per thread: 16 loads in flight, added in row order)
   }
   red[sl][threadIdx.x & 63] = t;
   __syncthreads();
