@@ -179,7 +179,7 @@ int64_t ctclip_visual_latent_fwd_workspace(int Bm, int N, int64_t K);
 /* CTCLIP.to_visual_latent: Linear(h*w*dim -> dim_latent, no bias) at M = batch (ct_clip.py:564,767); `workspace` >= ctclip_visual_latent_fwd_workspace bytes (split-K partials, fixed summation order). */
 int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, int Bm, int N, int64_t K, int dtype, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
-/* backward of the above (dX and dW). [replaces autograd through to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False), ct_clip.py:549,771] */
+/* backward of the above (dX and dW); Bm 1..8 rows per call, 1..24 in f32 (the VocabFine step's 18 pooled vectors in one pass over the weight and its gradient). [replaces autograd through to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False), ct_clip.py:549,771] */
 int ctclip_visual_latent_bwd(const float* dY, const void* X, const void* W, void* dX, float* dW, int Bm, int N, int64_t K, int accumulate, int dtype, hipStream_t s);
 
 /* l2norm + logits*exp(temperature) + symmetric InfoNCE, forward and backward (ct_clip.py:771,796,845-901). */
