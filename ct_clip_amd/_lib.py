@@ -24,6 +24,7 @@ SIGNATURES = {
     "ctclip_gemm_dw_db": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P]),
     "ctclip_gemm_argmax_workspace": (_L, [_L, _L]),
     "ctclip_gemm_argmax": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P, _L, _P]),
+    "ctclip_gemm_argmax_hilo": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _L, _P]),
     "ctclip_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
     "ctclip_layernorm_bwd_workspace": (_L, [_L, _I]),
     "ctclip_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),

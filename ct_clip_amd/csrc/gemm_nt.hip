@@ -82,6 +82,7 @@ struct NtParams {
   int ntm, ntn;
   // arg-max epilogue (vector-quantiser code search): no C; per (row, tile column half) partial (max, lowest index of the max)
   float* part_val; int32_t* part_idx; int nparts;
+  int argmax_pairs;        // 1: B's rows are (hi, lo) pairs of one code each (ctclip_gemm_argmax_hilo): score of code c = columns 2 c + (2 c + 1), index = c
   // GEGLU epilogue (feed-forward in-projection, attention.py:39-48): B's rows are interleaved in groups of four (output column
   // 8 q + r = x feature 4 q + r, 8 q + 4 + r = its gate), so a lane's eight consecutive columns are four (x, gate) pairs; the epilogue
   // stores u = [x | gate] in the split layout the backward reads AND g = x * gelu(gate).  geglu_hp = padded hidden width (0 = off).
@@ -427,10 +428,18 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float best = -INFINITY; int bidx = 0x7fffffff;
+          if (p.argmax_pairs) {        // kernel-uniform: a lane's eight consecutive columns are four codes
 #pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const float v = acc[a][b][r];
-            if (col0 + b < p.N && v > best) { best = v; bidx = (int)(col0 + b); }
+            for (int b = 0; b < 8; b += 2) {
+              const float v = acc[a][b][r] + acc[a][b + 1][r];
+              if (col0 + b < p.N && v > best) { best = v; bidx = (int)((col0 + b) >> 1); }
+            }
+          } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const float v = acc[a][b][r];
+              if (col0 + b < p.N && v > best) { best = v; bidx = (int)(col0 + b); }
+            }
           }
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) {
@@ -811,7 +820,7 @@ static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
 // Row-wise arg-max of A B^T on the same kernel (ctclip_gemm_argmax, bf16): partials (M x nparts), nparts = 2 * ceil(N / 256).
 // Returns 1 when the shape is not eligible.
 int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
-                              int32_t* part_idx, int* nparts, hipStream_t stream) {
+                              int32_t* part_idx, int* nparts, hipStream_t stream, int pairs) {
   if (K % TK || K / TK < 2) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
@@ -820,7 +829,7 @@ int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N
   NtParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.alpha = 1.f;
   p.ntm = (int)ntm; p.ntn = (int)ntn;
-  p.part_val = part_val; p.part_idx = part_idx; p.nparts = (int)(2 * ntn);
+  p.part_val = part_val; p.part_idx = part_idx; p.nparts = (int)(2 * ntn); p.argmax_pairs = pairs;
   *nparts = p.nparts;
   return nt_launch(p, false, stream);
 }

@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const TI* __restrict__
 // Unit rows as a THREE-TERM bf16 expansion for an f32-grade dot product on the bf16 matrix cores: y = [hi | hi | lo] (order 0) or
 // [hi | lo | hi] (order 1) with hi = bf16(x^), lo = bf16(x^ - hi), x^ = x / max(||x||, eps) in f32.  A row of order 0 times a row of
 // order 1 is  hi.hi' + hi.lo' + lo.hi'  = x^ . x^'  up to the dropped lo.lo' term (~2^-17 of the summands).
+// order 2: y = [hi | lo] (rows of 2 cols; read as (2 rows, cols) it is the interleaved codebook of ctclip_gemm_argmax_hilo); y == NULL: only the
+// inverse norms (the quantiser's EMA statistics need them when the search reads the raw tokens).
 template <typename TI>
 __global__ __launch_bounds__(256) void l2norm_split3_kernel(const TI* __restrict__ x, bf16_t* __restrict__ y, float* __restrict__ inv_out,
                                                             int64_t rows, int cols, int64_t ldx, float eps, int order) {
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(256) void l2norm_split3_kernel(const TI* __restrict
   }
   const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
   if (lane == 0 && inv_out) inv_out[row] = inv;
-  bf16_t* o = y + row * 3 * (int64_t)cols;
+  if (!y) return;                                            // kernel-uniform
+  bf16_t* o = y + row * (order == 2 ? 2 : 3) * (int64_t)cols;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = (i * 64 + lane) * 8;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) void l2norm_split3_kernel(const TI* __restrict
       }
       store8(o + c, hi);
       store8(o + cols + c, order == 0 ? hi : lo);
-      store8(o + 2 * cols + c, order == 0 ? lo : hi);
+      if (order != 2) store8(o + 2 * cols + c, order == 0 ? lo : hi);
     }
   }
 }
@@ -427,7 +430,7 @@ extern "C" int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t ro
 // y: (rows, 3 * cols) bf16; order 0 = [hi | hi | lo] (tokens), order 1 = [hi | lo | hi] (codes); inv (rows) f32 optional.
 extern "C" int ctclip_l2norm_split3(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype,
                                     int order, hipStream_t stream) {
-  if (!x || !y || cols % 8 || cols > 64 * 8 * LN_MAXV || ldx % 8 || (order != 0 && order != 1)) { ctclip_set_error("l2norm_split3: cols must be a multiple of 8 and <= 2048, order 0 or 1"); return CTCLIP_EBADARG; }
+  if (!x || (!y && !inv) || cols % 8 || cols > 64 * 8 * LN_MAXV || ldx % 8 || order < 0 || order > 2) { ctclip_set_error("l2norm_split3: cols must be a multiple of 8 and <= 2048, order 0, 1 or 2"); return CTCLIP_EBADARG; }
   dim3 grid((unsigned)cdiv(rows, 4));
   if (in_dtype == DT_F32) hipLaunchKernelGGL(l2norm_split3_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (bf16_t*)y, inv, rows, cols, ldx, eps, order);
   else if (in_dtype == DT_BF16) hipLaunchKernelGGL(l2norm_split3_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, inv, rows, cols, ldx, eps, order);

@@ -1355,7 +1355,8 @@ class VqFn(Function):
 
     The package forces `x.float()` and searches in f32 whatever the autocast state.  In bf16 mode the tokens are l2-normalised in
     f32 and the search GEMM runs on the bf16 matrix cores over the three-term expansion hi.hi' + hi.lo' + lo.hi' (K = 3 d,
-    f32 accumulate): f32-grade distances (error ~1e-7 against a median top-1 / top-2 margin of 8e-3), so
+    f32 accumulate) -- or, on the big token grids (round 6), the raw bf16 tokens against the codebook's (hi, lo) pair (K = 2 d: the arg-max does
+    not see a row's norm) --: f32-grade distances (error ~1e-7 against a median top-1 / top-2 margin of 8e-3), so
     code choices differ from the f32 reference only where the bf16 TOKENS themselves differ.  The EMA statistics are summed in
     f32 from x * inv in row order (deterministic).  `forced_idx` (test hook: teacher forcing) bypasses the search."""
 
@@ -1372,6 +1373,14 @@ class VqFn(Function):
             xn, inv = be.l2norm_rows(x, torch.float32)
             en, _ = be.l2norm_rows(embed, torch.float32)
             idx, _ = be.gemm_argmax(xn, en)
+        elif be.gemm_argmax_hilo_ok(x, embed.shape[0]) and os.environ.get("CTCLIP_VQ_HILO", "1") != "0":
+            # arg-max_c x^ . e_c = arg-max_c x . e_c (|x| is a positive factor) and a bf16 token has no low part: the RAW tokens against the
+            # (hi, lo) expansion of the unit codebook are two products per (token, code, dim) -- K = 2 d instead of the 3 d of the form below,
+            # no expanded copy of the tokens, and nothing dropped but e_lo's own rounding (~2^-17)
+            es, _ = be.l2norm_split3(embed, 2)
+            idx, _ = be.gemm_argmax_hilo(x, es.view(2 * embed.shape[0], embed.shape[1]))
+            if training:
+                inv = be.row_inv_norms(x)
         else:
             xs, inv = be.l2norm_split3(x, 0)
             es, _ = be.l2norm_split3(embed, 1)

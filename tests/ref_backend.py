@@ -54,6 +54,16 @@ class RefBackend:
         val, idx = s.max(dim=-1)
         return idx, val
 
+    @staticmethod
+    def gemm_argmax_hilo_ok(a, ncodes):
+        M, d = a.shape
+        return a.dtype == torch.bfloat16 and d % 64 == 0 and d >= 128 and ((M + 255) // 256) * ((2 * ncodes + 255) // 256) >= 160
+
+    def gemm_argmax_hilo(self, a, b2):
+        e = _f(b2[0::2]) + _f(b2[1::2])
+        val, idx = (_f(a) @ e.t()).max(dim=-1)
+        return idx, val
+
     # ---- norms
     def layernorm_fwd(self, x, gamma, beta, eps, want_stats=True):
         xf = _f(x)
@@ -111,7 +121,12 @@ class RefBackend:
         t = xf * inv[:, None]
         hi = t.to(torch.bfloat16)
         lo = (t - hi.float()).to(torch.bfloat16)
+        if order == 2:
+            return torch.cat([hi, lo], dim=1), inv
         return torch.cat([hi, hi, lo] if order == 0 else [hi, lo, hi], dim=1), inv
+
+    def row_inv_norms(self, x, eps=1e-12):
+        return 1.0 / _f(x).norm(dim=-1).clamp_min(eps)
 
     def segment_sum(self, keys, x, out, nseg, rowscale=None, counts=None, accumulate=False, key_mod=0):
         M, d = x.shape

@@ -938,6 +938,48 @@ def test_vq_split3_search_is_f32_grade(hip, ref):
     assert agree >= 0.9995, agree
 
 
+@pytest.mark.parametrize("M,C,d", [(20000, 8192, 512), (3000, 2000, 128), (4096, 1536, 64 * 3)])
+def test_vq_hilo_search_on_raw_tokens(hip, ref, M, C, d):
+    """Round 6: the code search on the RAW bf16 tokens against the unit codebook's (hi, lo) pair (K = 2 d) picks the f32 cosine arg-max like
+    the three-term form (K = 3 d) does -- the norm of a row does not move its arg-max and a bf16 token has no low part."""
+    embed = torch.nn.functional.normalize(rnd(C, d, seed=1), dim=-1) * (1 + 0.3 * rnd(C, 1, seed=4))      # not unit: the kernel normalises
+    x = (rnd(M, d, seed=2) * (0.2 + 3 * rnd(M, 1, seed=3).abs())).to(torch.bfloat16)                          # rows of very different norms
+    es, einv = hip.l2norm_split3(embed, 2)
+    esr, einvr = ref.l2norm_split3(embed, 2)
+    assert es.shape == (C, 2 * d)
+    # (the normalisation's last bit may differ from torch's: hi + lo is what the search multiplies)
+    close(es[:, :d].float() + es[:, d:].float(), esr[:, :d].float() + esr[:, d:].float(), rtol=0, atol=4e-6)      # (lo is a bf16 too: 2^-17 of the value)
+    close(es[:, :d].float() + es[:, d:].float(), torch.nn.functional.normalize(embed, dim=-1), rtol=0, atol=4e-6)
+    close(einv, einvr, rtol=1e-5, atol=0)
+    close(hip.row_inv_norms(x), ref.row_inv_norms(x), rtol=1e-5, atol=0)
+    assert hip.gemm_argmax_hilo_ok(x, C)
+    idx, val = hip.gemm_argmax_hilo(x, es.view(2 * C, d))
+    full = torch.nn.functional.normalize(x.float(), dim=-1) @ torch.nn.functional.normalize(embed, dim=-1).t()
+    refval, refidx = full.max(dim=-1)
+    assert (idx == refidx).float().mean().item() >= 0.9995
+    close(val * hip.row_inv_norms(x), refval, rtol=0, atol=2e-5)
+    # ... and agrees with the three-term search wherever that one agrees with f32
+    xs, _ = hip.l2norm_split3(x, 0)
+    e3, _ = hip.l2norm_split3(embed, 1)
+    idx3, _ = hip.gemm_argmax(xs, e3)
+    assert (idx == idx3).float().mean().item() >= 0.9995
+    ri, rv = ref.gemm_argmax_hilo(x, es.view(2 * C, d))
+    assert (idx == ri).float().mean().item() >= 0.9995
+    # ties go to the lowest code: duplicate codes
+    e2 = embed.clone(); e2[C // 2] = e2[3]
+    es2, _ = hip.l2norm_split3(e2, 2)
+    idx2, _ = hip.gemm_argmax_hilo(x, es2.view(2 * C, d))
+    assert not (idx2 == C // 2).any()
+
+
+def test_vq_hilo_declines_small_shapes(hip):
+    x = rnd(100, 128, dtype=torch.bfloat16, seed=1)
+    assert not hip.gemm_argmax_hilo_ok(x, 64)
+    es, _ = hip.l2norm_split3(rnd(64, 128, seed=2), 2)
+    with pytest.raises(RuntimeError):
+        hip.gemm_argmax_hilo(x, es.view(128, 128))
+
+
 # ---------------------------------------------------------------- CLIP head
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Bm,N,K", [(2, 64, 2048), (8, 512, 4096 + 1024), (11, 32, 1024),
