@@ -18,8 +18,13 @@ def is_hf_bert(module):
         and hasattr(module.embeddings, "word_embeddings")
 
 
-def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype=None):
-    """Returns last_hidden_state as a (B*T, hidden) activation in ``dtype``.
+def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype=None, cls_only=False):
+    """Returns last_hidden_state as a (B*T, hidden) activation in ``dtype`` -- or, with cls_only, its rows of the [CLS] positions, (B, hidden).
+
+    cls_only: CT-CLIP reads enc_text[:, 0, :] and nothing else (ct_clip.py:762), so in the LAST layer only the [CLS] rows of the attention output
+    have a consumer: the attention output projection, both LayerNorms, the feed-forward block, their dropouts and all their backward run on B rows
+    instead of B*T (9 of the 12 d^2 multiply-adds per token of that layer; the q | k | v projection and the attention core still see every
+    token: the keys and values of all positions feed the [CLS] query).  Same numbers for every consumer of the [CLS] rows, same parameter gradients.
 
     operand_dtype (mixed precision, the default of the bf16 mode: dtype = f32, operand_dtype = bf16): the residual stream, both
     LayerNorms of a layer, bias / dropout / residual adds, GELU and every GEMM's accumulate-and-store are f32 -- what torch.autocast
@@ -58,6 +63,7 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype
         # additive key mask, as HF builds it: (1 - mask) * finfo.min
         keymask = ((1.0 - attention_mask.to(device=dev, dtype=torch.float32)) * torch.finfo(torch.float32).min).contiguous()
     scale = 1.0 / math.sqrt(dh)
+    nlayers = len(bert.encoder.layer)
     for li, layer in enumerate(bert.encoder.layer):
         x = Fn.grad_ready(x, layer)
         sa, so = layer.attention.self, layer.attention.output
@@ -65,6 +71,10 @@ def bert_last_hidden_state(bert, input_ids, attention_mask, dtype, operand_dtype
         # path's gradient is added inside the grad-input GEMM's epilogue instead of by an elementwise accumulation kernel)
         c, x_res = Fn.QkvSdpaFn.apply(x, sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias, keymask,
                                       Bsz, T, nh, dh, scale, (p_att, seed + 1 + li) if p_att > 0 else None, od, True)
+        if cls_only and li == nlayers - 1 and T > 1:
+            # rows b * T of the attention output and of the layer input: everything behind them in this layer is row-wise
+            c = c.view(Bsz, T * c.shape[1])[:, :c.shape[1]].contiguous()
+            x_res = x_res.view(Bsz, T * hidden)[:, :hidden].contiguous()
         if p_hid > 0:    # dense -> dropout -> + input -> LayerNorm
             h1 = drop(Fn.linear(c, so.dense.weight, so.dense.bias, out_dtype=dtype, operand_dtype=od), x_res, 1 + 2 * li)
         else:

@@ -125,14 +125,12 @@ class CTCLIP(nn.Module):
     def encode_text(self, text):
         """HF BatchEncoding-like (.input_ids, .attention_mask) -> (Bt, dim_latent) l2-normalised f32 text latents (ct_clip.py:685-686,762,771)."""
         ids, mask = text.input_ids, text.attention_mask
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes())
-        cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
+        cls = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes(), cls_only=True)      # (Bt, dim_text)
         return Fn.l2norm_f32(Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32))
 
     def text_latents_raw(self, ids, mask):
         """(Bt, T) ids / mask -> (Bt, dim_latent) f32 text latents BEFORE l2norm (ct_clip.py:685-686,762,765), differentiable."""
-        enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes())
-        cls = enc_text.view(ids.shape[0], -1)[:, :self.dim_text]
+        cls = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, *self._text_dtypes(), cls_only=True)      # (Bt, dim_text)
         cls = Fn.grad_ready(cls, self.to_text_latent)
         return Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)
 
@@ -153,14 +151,16 @@ class CTCLIP(nn.Module):
         Bt, T = ids.shape
         # The text tower (M = B*T rows: far too small to fill 256 CUs) runs on a side stream underneath the image tower;
         # autograd replays each tower's backward on the stream its forward used.
+        # only enc_text[:, 0, :] is read below (ct_clip.py:762) unless the caller asks for the encodings: (Bt, dim_text) rows then, else (Bt*T, dim_text)
+        cls_only = not return_encodings
         side = self._text_stream(ids.device if ids.is_cuda else self.temperature.device)
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od)   # (Bt*T, dim_text)
+                enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od, cls_only=cls_only)
         else:
-            enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od)
+            enc_text = _bert.bert_last_hidden_state(self.text_transformer, ids, mask, dt, od, cls_only=cls_only)
         enc_tokens = self.visual_transformer(image, return_encoded_tokens=True)                 # (Bi, t, h, w, d)
         if side is not None:
             main.wait_stream(side)
@@ -169,7 +169,7 @@ class CTCLIP(nn.Module):
         enc_image = self.pool_tokens(enc_tokens)                                                 # ct_clip.py:724,740
         if return_encodings:
             return enc_text.view(Bt, T, -1), enc_image
-        cls = enc_text.view(Bt, -1)[:, :self.dim_text]                                          # enc_text[:, 0, :] (ct_clip.py:762)
+        cls = enc_text                                                                           # enc_text[:, 0, :] (ct_clip.py:762)
         cls = Fn.grad_ready(cls, self.to_text_latent)
         enc_image = Fn.grad_ready(enc_image, self.to_visual_latent)
         text_lat = Fn.linear(cls, self.to_text_latent.weight, out_dtype=torch.float32)          # (Bt, Dl) f32, pre-l2norm

@@ -227,8 +227,9 @@ def test_three_optimisation_steps_equal_the_single_process_run(tmp_path, world):
     torch.testing.assert_close(torch.tensor(b["losses"]), torch.tensor(a["losses"]), rtol=1e-5, atol=1e-6)
     assert abs(a["norm"] - b["norm"]) <= 1e-4 * a["norm"]
     # (Adam divides by sqrt(v): where a gradient is ~0 the update direction is decided by rounding noise -- a handful of 1.4 M elements move by
-    # a percent of one step, lr = 1e-3; everything else agrees to 1e-6)
-    torch.testing.assert_close(b["params"], a["params"], rtol=1e-4, atol=3e-5)
+    # a few percent of one step, lr = 1e-3 (largest seen: 2.5e-5, and 4.7e-5 since the last BERT layer runs its row-wise half on the [CLS] rows only:
+    # a rank with ONE sample then sums one row where the single process sums four); everything else agrees to 1e-6)
+    torch.testing.assert_close(b["params"], a["params"], rtol=1e-4, atol=1e-4)
     assert float((b["params"] - a["params"]).abs().gt(2e-6).float().mean()) < 1e-4
     torch.testing.assert_close(b["cluster"], a["cluster"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(b["embed"], a["embed"], rtol=1e-4, atol=5e-6)

@@ -145,3 +145,45 @@ def test_training_on_a_fixed_batch_reduces_the_loss(golden, tmp_path, dtype):
     assert all(l == l for l in losses)
     assert losses[-1] < 0.6 * losses[0], losses
     assert all(bool(torch.isfinite(p).all()) for p in clip.parameters())
+
+
+@pytest.mark.parametrize("dtype,od", [(torch.float32, None), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_bert_cls_only_last_layer_equals_the_full_layer(golden, dtype, od, dropout):
+    """Round 6: CT-CLIP reads enc_text[:, 0, :] only (ct_clip.py:762); the last BERT layer's row-wise half runs on the [CLS] rows alone.  Same
+    [CLS] hidden states and the same parameter gradients as the full layer (without dropout; with it: the run is reproducible and finite --
+    the masks of the B-row tensors are other draws than those of the B*T-row tensors)."""
+    from ct_clip_amd import bert as Bm
+    g = golden("small")
+    clip = build_model(g["config"], g["state_dict"], DEV, torch.float32)
+    model = clip.text_transformer
+    model.train(dropout > 0)
+    model.config.hidden_dropout_prob = dropout
+    model.config.attention_probs_dropout_prob = dropout
+    ids, mask = g["input_ids"].to(DEV), g["attention_mask"].to(DEV)
+    Bsz, T = ids.shape
+    w = torch.randn(Bsz, model.config.hidden_size, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+
+    def run(cls_only):
+        for p_ in model.parameters():
+            p_.grad = None
+        torch.manual_seed(11)
+        h = Bm.bert_last_hidden_state(model, ids, mask, dtype, od, cls_only=cls_only)
+        cls = h if cls_only else h.view(Bsz, -1)[:, :model.config.hidden_size]
+        assert cls.shape == (Bsz, model.config.hidden_size)
+        (cls.float() * w).sum().backward()
+        return cls.detach().float().clone(), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+
+    c1, g1 = run(True)
+    c1b, g1b = run(True)
+    assert torch.equal(c1, c1b) and all(torch.equal(g1[n], g1b[n]) for n in g1)          # reproducible from the seed
+    assert torch.isfinite(c1).all()
+    if dropout > 0:
+        return
+    c0, g0 = run(False)
+    tol = 1e-5 if od is None else 2e-2
+    assert (c1 - c0).abs().max() <= tol * c0.abs().max()
+    assert set(g0) == set(g1)
+    for n in g0:
+        ref = g0[n].float()
+        assert (g1[n].float() - ref).norm() <= tol * max(float(ref.norm()), 1e-6), n

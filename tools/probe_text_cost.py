@@ -14,10 +14,11 @@ from ct_clip_amd import ctclip  # noqa: E402
 if os.environ.get("PROBE_SKIP_TEXT") == "1":
     cache = {}
 
-    def constant_text(bert, ids, mask, dt, od=None):
-        key = (tuple(ids.shape), dt)
+    def constant_text(bert, ids, mask, dt, od=None, cls_only=False):
+        key = (tuple(ids.shape), dt, cls_only)
         if key not in cache:
-            cache[key] = torch.randn(ids.numel(), bert.config.hidden_size, device=ids.device).to(dt or torch.float32)
+            rows = ids.shape[0] if cls_only else ids.numel()
+            cache[key] = torch.randn(rows, bert.config.hidden_size, device=ids.device).to(dt or torch.float32)
         return cache[key]
 
     ctclip._bert.bert_last_hidden_state = constant_text
