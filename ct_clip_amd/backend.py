@@ -178,19 +178,19 @@ class HipBackend:
     def gemm_argmax_hilo_ok(a, ncodes):
         """shapes ctclip_gemm_argmax_hilo serves (the persistent NT kernel): bf16 row-major tokens, K a multiple of 64, at least 160 tiles of 256 x 256"""
         M, d = a.shape
-        return (a.dtype == torch.bfloat16 and d % 64 == 0 and d >= 128 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
-                and ((M + 255) // 256) * ((2 * ncodes + 255) // 256) >= 160)
+        return (a.dtype == torch.bfloat16 and d % 64 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
+                and ((M + 255) // 256) * ((ncodes + 255) // 256) >= 160)
 
     def gemm_argmax_hilo(self, a, b2):
-        """arg-max over codes c of a[m] . (b2[2 c] + b2[2 c + 1]): RAW bf16 tokens against the interleaved (hi, lo) unit codebook
-        (l2norm_split3 order 2 viewed as (2 C, d)).  -> (idx int64 (M,), val f32 (M,) = the winning dot product, not normalised by |a[m]|)"""
+        """arg-max over codes c of a[m] . (b2[c, :K] + b2[c, K:]): RAW bf16 tokens (M, K) against the unit codebook's [hi | lo] rows (C, 2 K)
+        (l2norm_split3 order 2).  -> (idx int64 (M,), val f32 (M,) = the winning dot product, not normalised by |a[m]|)"""
         M, K = a.shape
-        C2 = b2.shape[0]
-        assert C2 % 2 == 0 and b2.shape[1] == K and b2.dtype == torch.bfloat16 and a.dtype == torch.bfloat16
+        C = b2.shape[0]
+        assert b2.shape[1] == 2 * K and b2.dtype == torch.bfloat16 and a.dtype == torch.bfloat16
         idx = torch.empty(M, dtype=torch.int64, device=a.device)
         val = torch.empty(M, dtype=torch.float32, device=a.device)
-        ws = self.workspace(a.device, self.lib.ctclip_gemm_argmax_workspace(M, C2))
-        rc = self.lib.ctclip_gemm_argmax_hilo(_p(a), _p(b2), _p(idx), _p(val), M, C2 // 2, K, _rowmajor(a, "a"), _rowmajor(b2, "b2"), _p(ws), ws.numel(),
+        ws = self.workspace(a.device, self.lib.ctclip_gemm_argmax_workspace(M, C))
+        rc = self.lib.ctclip_gemm_argmax_hilo(_p(a), _p(b2), _p(idx), _p(val), M, C, K, _rowmajor(a, "a"), _rowmajor(b2, "b2"), _p(ws), ws.numel(),
                                               _stream())
         _lib.check(rc, "ctclip_gemm_argmax_hilo")
         return idx, val
@@ -264,7 +264,7 @@ class HipBackend:
 
     def l2norm_split3(self, x, order, eps=1e-12):
         """Unit rows as the bf16 expansion [hi | hi | lo] (order 0) / [hi | lo | hi] (order 1): (rows, 3 * cols) bf16; order 2: [hi | lo],
-        (rows, 2 * cols) -- viewed as (2 rows, cols) the interleaved codebook of gemm_argmax_hilo.  Also returns the inverse norms."""
+        (rows, 2 * cols): the codebook operand of gemm_argmax_hilo.  Also returns the inverse norms."""
         rows, cols = x.shape
         y = torch.empty((rows, (2 if order == 2 else 3) * cols), dtype=torch.bfloat16, device=x.device)
         inv = torch.empty(rows, dtype=torch.float32, device=x.device)

@@ -31,7 +31,7 @@ int ctclip_gemm_tn_try(const void* A, const void* B, void* C, const float* bias,
                        int64_t workspace_bytes, hipStream_t stream);
 int64_t ctclip_gemm_tn_workspace(int64_t M, int64_t N, int64_t K, int split_k);
 int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
-                              int32_t* part_idx, int* nparts, hipStream_t stream, int pairs);
+                              int32_t* part_idx, int* nparts, hipStream_t stream, int64_t a_wrap_k);
 int ctclip_gemm_sm_try(const void* A, const void* B, void* C, const float* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int a_kc, int b_kc, int out_dtype, int res_dtype, int accumulate,
                        float alpha, hipStream_t stream);
@@ -466,22 +466,23 @@ extern "C" int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx
   return ctclip_check_launch("argmax_reduce");
 }
 
-// The same search against a codebook given as INTERLEAVED (hi, lo) bf16 rows: B2 is (2 C, K), rows 2 c and 2 c + 1 are bf16(e_c) and
-// bf16(e_c - hi) of the unit code e_c (ctclip_l2norm_split3 order 2), A the RAW bf16 tokens: arg-max_c a . e_c = arg-max_c a^ . e_c (the norm of a
-// row is a positive factor), and a bf16 token has no low part -- two products per (token, code, dim) instead of the three of the
-// [hi | hi | lo] x [hi | lo | hi] expansion, and no expanded copy of the tokens (round 6: the 110 592 x 8 192 search 2.3 -> 1.5 ms).
-// out_val = the winning a . (hi + lo) (NOT normalised by |a|).  bf16 only, shapes the persistent NT kernel takes (K % 64 == 0, K >= 128, ceil(M / 256) x ceil(2 C / 256) >= 160 tiles);
-// others: CTCLIP_EUNSUPPORTED (the caller keeps the three-term form).  workspace >= ctclip_gemm_argmax_workspace(M, 2 C).
+// The same search on the RAW bf16 tokens: B2 is (C, 2 K), row c = [bf16(e_c) | bf16(e_c - hi)] of the unit code e_c (ctclip_l2norm_split3 order 2),
+// A the (M, K) tokens as they are: arg-max_c a . e_c = arg-max_c a^ . e_c (the norm of a row is a positive factor), and a bf16 token has no low
+// part -- two products per (token, code, dim) instead of the three of the [hi | hi | lo] x [hi | lo | hi] expansion, and no expanded copy of the
+// tokens: the persistent NT kernel reads A a second time for the k-steps behind K (epilogue family 5: [a | a] . [hi | lo] with 2 K / 64 k-steps per
+// tile).  Round 6: the 110 592 x 8 192 search 2.3 -> 1.2 ms.  out_val = the winning a . (hi + lo) (NOT normalised by |a|).  bf16 only, shapes the
+// persistent NT kernel takes (K % 64 == 0, ceil(M / 256) x ceil(C / 256) >= 160 tiles); others: CTCLIP_EUNSUPPORTED (the caller keeps the
+// three-term form).  workspace >= ctclip_gemm_argmax_workspace(M, C).
 extern "C" int ctclip_gemm_argmax_hilo(const void* A, const void* B2, int64_t* out_idx, float* out_val, int64_t M, int64_t C, int64_t K,
                                        int64_t lda, int64_t ldb, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
-  const int64_t N = 2 * C;
-  int rc = check_operands(A, B2, lda, ldb, M, N, K, 1, 1, DT_BF16);
+  int rc = check_operands(A, B2, lda, ldb, M, C, K, 1, 1, DT_BF16);
   if (rc) return rc;
-  if (workspace_bytes < ctclip_gemm_argmax_workspace(M, N) || !workspace) { ctclip_set_error("gemm_argmax_hilo: workspace too small"); return CTCLIP_EWORKSPACE; }
+  if (ldb < 2 * K) { ctclip_set_error("gemm_argmax_hilo: B2 rows hold [hi | lo]: ldb >= 2 K"); return CTCLIP_EBADARG; }
+  if (workspace_bytes < ctclip_gemm_argmax_workspace(M, C) || !workspace) { ctclip_set_error("gemm_argmax_hilo: workspace too small"); return CTCLIP_EWORKSPACE; }
   float* part_val = reinterpret_cast<float*>(workspace);
   int np = 0;
-  rc = ctclip_gemm_nt_argmax_try(A, B2, M, N, K, lda, ldb, part_val, reinterpret_cast<int32_t*>(part_val + M * 2 * cdiv(N, 256)), &np, stream, 1);
-  if (rc == 1) { ctclip_set_error("gemm_argmax_hilo: shape not served by the persistent NT kernel (K % 64 == 0, K >= 128, >= 160 tiles of 256 x 256, 16-byte aligned rows)"); return CTCLIP_EUNSUPPORTED; }
+  rc = ctclip_gemm_nt_argmax_try(A, B2, M, C, 2 * K, lda, ldb, part_val, reinterpret_cast<int32_t*>(part_val + M * 2 * cdiv(C, 256)), &np, stream, K);
+  if (rc == 1) { ctclip_set_error("gemm_argmax_hilo: shape not served by the persistent NT kernel (K % 64 == 0, >= 160 tiles of 256 x 256, 16-byte aligned rows)"); return CTCLIP_EUNSUPPORTED; }
   if (rc) return rc;
   hipLaunchKernelGGL(argmax_reduce_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, stream, part_val, reinterpret_cast<int32_t*>(part_val + M * np), out_idx,
                      out_val, M, np);

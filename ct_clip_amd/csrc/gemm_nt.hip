@@ -82,7 +82,7 @@ struct NtParams {
   int ntm, ntn;
   // arg-max epilogue (vector-quantiser code search): no C; per (row, tile column half) partial (max, lowest index of the max)
   float* part_val; int32_t* part_idx; int nparts;
-  int argmax_pairs;        // 1: B's rows are (hi, lo) pairs of one code each (ctclip_gemm_argmax_hilo): score of code c = columns 2 c + (2 c + 1), index = c
+  int a_wrap;              // epilogue family 5 (ctclip_gemm_argmax_hilo): A has a_wrap k-steps and is read again from its first column for the k-steps behind them: [x | x] without the copy
   // GEGLU epilogue (feed-forward in-projection, attention.py:39-48): B's rows are interleaved in groups of four (output column
   // 8 q + r = x feature 4 q + r, 8 q + 4 + r = its gate), so a lane's eight consecutive columns are four (x, gate) pairs; the epilogue
   // stores u = [x | gate] in the split layout the backward reads AND g = x * gelu(gate).  geglu_hp = padded hidden width (0 = off).
@@ -239,6 +239,9 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #endif
   };
   auto wrap = [](int s) { return s >= NPANEL ? s - NPANEL : s; };
+  // byte offset of A's k-step t.  Family 5: the k-steps behind a_wrap read A from its first column again (scalar arithmetic; compiled into that family only)
+  const int a_wrap = EPI == 5 ? p.a_wrap : 0;
+  auto a_koff = [&](int t) -> int64_t { return (int64_t)((EPI == 5 && t >= a_wrap) ? t - a_wrap : t) * (TK * 2); };
 
   // fragment registers, reloaded IN PLACE as soon as their last MFMA of a sub-step has been issued
   u32x4 fa[4], fb[8];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
   for (int j = 0; j < GL; ++j) glds(b_base, b_off[j], 1, j);                                  // B(0)
   if (++b_t == nk) enter_b(b_it + 1);
 #pragma unroll
-  for (int j = 0; j < GL; ++j) glds(a_base + (int64_t)a_t * (TK * 2), a_off[j], 2, j);        // A(1)
+  for (int j = 0; j < GL; ++j) glds(a_base + a_koff(a_t), a_off[j], 2, j);                    // A(1)
   if (++a_t == nk) enter_a(a_it + 1);
   wait_vm<GL>();
   __builtin_amdgcn_s_barrier();                                                               // "barrier_-1": step 0 is in LDS
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
       const int slot_a2 = wrap(cs + 4); \
       const int slot_na = wrap(cs + 2), slot_nb = wrap(cs + 3); \
       cs = wrap(cs + 2); \
-      const char* a_k = a_base + (int64_t)a_t * (TK * 2); \
+      const char* a_k = a_base + a_koff(a_t); \
       NT_RA(2, 0) NT_RA(3, 0) \
       __builtin_amdgcn_sched_barrier(0); \
       NT_H13(0) __builtin_amdgcn_sched_barrier(0); \
@@ -421,37 +424,36 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int li_e = lane_e & 15, lg_e = lane_e >> 4;
-    if (EPI == 0 && p.part_val) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
+    if (EPI == 5 || (EPI == 0 && p.part_val)) {     // kernel-uniform: row-wise arg-max over this wave's 128 columns; ties -> lowest column (torch.argmax on CPU)
       const int64_t col0 = n0 + wn * 128 + li_e * 8;
+      float keep_v = -INFINITY; int keep_i = 0x7fffffff;     // lane li keeps the result of row (a, r) = (li >> 2, li & 3) of its lane group
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float best = -INFINITY; int bidx = 0x7fffffff;
-          if (p.argmax_pairs) {        // kernel-uniform: a lane's eight consecutive columns are four codes
 #pragma unroll
-            for (int b = 0; b < 8; b += 2) {
-              const float v = acc[a][b][r] + acc[a][b + 1][r];
-              if (col0 + b < p.N && v > best) { best = v; bidx = (int)((col0 + b) >> 1); }
-            }
-          } else {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-              const float v = acc[a][b][r];
-              if (col0 + b < p.N && v > best) { best = v; bidx = (int)(col0 + b); }
-            }
+          for (int b = 0; b < 8; ++b) {
+            const float v = acc[a][b][r];
+            if (col0 + b < p.N && v > best) { best = v; bidx = (int)(col0 + b); }
           }
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bidx, o, 64);
-            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-          }
-          const int64_t row = m0 + wm * 64 + a * 16 + lg_e * 4 + r;
-          if (li_e == 0 && row < p.M) {
-            const int64_t slot = row * p.nparts + (n0 / TN) * 2 + wn;
-            p.part_val[slot] = best; p.part_idx[slot] = bidx;
-          }
+          // all-reduce over the 16 lanes of the row by DPP rotations (row_ror 8, 4, 2, 1: one VALU move each; the butterfly of __shfl_xor was
+          // eight ds_bpermute round trips per row, 128 per wave and tile -- the epilogue cost as much as the tile's eight k-steps)
+#define NT_ARG_STEP(CTRL) {                                                                                              \
+            const float ov = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best), CTRL, 0xF, 0xF, true));        \
+            const int oi = __builtin_amdgcn_mov_dpp(bidx, CTRL, 0xF, 0xF, true);                                          \
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; } }
+          NT_ARG_STEP(0x128) NT_ARG_STEP(0x124) NT_ARG_STEP(0x122) NT_ARG_STEP(0x121)
+#undef NT_ARG_STEP
+          if (li_e == a * 4 + r) { keep_v = best; keep_i = bidx; }   // (after the rotations every lane of the row holds the result)
         }
+      // ONE pair of store instructions per wave and tile (sixteen rows per lane group at once; it was one pair per row: 32 instructions on a
+      // store path that takes 60-85 clocks per instruction and CU)
+      const int64_t row = m0 + wm * 64 + (li_e >> 2) * 16 + lg_e * 4 + (li_e & 3);
+      if (row < p.M) {
+        const int64_t slot = row * p.nparts + (n0 / TN) * 2 + wn;
+        p.part_val[slot] = keep_v; p.part_idx[slot] = keep_i;
+      }
     } else {
       const bool vec_ok = ((p.ldc % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.C) % 16) == 0) &&
                           (!p.residual || (((p.ldr % 8) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) % 16) == 0)));
@@ -796,13 +798,13 @@ int ctclip_gemm_nt2_dgeglu_try(const void* A, const void* B, const void* U, void
                                int64_t ldu, int64_t lddu, bool nontemporal, hipStream_t stream);
 
 static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
-  const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : (p.comp_out ? 3 : (p.hn_out[0] ? 4 : 0)));
+  const int epi = p.geglu_hp ? 1 : (p.dgeglu_u ? 2 : (p.comp_out ? 3 : (p.hn_out[0] ? 4 : (p.a_wrap ? 5 : 0))));
   static bool raised = false;
   if (!raised) {
-    const void* fns[10] = {(const void*)gemm_nt_kernel<false, 0>, (const void*)gemm_nt_kernel<true, 0>, (const void*)gemm_nt_kernel<false, 1>,
+    const void* fns[11] = {(const void*)gemm_nt_kernel<false, 0>, (const void*)gemm_nt_kernel<true, 0>, (const void*)gemm_nt_kernel<false, 1>,
                            (const void*)gemm_nt_kernel<true, 1>, (const void*)gemm_nt_kernel<false, 2>, (const void*)gemm_nt_kernel<true, 2>,
                            (const void*)gemm_nt_kernel<false, 3>, (const void*)gemm_nt_kernel<true, 3>, (const void*)gemm_nt_kernel<false, 4>,
-                           (const void*)gemm_nt_kernel<true, 4>};
+                           (const void*)gemm_nt_kernel<true, 4>, (const void*)gemm_nt_kernel<false, 5>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NPANEL * PANEL) != hipSuccess) return 1;
     raised = true;
@@ -812,7 +814,9 @@ static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
   const dim3 grid((unsigned)ncu), block(NTH);
 #define NT_GO(E) do { if (nontemporal) hipLaunchKernelGGL((gemm_nt_kernel<true, E>), grid, block, NPANEL * PANEL, stream, p); \
                       else hipLaunchKernelGGL((gemm_nt_kernel<false, E>), grid, block, NPANEL * PANEL, stream, p); } while (0)
-  if (epi == 1) NT_GO(1); else if (epi == 2) NT_GO(2); else if (epi == 3) NT_GO(3); else if (epi == 4) NT_GO(4); else NT_GO(0);
+  if (epi == 1) NT_GO(1); else if (epi == 2) NT_GO(2); else if (epi == 3) NT_GO(3); else if (epi == 4) NT_GO(4);
+  else if (epi == 5) hipLaunchKernelGGL((gemm_nt_kernel<false, 5>), grid, block, NPANEL * PANEL, stream, p);
+  else NT_GO(0);
 #undef NT_GO
   return ctclip_check_launch("gemm_nt");
 }
@@ -820,7 +824,7 @@ static int nt_launch(const NtParams& p, bool nontemporal, hipStream_t stream) {
 // Row-wise arg-max of A B^T on the same kernel (ctclip_gemm_argmax, bf16): partials (M x nparts), nparts = 2 * ceil(N / 256).
 // Returns 1 when the shape is not eligible.
 int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, float* part_val,
-                              int32_t* part_idx, int* nparts, hipStream_t stream, int pairs) {
+                              int32_t* part_idx, int* nparts, hipStream_t stream, int64_t a_wrap_k) {
   if (K % TK || K / TK < 2) return 1;
   if ((reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(B) % 16) || (lda % 8) || (ldb % 8)) return 1;
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return 1;
@@ -829,7 +833,8 @@ int ctclip_gemm_nt_argmax_try(const void* A, const void* B, int64_t M, int64_t N
   NtParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.alpha = 1.f;
   p.ntm = (int)ntm; p.ntn = (int)ntn;
-  p.part_val = part_val; p.part_idx = part_idx; p.nparts = (int)(2 * ntn); p.argmax_pairs = pairs;
+  if (a_wrap_k && (a_wrap_k % TK || 2 * a_wrap_k != K)) return 1;      // [x | x]: exactly two passes over A
+  p.part_val = part_val; p.part_idx = part_idx; p.nparts = (int)(2 * ntn); p.a_wrap = (int)(a_wrap_k / TK);
   *nparts = p.nparts;
   return nt_launch(p, false, stream);
 }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const TI* __restrict__
 // Unit rows as a THREE-TERM bf16 expansion for an f32-grade dot product on the bf16 matrix cores: y = [hi | hi | lo] (order 0) or
 // [hi | lo | hi] (order 1) with hi = bf16(x^), lo = bf16(x^ - hi), x^ = x / max(||x||, eps) in f32.  A row of order 0 times a row of
 // order 1 is  hi.hi' + hi.lo' + lo.hi'  = x^ . x^'  up to the dropped lo.lo' term (~2^-17 of the summands).
-// order 2: y = [hi | lo] (rows of 2 cols; read as (2 rows, cols) it is the interleaved codebook of ctclip_gemm_argmax_hilo); y == NULL: only the
+// order 2: y = [hi | lo] (rows of 2 cols: the codebook operand of ctclip_gemm_argmax_hilo); y == NULL: only the
 // inverse norms (the quantiser's EMA statistics need them when the search reads the raw tokens).
 template <typename TI>
 __global__ __launch_bounds__(256) void l2norm_split3_kernel(const TI* __restrict__ x, bf16_t* __restrict__ y, float* __restrict__ inv_out,

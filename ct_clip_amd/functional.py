@@ -1378,7 +1378,7 @@ class VqFn(Function):
             # (hi, lo) expansion of the unit codebook are two products per (token, code, dim) -- K = 2 d instead of the 3 d of the form below,
             # no expanded copy of the tokens, and nothing dropped but e_lo's own rounding (~2^-17)
             es, _ = be.l2norm_split3(embed, 2)
-            idx, _ = be.gemm_argmax_hilo(x, es.view(2 * embed.shape[0], embed.shape[1]))
+            idx, _ = be.gemm_argmax_hilo(x, es)
             if training:
                 inv = be.row_inv_norms(x)
         else:

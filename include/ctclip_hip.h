@@ -149,7 +149,7 @@ int64_t ctclip_gemm_argmax_workspace(int64_t M, int64_t N);
 /* vector_quantize_pytorch CosineSimCodebook: argmax_c <x_n, e_c> (ctvit.py:403) without materialising the distance matrix. */
 int ctclip_gemm_argmax(const void* A, const void* B, int64_t* out_idx, float* out_val, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int in_dtype, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* The vector quantiser's code search (vector_quantize_pytorch CosineSimCodebook.forward, call site ctvit.py:403) on the RAW bf16 tokens: arg-max over codes c of A[m] . (B2[2c] + B2[2c+1]), B2 = the unit codebook as interleaved (hi, lo) bf16 rows (ctclip_l2norm_split3 order 2).  The arg-max does not see a row's norm and a bf16 token has no low part: K = 2 d instead of the 3 d of the [hi|hi|lo] x [hi|lo|hi] form.  out_val = the winning dot product (not normalised by |A[m]|).  bf16, K % 64 == 0, K >= 128, ceil(M / 256) x ceil(2 C / 256) >= 160 tiles; other shapes: CTCLIP_EUNSUPPORTED (use ctclip_gemm_argmax).  workspace >= ctclip_gemm_argmax_workspace(M, 2 C). */
+/* The vector quantiser's code search (vector_quantize_pytorch CosineSimCodebook.forward, call site ctvit.py:403) on the RAW bf16 tokens: arg-max over codes c of A[m] . (hi_c + lo_c), A (M, K) the tokens as they are, B2 (C, 2 K) the unit codebook's rows [hi | lo] (ctclip_l2norm_split3 order 2).  The arg-max does not see a row's norm and a bf16 token has no low part: two products per (token, code, dim) instead of the three of the [hi|hi|lo] x [hi|lo|hi] form, no expanded copy of the tokens (the kernel reads A twice along k).  out_val = the winning dot product (not normalised by |A[m]|).  bf16, K % 64 == 0, ceil(M / 256) x ceil(C / 256) >= 160 tiles; other shapes: CTCLIP_EUNSUPPORTED (use ctclip_gemm_argmax).  workspace >= ctclip_gemm_argmax_workspace(M, C). */
 int ctclip_gemm_argmax_hilo(const void* A, const void* B2, int64_t* out_idx, float* out_val, int64_t M, int64_t C, int64_t K, int64_t lda, int64_t ldb, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* FeedForward[1].weight (2 * inner, K) f32 = [x rows | gate rows] (attention.py:48) -> the bf16 operand of ctclip_gemm_geglu: (2 * hp, ldo >= K) with row 8 q + r = x row 4 q + r and row 8 q + 4 + r = gate row 4 q + r (r < 4); rows of padded features (>= inner) are zero. */
@@ -287,7 +287,7 @@ int ctclip_patch_ln_fwd(const float* video, void* out, int64_t B, int F, int H, 
 /* F.normalize(x, dim=-1) (attention.py:22-23; ct_clip.py:49-50; VQ l2norm). */
 int ctclip_l2norm_rows(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int out_dtype, hipStream_t stream);
 
-/* F.normalize rows as the three-term bf16 expansion the vector-quantiser code search multiplies on the matrix cores (vector_quantize_pytorch 1.1.2 CosineSimCodebook.forward computes the distances in f32): y (rows, 3 cols) bf16 = [hi | hi | lo] (order 0, tokens) or [hi | lo | hi] (order 1, codes) with hi = bf16(x^), lo = bf16(x^ - hi); order 2: y (rows, 2 cols) = [hi | lo], read as (2 rows, cols) the interleaved codebook of ctclip_gemm_argmax_hilo; y null: inverse norms only; inv (rows) f32 inverse norms or null. */
+/* F.normalize rows as the three-term bf16 expansion the vector-quantiser code search multiplies on the matrix cores (vector_quantize_pytorch 1.1.2 CosineSimCodebook.forward computes the distances in f32): y (rows, 3 cols) bf16 = [hi | hi | lo] (order 0, tokens) or [hi | lo | hi] (order 1, codes) with hi = bf16(x^), lo = bf16(x^ - hi); order 2: y (rows, 2 cols) = [hi | lo], the codebook operand of ctclip_gemm_argmax_hilo; y null: inverse norms only; inv (rows) f32 inverse norms or null. */
 int ctclip_l2norm_split3(const void* x, void* y, float* inv, int64_t rows, int cols, int64_t ldx, float eps, int in_dtype, int order, hipStream_t stream);
 
 /* bytes of workspace ctclip_grad_norm_clip needs. [workspace query of ctclip_grad_norm_clip (accelerator.clip_grad_norm_, scripts/CTCLIPTrainer.py:259-260)] */

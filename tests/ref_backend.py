@@ -57,10 +57,11 @@ class RefBackend:
     @staticmethod
     def gemm_argmax_hilo_ok(a, ncodes):
         M, d = a.shape
-        return a.dtype == torch.bfloat16 and d % 64 == 0 and d >= 128 and ((M + 255) // 256) * ((2 * ncodes + 255) // 256) >= 160
+        return a.dtype == torch.bfloat16 and d % 64 == 0 and ((M + 255) // 256) * ((ncodes + 255) // 256) >= 160
 
     def gemm_argmax_hilo(self, a, b2):
-        e = _f(b2[0::2]) + _f(b2[1::2])
+        K = a.shape[1]
+        e = _f(b2[:, :K]) + _f(b2[:, K:])
         val, idx = (_f(a) @ e.t()).max(dim=-1)
         return idx, val
 

@@ -90,7 +90,7 @@ soak("gemm TN weight gradient (M=2816, N=512, K=110592)",
 # ---- vector-quantiser code search (arg-max epilogue)
 xs, es = be.l2norm_split3(rnd(M, 512, dtype=torch.float32), 0)[0], be.l2norm_split3(rnd(8192, 512, dtype=torch.float32), 1)[0]
 soak("gemm_argmax (110592 x 8192 x 1536)", lambda: as_list(be.gemm_argmax(xs, es)))
-eh = be.l2norm_split3(rnd(8192, 512, dtype=torch.float32), 2)[0].view(2 * 8192, 512)
+eh = be.l2norm_split3(rnd(8192, 512, dtype=torch.float32), 2)[0]
 soak("gemm_argmax_hilo (round 6: raw tokens x (hi, lo) codebook, 110592 x 8192 x 1024)", lambda: as_list(be.gemm_argmax_hilo(x512, eh)))
 # ---- LayerNorm, PEG
 gamma, beta = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev)
