@@ -94,16 +94,32 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(p) = a;
 }
 
-// wave64 reductions (all 64 lanes participate)
+// wave64 reductions (all 64 lanes participate; every lane gets the result).  Round 6: on the vector unit only -- lanes 1, 2 apart by DPP quad
+// permutations, 4 and 8 apart by the DPP half-row / row mirrors (the partners then hold equal partial results: the mirror IS the butterfly
+// partner's value), rows 16 and 32 apart by gfx950's v_permlane16_swap / v_permlane32_swap.  __shfl_xor is a ds_bpermute round trip through
+// the LDS crossbar: six of them per reduction were ~400 clocks of latency in every row of the LayerNorm kernels.  Fixed order: deterministic.
+template <int CTRL> __device__ __forceinline__ float dpp_lanes(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_lanes<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += dpp_lanes<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += dpp_lanes<0x141>(v);      // row_half_mirror
+  v += dpp_lanes<0x140>(v);      // row_mirror
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_lanes<0xB1>(v));
+  v = fmaxf(v, dpp_lanes<0x4E>(v));
+  v = fmaxf(v, dpp_lanes<0x141>(v));
+  v = fmaxf(v, dpp_lanes<0x140>(v));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // block reductions for blockDim.x a multiple of 64 (<= 1024); `red` = >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
