@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     float mx = val[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     float mnew = fmaxf(m, mx);
     if (mnew == -INFINITY) mnew = 0.f;
     const float alpha = __expf(m - mnew);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < D / 32; ++i) vf[i] = vn[i];
   }
-  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  const float l = half_sum(lsum);
   if (qi < L) {
     const float inv = 1.f / l;
     T* O = reinterpret_cast<T*>(p.out) + ((int64_t)seq * L + qi) * p.ldo + h * D;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnParams p) {
     float mx = val[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     float mnew = fmaxf(m, mx);
     if (!FAST && mnew == -INFINITY) mnew = 0.f;
     const float alpha = FAST ? __builtin_amdgcn_exp2f(m - mnew) : __expf(m - mnew);
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnParams p) {
     *reinterpret_cast<u32x4*>(sdst + (buf ^ 1) * 2 * STILE) = staged;   // every wave finished reading that buffer before the last barrier
     __syncthreads();
   }
-  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  const float l = half_sum(lsum);
   if (active && qi < L) {
     const float inv = 1.f / l;
     T* O = reinterpret_cast<T*>(p.out) + ((int64_t)seq * L + qi) * p.ldo + h * D;
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void attn64_fwd_kernel(AttnParams p) {
     float mx = val[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, val[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     const float mnew = fmaxf(m, mx);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);
     float pr[16], ps = 0.f;
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(256) void attn64_fwd_kernel(AttnParams p) {
     *reinterpret_cast<u32x4*>(vdst + nb) = sv;
     __syncthreads();
   }
-  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  const float l = half_sum(lsum);
   if (active) {
     const float inv = 1.f / l;
     T* O = reinterpret_cast<T*>(p.out) + ((int64_t)seq * L + qi) * p.ldo + h * D;

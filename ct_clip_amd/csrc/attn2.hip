@@ -83,7 +83,7 @@ __device__ __forceinline__ void fwd_body(const Params& p, Rel& rel, char (*ring)
       float mx = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = half_max(mx);
       const float mnew = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);
       float ps = 0.f;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void fwd_body(const Params& p, Rel& rel, char (*ring)
   if (kb < nkb) step(kb, st0);
 
   lsum = (lsum + ls1) + (ls2 + ls3);
-  const float l = lsum + __shfl_xor(lsum, 32, 64);
+  const float l = half_sum(lsum);
   if (active) {
     const float inv = 1.f / l;
     bf16_t* O = p.out + ((int64_t)seq * L + qi) * p.ldo + h * D;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void dq_body(const Params& p, Rel& rel, char (*ring)[
   float delta = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) delta += dov[e] * ov[e];
-  delta += __shfl_xor(delta, 32, 64);
+  delta = half_sum(delta);
   const float lse2 = p.lse2[(int64_t)h * p.M + tok];
   const float w = SAFE ? __builtin_amdgcn_exp2f(rel.m2 - lse2) : 1.f;
 #pragma unroll

@@ -386,7 +386,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
             dkacc[i] = gk0;
           }
         }
-        const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+        const float dot = (half_sum(part[0])) + (half_sum(part[1]));
         __builtin_amdgcn_sched_barrier(0);
         bf16_t* dK = a.dk + (int64_t)row * a.ldk;
 #pragma unroll
@@ -513,7 +513,7 @@ __device__ __noinline__ void bwd1_unprep_q(UnprepArgs a_) {
           part[gq] += uq * gv;
           qx[i] = uq; dq[i] = gv;
         }
-      const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+      const float dot = (half_sum(part[0])) + (half_sum(part[1]));
       bf16_t* dQ = a.dq + (int64_t)(tq * 32 + ar) * a.lddq;
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {

@@ -420,7 +420,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
           dkacc[i] = gk0 * ks;
         }
       }
-      const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+      const float dot = (half_sum(part[0])) + (half_sum(part[1]));
       bf16_t* dK = a.dk + (int64_t)row * a.ldk;
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {
@@ -519,7 +519,7 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
           qx[i] = uq; g16[i] = gv;
         }
       }
-      const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+      const float dot = (half_sum(part[0])) + (half_sum(part[1]));
       bf16_t* dQ = a.dq + (int64_t)qrow * a.ldq;
 #pragma unroll
       for (int gq = 0; gq < 2; ++gq) {

@@ -250,7 +250,7 @@ __device__ __forceinline__ void fwd_unit(const Params& p, const SRel& rel, const
         float mx = s[ch][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[ch][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_max(mx);
         const float mnew = fmaxf(m[ch], mx);
         const float alpha = __builtin_amdgcn_exp2f(m[ch] - mnew);
         float ps = 0.f;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void fwd_unit(const Params& p, const SRel& rel, const
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const float lsum = (ls[ch][0] + ls[ch][1]) + (ls[ch][2] + ls[ch][3]);
-    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float l = half_sum(lsum);
     const float inv = 1.f / l;
     bf16_t* O = p.out + ((int64_t)it.seq * L + qi[ch]) * p.ldo + it.h * D;
 #pragma unroll
@@ -374,7 +374,7 @@ __device__ __forceinline__ void dq_block(const Params& p, const SRel& rel, const
   float delta = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) delta += dov[e] * ov[e];
-  delta += __shfl_xor(delta, 32, 64);
+  delta = half_sum(delta);
   const float w = SAFE ? __builtin_amdgcn_exp2f(rel.m2 - row.lse2) : 1.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) dov[e] *= w;
@@ -536,7 +536,7 @@ __device__ __forceinline__ void dkv_block(const Params& p, const SRel& rel, cons
       }
     // (u . g) over the 32 head dims = the four 8-dim chunks in the un-prep kernel's order: (c0 + c1) + (c2 + c3); this lane holds chunks
     // half and 2 + half, its partner (lane ^ 32) the other two
-    const float dot = (part[0] + __shfl_xor(part[0], 32, 64)) + (part[1] + __shfl_xor(part[1], 32, 64));
+    const float dot = (half_sum(part[0])) + (half_sum(part[1]));
     bf16_t* dK = p.dk_tok + tok * p.ldk_tok + it.h * D;
     bf16_t* dV = p.dv_tok + tok * p.ldv_tok + it.h * D;
 #pragma unroll

@@ -137,8 +137,8 @@ __device__ __forceinline__ Frag tile_cols(const char* tile, int lane) {
   f.v[1] = __builtin_bit_cast(bf16x8, u32x4{r10[0], r10[1], r11[0], r11[1]});
   return f;
 }
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float pair_sum(float v) { return half_sum(v); }
+__device__ __forceinline__ float pair_max(float v) { return half_max(v); }
 
 struct ShortParams {
   const bf16_t* q; const bf16_t* kv; const float* q_scale; const float* k_scale;

@@ -121,6 +121,16 @@ __device__ __forceinline__ float wave_max(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// v (+ | max) the value of the lane 32 away (the two halves of a wave hold the two half-rows of a 32 x 32 MFMA tile): one v_permlane32_swap,
+// no LDS round trip (was __shfl_xor(v, 32, 64) = ds_bpermute, in the online-softmax chain of every attention tile)
+__device__ __forceinline__ float half_sum(float v) {
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float half_max(float v) {
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 // block reductions for blockDim.x a multiple of 64 (<= 1024); `red` = >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
