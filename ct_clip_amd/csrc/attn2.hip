@@ -518,8 +518,8 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const bf16_t* __restrict
   float sa = 0.f, sb = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sa += a[e] * a[e]; sb += b[e] * b[e]; }
-  sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
-  sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
+  sa = quad_sum(sa);
+  sb = quad_sum(sb);
   const float ia = 1.f / fmaxf(sqrtf(sa), 1e-12f), ib = 1.f / fmaxf(sqrtf(sb), 1e-12f);
   if (!ok) return;
 #pragma unroll
@@ -582,8 +582,8 @@ __global__ __launch_bounds__(256) void attn_unprep_kernel(const bf16_t* __restri
       gq[e] *= qsc[e]; gk[e] *= ksc[e];
       dotq += uq[e] * gq[e]; dotk += uk[e] * gk[e];
     }
-    dotq += __shfl_xor(dotq, 1, 64); dotq += __shfl_xor(dotq, 2, 64);
-    dotk += __shfl_xor(dotk, 1, 64); dotk += __shfl_xor(dotk, 2, 64);
+    dotq = quad_sum(dotq);
+    dotk = quad_sum(dotk);
     if (ok) {
       float oq[8], ok8[8];
 #pragma unroll

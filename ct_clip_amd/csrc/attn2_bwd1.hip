@@ -412,8 +412,7 @@ __device__ __noinline__ void bwd1_steps(StepArgs a_) {
   // this item's k_scale-gradient sums: the 32 lanes of a half by an xor tree, then added to the wave's row of the LDS accumulator
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) ksacc[i] += __shfl_xor(ksacc[i], o, 64);
+    ksacc[i] = half32_sum(ksacc[i]);
   if (c == 0) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
@@ -526,8 +525,7 @@ __device__ __noinline__ void bwd1_unprep_q(UnprepArgs a_) {
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) qsacc[i] += __shfl_xor(qsacc[i], o, 64);
+    qsacc[i] = half32_sum(qsacc[i]);
   if (c == 0) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
@@ -628,9 +626,9 @@ __device__ __forceinline__ void bwd1_body(const Params& p, const X1& x, const G1
         float ds = 0.f, dn = 0.f, vnn = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ds += x8[e] * b[e]; dn += x8[e] * x8[e]; vnn += v8[e] * v8[e]; }
-        ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
-        dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
-        vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
+        ds = quad_sum(ds);
+        dn = quad_sum(dn);
+        vnn = quad_sum(vnn);
         nd[row] = -ds;                                                // (the four chunk threads of a row hold the same value)
         mxd = fmaxf(mxd, dn); mxv = fmaxf(mxv, vnn);                  // |dS| <= P 2 |dO_q| |v_k| with the probability P <= 1
       }

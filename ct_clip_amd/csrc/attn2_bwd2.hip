@@ -290,6 +290,9 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
     // (Prescribing the instruction mix of B and C with sched_group_barrier -- one matrix instruction per six vector and five LDS instructions --
     // measured 3-5 % SLOWER than leaving the order inside a phase to the scheduler: profiles/r06_attn_bwd2.md.)
 #define BWD2_TST(i) do { if (BWD2_TSTAMPS && a.bstamps && kbi == 1 && a.seq0 == 0 && threadIdx.x == 0) *GLB(unsigned long long, a.bstamps + 192 + (i)) = __builtin_readcyclecounter(); } while (0)
+#ifndef BWD2_DPP_SUMS
+#define BWD2_DPP_SUMS 0           // 1: the un-preps' lane sums by DPP / permlane swaps instead of __shfl_xor (A/B: profiles/r06_ab_experiments.md)
+#endif
 #ifndef BWD2_DQ_IN_B
 #define BWD2_DQ_IN_B 0             // 1: the two dQ^T matrix instructions of tile T - 1 are issued in phase B of tile T (8 + 4 instead of 6 + 6 per phase): 480-491 against 444-445 us
 #endif
@@ -445,8 +448,12 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   // this item's k_scale-gradient sums: the 32 lanes of a half by an xor tree, then added to the wave's row of the LDS accumulator
 #pragma unroll
   for (int i = 0; i < 16; ++i)
+#if BWD2_DPP_SUMS
+    ksacc[i] = half32_sum(ksacc[i]);
+#else
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) ksacc[i] += __shfl_xor(ksacc[i], o, 64);
+#endif
   if (c == 0) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
@@ -532,8 +539,12 @@ __device__ __noinline__ void bwd2_steps(Steps2 a_) {
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i)
+#if BWD2_DPP_SUMS
+    qsacc[i] = half32_sum(qsacc[i]);
+#else
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) qsacc[i] += __shfl_xor(qsacc[i], o, 64);
+#endif
   if (c == 0) {
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
@@ -600,9 +611,13 @@ __device__ __noinline__ float bwd2_load(Load2 a_) {
         float ds = 0.f, dn = 0.f, vnn = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ds += x8[e] * b[e]; dn += x8[e] * x8[e]; vnn += v8[e] * v8[e]; }
+#if BWD2_DPP_SUMS
+        ds = quad_sum(ds); dn = quad_sum(dn); vnn = quad_sum(vnn);
+#else
         ds += __shfl_xor(ds, 1, 64); ds += __shfl_xor(ds, 2, 64);
         dn += __shfl_xor(dn, 1, 64); dn += __shfl_xor(dn, 2, 64);
         vnn += __shfl_xor(vnn, 1, 64); vnn += __shfl_xor(vnn, 2, 64);
+#endif
         uint32_t w0, w1;
         split3(-ds, w0, w1);
         if (ch < 2) trip[row * 4 + ch] = ch ? w1 : w0;              // (the four chunk threads of a row hold the same value)

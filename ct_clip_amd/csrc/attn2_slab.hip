@@ -624,8 +624,7 @@ __global__ __launch_bounds__(NTH) void dkv_slab_kernel(Params p, Geo g, int item
   if (TOK) {           // k_scale gradient of this workgroup, in a fixed order: the 32 key lanes of a half by an xor tree, then the eight waves
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) ksacc[i] += __shfl_xor(ksacc[i], o, 64);
+      ksacc[i] = half32_sum(ksacc[i]);
     __syncthreads();                                           // the slabs are free now
     float* red = reinterpret_cast<float*>(slabs);              // [SW][32]
     if (c == 0) {

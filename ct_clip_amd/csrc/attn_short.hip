@@ -357,8 +357,7 @@ __global__ __launch_bounds__(WPB_B * 64, 2) void attn_short_bwd_kernel(ShortPara
   // fold the scale gradients: the 32 token lanes of each half, then the waves of the workgroup in order -> one partial row per workgroup
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { dsq[i] += __shfl_xor(dsq[i], o, 64); dsk[i] += __shfl_xor(dsk[i], o, 64); }
+    { dsq[i] = half32_sum(dsq[i]); dsk[i] = half32_sum(dsk[i]); }
   }
   if (row == 0) {
 #pragma unroll

@@ -131,6 +131,18 @@ __device__ __forceinline__ float half_max(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// sum over the aligned group of 4 lanes (xor 1, xor 2) / of 32 lanes (xor 1 ... 16): the ascending butterfly's tree, on the vector unit
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_lanes<0xB1>(v);
+  return v + dpp_lanes<0x4E>(v);
+}
+__device__ __forceinline__ float half32_sum(float v) {
+  v = quad_sum(v);
+  v += dpp_lanes<0x141>(v);
+  v += dpp_lanes<0x140>(v);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
 // block reductions for blockDim.x a multiple of 64 (<= 1024); `red` = >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

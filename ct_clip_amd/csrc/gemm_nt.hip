@@ -658,7 +658,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
               float ss = 0.f;
 #pragma unroll
               for (int b = 0; b < 8; ++b) ss += v[b] * v[b];
-              ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+              ss = quad_sum(ss);
               const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
               for (int b = 0; b < 8; ++b) v[b] *= inv * sc[b] * mult;
