@@ -9,7 +9,10 @@ namespace {
 #define PATCH_LN_XCD 1     // 0 = token = workgroup index (A/B builds)
 #endif
 #ifndef LN_FWD_RU
-#define LN_FWD_RU 4
+#define LN_FWD_RU 8     // rows in flight per wave, forward (round 6: 4 -> 8 once the reductions left the LDS crossbar: 44.3 -> 41.4 us isolated)
+#endif
+#ifndef LN_BWD_RU
+#define LN_BWD_RU 4     // rows in flight per wave, backward (round 6: 2 -> 4: 82 -> 74 us plain, 118 -> 110.5 with two addends, isolated)
 #endif
 constexpr int LN_MAXV = 4;  // up to 64 lanes * 8 * 4 = 2048 columns per row
 
@@ -362,9 +365,9 @@ extern "C" int ctclip_layernorm_bwd_partials(const void* dy, const void* x, cons
   float* part = (float*)partials;
   const size_t shm = (size_t)4 * 2 * cols * sizeof(float);
   const int nv = (cols + 511) / 512;
-  const bool two = nv == 1 && rows >= 65536;        // two rows in flight per wave on the big token grids of the image tower
+  const bool two = nv == 1 && rows >= 65536;        // LN_BWD_RU rows in flight per wave on the big token grids of the image tower
 #define LNB(T, NVV, RUU) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NVV, RUU>), dim3((unsigned)nb), dim3(256), shm, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, part, rows, cols, (const T*)add1, (const T*)add2)
-#define LNB_NV(T) do { if (nv == 1) { if (two) LNB(T, 1, 2); else LNB(T, 1, 1); } else if (nv == 2) LNB(T, 2, 1); else if (nv == 3) LNB(T, 3, 1); else LNB(T, 4, 1); } while (0)
+#define LNB_NV(T) do { if (nv == 1) { if (two) LNB(T, 1, LN_BWD_RU); else LNB(T, 1, 1); } else if (nv == 2) LNB(T, 2, 1); else if (nv == 3) LNB(T, 3, 1); else LNB(T, 4, 1); } while (0)
   if (dtype == DT_F32) LNB_NV(float);
   else if (dtype == DT_BF16) LNB_NV(bf16_t);
   else return CTCLIP_EUNSUPPORTED;

@@ -430,7 +430,12 @@ bool lds_path_enabled() {
 
 // TB = 12 when that fills the chip, else TB = 4 (three workgroups per CU).  D3 = 8 always takes TB = 4: at thirteen waves per workgroup (128
 // registers) the two-column threads of that geometry spill, at five waves they do not.
-int pick_tb(int64_t B, int D2, int D3, int C) { return (D3 != 8 && B * ((D2 + 11) / 12) * (C / PCC) >= 200) ? 12 : 4; }
+int pick_tb(int64_t B, int D2, int D3, int C) {
+  static int forced = -1;                                  // CTCLIP_PEG_TB=4|12: A/B timing of the tile height
+  if (forced < 0) { const char* e = getenv("CTCLIP_PEG_TB"); forced = e ? atoi(e) : 0; }
+  if ((forced == 4 || forced == 12) && D3 != 8) return forced;
+  return (D3 != 8 && B * ((D2 + 11) / 12) * (C / PCC) >= 200) ? 12 : 4;
+}
 
 template <int TB, int D3, int DIR>
 int launch_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, const bf16_t* ein, bf16_t* rres, int64_t B, int D1, int D2, int C, hipStream_t s) {

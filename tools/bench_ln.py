@@ -33,3 +33,12 @@ us = timeit(lambda: be.layernorm_fwd(x, gamma, beta, 1e-5))
 print(f"layernorm_fwd {us:7.1f} us  {2 * M * D * 2 / us / 1e3:7.0f} GB/s")
 yr = torch.nn.functional.layer_norm(x.float(), (D,), gamma, beta, 1e-5)
 print("max abs err vs torch", float((y.float() - yr).abs().max()))
+
+dgam, dbet = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+us = timeit(lambda: be.layernorm_bwd(dy, x, gamma, mean, rstd, dgam, dbet))
+print(f"layernorm_bwd {us:7.1f} us  {3 * M * D * 2 / us / 1e3:7.0f} GB/s (dy, x -> dx)")
+a1 = torch.randn(M, D, device="cuda", generator=g).to(torch.bfloat16)
+us = timeit(lambda: be.layernorm_bwd(dy, x, gamma, mean, rstd, dgam, dbet, a1, None))
+print(f"layernorm_bwd + 1 add {us:7.1f} us  {4 * M * D * 2 / us / 1e3:7.0f} GB/s")
+us = timeit(lambda: be.layernorm_bwd(dy, x, gamma, mean, rstd, dgam, dbet, a1, a1))
+print(f"layernorm_bwd + 2 adds {us:7.1f} us  {5 * M * D * 2 / us / 1e3:7.0f} GB/s")
