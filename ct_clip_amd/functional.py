@@ -207,6 +207,16 @@ def sink_of(param):
     return getattr(param, "_ctclip_grad_sink", None)
 
 
+def take_fresh_grad(param):
+    """True once after the owning FusedAdam cleared its gradients (FusedAdam._mark_fresh): the caller -- which must be the only writer of this
+    parameter's gradient, on the stream the clearing is ordered before -- may then OVERWRITE the (zero) gradient instead of accumulating into it.
+    Anything else that clears gradients leaves the flag alone: the caller accumulates into zeros, which is merely slower."""
+    fresh = getattr(param, "_ctclip_grad_fresh", False)
+    if fresh:
+        param._ctclip_grad_fresh = False
+    return fresh
+
+
 def _split_k_for(n_rows, n_cols, K, dtype):
     tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
     bk = 32 if dtype == torch.float32 else 64
@@ -1421,7 +1431,9 @@ class VisualLatentFn(Function):
         dw = None
         if w.requires_grad:
             dw = sink if sink is not None else torch.empty(w.shape, dtype=torch.float32, device=dy.device)
-        dx = B().visual_latent_bwd(dy.contiguous(), x, wsh, dw, accumulate=sink is not None, want_dx=ctx.needs_input_grad[0])
+        # the 604-MB gradient of the 151-M-parameter weight: the first write after the optimiser cleared it overwrites (no read of the zeros)
+        accumulate = sink is not None and not take_fresh_grad(w)
+        dx = B().visual_latent_bwd(dy.contiguous(), x, wsh, dw, accumulate=accumulate, want_dx=ctx.needs_input_grad[0])
         return dx, (None if sink is not None else dw), None
 
 

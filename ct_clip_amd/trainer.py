@@ -105,6 +105,7 @@ class FusedAdam:
         """overlap=True (the trainer's step): the 1.1-GB fill runs on a side stream behind the optimiser step, UNDER the next step's forward
         (nothing writes a gradient before the next backward); `wait_zero()` -- called by the trainer right before backward -- orders the
         backward behind it.  Default: on the caller's stream, complete in stream order."""
+        self._mark_fresh()
         if not (overlap and self.flat_grad.is_cuda) or torch.cuda.is_current_stream_capturing():
             self.wait_zero()
             self.flat_grad.zero_()
@@ -118,6 +119,12 @@ class FusedAdam:
         with torch.cuda.stream(self._zero_stream):
             self.flat_grad.zero_()
             self._zero_done = self._zero_stream.record_event()
+
+    def _mark_fresh(self):
+        """Every gradient of this optimiser is (being) cleared: a backward function that is the ONLY writer of a parameter's gradient may
+        overwrite instead of read-modify-write on its first write (functional.take_fresh_grad; today: to_visual_latent's 604-MB gradient)."""
+        for p in self.params:
+            p._ctclip_grad_fresh = True
 
     def wait_zero(self):
         """The current stream waits for an overlapped zero_grad (no-op otherwise)."""
@@ -139,6 +146,8 @@ class FusedAdam:
         self.lr = self.param_groups[0]["lr"]          # learning-rate schedules write param_groups (finetune.cosine_lr)
         be.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                      self.eps, self.step_count, self.weight_decay, clip if max_grad_norm else None, self.decay_mask4, zero_grad=zero_grad)
+        if zero_grad:
+            self._mark_fresh()
         Fn.bump_weight_epoch(self.params)
         Fn.refresh_shadows(self.params)   # every bf16 GEMM operand of THIS optimiser's parameters rebuilt from the new f32 weights in one launch
 
