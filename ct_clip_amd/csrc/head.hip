@@ -9,6 +9,9 @@ namespace {
 
 constexpr int VL_MAXB = 8;    // rows of X per call (the host loops over chunks of 8 samples)
 constexpr int VL_KCH = 2048;  // k-chunk per block
+#ifndef VL_FWD_RG
+#define VL_FWD_RG 2             // f32 forward: groups of four weight rows per wave and staged X chunk
+#endif
 // wide form of the BACKWARD (f32 only): up to 24 rows per launch, 4 k per lane -- the VocabFine step projects its 18 pooled vectors (one per
 // pathology) and used to stream the 604-MB weight and its gradient (read + write) once per chunk of 8 rows: 3 x 440 us, now 644-655.
 // Measured and dropped: 2 k per lane (1 032 us), the weight rows split over the halves of a workgroup (668 us: 253 registers allow two
@@ -33,12 +36,29 @@ template <int KW> __device__ __forceinline__ void storek(bf16_t* p, const float 
 
 // part[chunk][b][n] = sum_{k in chunk} X[b][k] * W[n][k].  block = 4 waves x 4 weight rows; X chunk staged in LDS as f32.
 // (The k-chunks are combined by vlat_reduce_kernel in chunk order: the first version added them with f32 atomics.)
-template <typename T>
+template <typename T, int RG = 1>      // RG: groups of four weight rows per wave and staged X chunk (2: half the staging traffic)
 __global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, const T* __restrict__ W, float* __restrict__ part, int Bm,
                                                        int N, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [Bm][VL_KCH]
   const int64_t k0 = (int64_t)blockIdx.y * VL_KCH;
   const int kc = (int)((K - k0) < VL_KCH ? (K - k0) : VL_KCH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbase = (blockIdx.x * 4 + wave) * 4 * RG;
+  // the weight rows of k-slice `it` (64 lanes x 8 k): requested one slice AHEAD of their use, the first one before the X chunk is staged
+  // (round 6: the loop used to fetch and consume a slice per iteration -- one memory round trip per slice and wave, behind the staging barrier:
+  // 2.8 TB/s)
+  constexpr int NIT = VL_KCH / 512;
+  float w[2][4][8];
+  auto loadw = [&](int j, float (&dst)[4][8]) {            // j = row group * NIT + k-slice
+    const int c = lane * 8 + (j % NIT) * 512, n0 = nbase + (j / NIT) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[r][e] = 0.f;
+      if (n0 + r < N && c < kc) load8(W + (int64_t)(n0 + r) * K + k0 + c, dst[r]);
+    }
+  };
+  loadw(0, w[0]);
   for (int i = threadIdx.x; i < Bm * (VL_KCH / 8); i += 256) {
     const int b = i / (VL_KCH / 8), c = (i % (VL_KCH / 8)) * 8;
     float v[8];
@@ -49,23 +69,15 @@ __global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, 
     for (int e = 0; e < 8; ++e) xs[b * VL_KCH + c + e] = v[e];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 4;
   float acc[4][VL_MAXB];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int b = 0; b < VL_MAXB; ++b) acc[r][b] = 0.f;
-  for (int c = lane * 8; c < kc; c += 512) {
-    float w[4][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (n0 + r < N) load8(W + (int64_t)(n0 + r) * K + k0 + c, w[r]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w[r][e] = 0.f;
-      }
-    }
+  for (int j = 0; j < RG * NIT; ++j) {
+    if (j + 1 < RG * NIT) loadw(j + 1, w[(j + 1) & 1]);
+    const int c = lane * 8 + (j % NIT) * 512;
 #pragma unroll
     for (int b = 0; b < VL_MAXB; ++b) {
       if (b < Bm) {
@@ -75,19 +87,23 @@ __global__ __launch_bounds__(256) void vlat_fwd_kernel(const T* __restrict__ X, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[r][b] += w[r][e] * xv[e];
+          for (int e = 0; e < 8; ++e) acc[r][b] += w[j & 1][r][e] * xv[e];
       }
+    }
+    if (j % NIT == NIT - 1) {                               // this row group is complete
+      const int n0 = nbase + (j / NIT) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < VL_MAXB; ++b) {
+          if (b < Bm) {
+            const float t = wave_sum(acc[r][b]);
+            if (lane == 0 && n0 + r < N) part[((int64_t)blockIdx.y * Bm + b) * N + n0 + r] = t;
+          }
+          acc[r][b] = 0.f;
+        }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int b = 0; b < VL_MAXB; ++b) {
-      if (b < Bm) {
-        const float t = wave_sum(acc[r][b]);
-        if (lane == 0 && n0 + r < N) part[((int64_t)blockIdx.y * Bm + b) * N + n0 + r] = t;
-      }
-    }
 }
 
 __global__ __launch_bounds__(256) void vlat_reduce_kernel(const float* __restrict__ part, int nchunk, int n, float* __restrict__ Y) {
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void vlat_reduce_kernel(const float* __restric
 // Each thread owns KW consecutive k.  dX[b][k] = sum_n dY[b][n] W[n][k] ;  dW[n][k] (+)= sum_b dY[b][n] X[b][k].
 // The walk over n is unrolled by four with every load of the group issued first (the first version fetched W and the old dW of one
 // row per iteration, the latter behind a branch: one dependent round trip per row at 2 waves per CU -- 800 us for 1.5 GB).
-template <typename T, bool ACC, bool WANT_DW, int MAXB = VL_MAXB, int KW = 8, int THREADS = 128>
+template <typename T, bool ACC, bool WANT_DW, int MAXB = VL_MAXB, int KW = 8, int THREADS = 128, int UNR = 4>
 __global__ __launch_bounds__(THREADS) void vlat_bwd_kernel(const float* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ W,
                                                            T* __restrict__ dX, float* __restrict__ dW, int Bm, int N, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) float dys[];  // [Bm][N]
@@ -116,7 +132,6 @@ __global__ __launch_bounds__(THREADS) void vlat_bwd_kernel(const float* __restri
     for (int e = 0; e < KW; ++e) { xv[b][e] = 0.f; dx[b][e] = 0.f; }
     if (b < Bm) loadk<KW>(X + (int64_t)b * K + k, xv[b]);
   }
-  constexpr int UNR = 4;
   for (int n0 = 0; n0 < N; n0 += UNR) {
     float w[UNR][KW], old[UNR][KW];
 #pragma unroll
@@ -342,12 +357,12 @@ extern "C" int ctclip_visual_latent_fwd(const void* X, const void* W, float* Y, 
   const size_t shm = (size_t)Bm * VL_KCH * sizeof(float);
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<float, VL_FWD_RG>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void*)vlat_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     raised = true;
   }
   float* part = (float*)workspace;
-  if (dtype == DT_F32) hipLaunchKernelGGL(vlat_fwd_kernel<float>, grid, dim3(256), shm, s, (const float*)X, (const float*)W, part, Bm, N, K);
+  if (dtype == DT_F32) hipLaunchKernelGGL((vlat_fwd_kernel<float, VL_FWD_RG>), dim3((unsigned)cdiv(N, 16 * VL_FWD_RG), (unsigned)nchunk), dim3(256), shm, s, (const float*)X, (const float*)W, part, Bm, N, K);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(vlat_fwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)X, (const bf16_t*)W, part, Bm, N, K);
   else return CTCLIP_EUNSUPPORTED;
   hipLaunchKernelGGL(vlat_reduce_kernel, dim3((unsigned)cdiv(Bm * N, 256)), dim3(256), 0, s, (const float*)part, nchunk, Bm * N, Y);
@@ -377,6 +392,20 @@ extern "C" int ctclip_visual_latent_bwd(const float* dY, const void* X, const vo
     return ctclip_check_launch("visual_latent_bwd (wide)");
   }
   dim3 grid((unsigned)cdiv(K / 8, 128));
+#ifndef VL_F32_KW
+#define VL_F32_KW 4          // f32 operands: k per lane / weight rows in flight per lane of the 8-row backward (8 / 4: 576 waves for the whole chip)
+#endif
+#ifndef VL_F32_UNR
+#define VL_F32_UNR 16
+#endif
+  if (dtype == DT_F32 && VL_F32_KW != 8) {
+    dim3 g4((unsigned)cdiv(K / VL_F32_KW, 128));
+#define VLF(ACC, WDW, U) hipLaunchKernelGGL((vlat_bwd_kernel<float, ACC, WDW, VL_MAXB, VL_F32_KW, 128, U>), g4, dim3(128), shm, s, dY, (const float*)X, (const float*)W, (float*)dX, dW, Bm, N, K)
+    // (same box, us: overwrite 383 at 8 k x 4 rows in flight per lane, 343 at 4 x 4, 297 at 4 x 8, 275 at 4 x 16; accumulate 424 / 365 / 400 / 415)
+    if (!dW) VLF(false, false, VL_F32_UNR); else if (accumulate) VLF(true, true, 4); else VLF(false, true, VL_F32_UNR);
+#undef VLF
+    return ctclip_check_launch("visual_latent_bwd");
+  }
 #define VLB(T, ACC, WDW) hipLaunchKernelGGL((vlat_bwd_kernel<T, ACC, WDW>), grid, dim3(128), shm, s, dY, (const T*)X, (const T*)W, (T*)dX, dW, Bm, N, K)
 #define VLB_T(T) do { if (!dW) VLB(T, false, false); else if (accumulate) VLB(T, true, true); else VLB(T, false, true); } while (0)
   if (dtype == DT_F32) VLB_T(float);
