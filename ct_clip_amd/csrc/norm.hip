@@ -349,7 +349,10 @@ extern "C" int ctclip_layernorm_fwd(const void* x, const float* gamma, const flo
   return ctclip_check_launch("layernorm_fwd");
 }
 
-static int64_t ln_bwd_blocks(int64_t rows) { int64_t nb = cdiv(rows, 8); if (nb > 1024) nb = 1024; return nb < 1 ? 1 : nb; }
+#ifndef LN_BWD_BLOCKS
+#define LN_BWD_BLOCKS 512      // workgroups (= partial rows of the dgamma / dbeta fold) of the backward on big grids (two per CU: 1024 / 512 / 2048 measured 73.4 / 72.9 / 79.8 us plain, 112.7 / 110.4 / 118.5 with two addends)
+#endif
+static int64_t ln_bwd_blocks(int64_t rows) { int64_t nb = cdiv(rows, 8); if (nb > LN_BWD_BLOCKS) nb = LN_BWD_BLOCKS; return nb < 1 ? 1 : nb; }
 extern "C" int64_t ctclip_layernorm_bwd_workspace(int64_t rows, int cols) { return ln_bwd_blocks(rows) * 2 * cols * 4; }
 
 // LayerNorm backward, first half: dx (+ add1 + add2: optional same-shape gradients of the input's other consumers, see the kernel) and, when
