@@ -288,6 +288,11 @@ def attention_block_util(args, device, dtype, iters=10):
         tab0 = cpb(hw, hw)                       # the position-bias MLP runs once per forward for ALL spatial layers (ctvit.py:293)
     tab = tab0.detach().requires_grad_(True)     # ... but its table gradient (dBias) is part of every layer's backward
 
+    # the block's parameters get gradient sinks (views of one flat f32 buffer) as every parameter of the trainer has: their gradients are written by
+    # the kernels themselves, not by autograd's AccumulateGrad (~10 fill / add launches of 5 us per backward that the training step does not have)
+    from ct_clip_amd.trainer import FusedAdam
+    sinks = FusedAdam(list(attn.named_parameters()), lr=0.0)      # noqa: F841  (keeps the flat buffers alive)
+
     def block():
         xn, x_kv, xr = Fn.layer_norm_branch(x, attn.norm.gamma, None, 2)
         # (the product's own composition, ctvit.Transformer.forward: the projections write the attention operands from their epilogues)
@@ -318,7 +323,7 @@ def attention_block_util(args, device, dtype, iters=10):
                 gflop_fwd=round(flops_fwd / 1e9, 1), gflop_fwd_bwd=round(3 * flops_fwd / 1e9, 1),
                 tflops_fwd=round(flops_fwd / fwd / 1e6, 1), tflops_fwd_bwd=round(3 * flops_fwd / tot / 1e6, 1),
                 mfma_util_fwd=round(flops_fwd / fwd / 1e6 / peak, 4), mfma_util_fwd_bwd=round(3 * flops_fwd / tot / 1e6 / peak, 4),
-                peak_tflops=peak, note="event pairs on the launch stream; every layout / normalisation kernel between the projections and the "
+                peak_tflops=peak, note="event pairs on the launch stream; the block's parameters have gradient sinks as in the trainer (round 6); every layout / normalisation kernel between the projections and the "
                                        "attention core and the position-bias table gradient (dBias) are inside; the position-bias MLP itself "
                                        "(once per forward for all layers) is outside")
 
