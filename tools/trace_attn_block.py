@@ -36,14 +36,6 @@ args = argparse.Namespace(image=480, frames=240, batch=8)
 be = backend.get()
 dev = torch.device("cuda", 0)
 spin = lambda: be.lib.ctclip_spin(20, torch.cuda.current_stream().cuda_stream)      # markers in the trace
-orig = bench.attention_block_util
-
-
-def marked(*a, **k):
-    return orig(*a, **k)
-
-
-# two marked repetitions: the block's own timing loop runs `iters` forward + backward pairs; markers around the whole call
 spin(); out = bench.attention_block_util(args, dev, torch.bfloat16, iters=1); spin()
 torch.cuda.synchronize()
 print(out["fwd_us"], out["fwd_bwd_us"])
