@@ -570,3 +570,45 @@ def test_side_stream_without_a_free_queue_warns_once(monkeypatch, capsys):
     streams.forget("cuda:0", "text")
     streams.concurrent_stream("cuda:0", "text")
     assert capsys.readouterr().err == "", "once per purpose"
+
+
+def test_first_gradient_write_after_a_clear_overwrites_later_ones_accumulate(ref_backend, monkeypatch):
+    """Round 6: to_visual_latent's 604-MB gradient is OVERWRITTEN by the first backward after the optimiser cleared its gradients (no read of the
+    zeros) and accumulated into by every later backward before the next clear -- two backwards give the sum, a clear in between gives the last."""
+    from ct_clip_amd import functional as Fn
+    from ct_clip_amd.trainer import FusedAdam
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(16, 64) * 0.1)
+    opt = FusedAdam([("w", w)], lr=0.0)
+    calls = []
+    be = backend.get()
+    real = be.visual_latent_bwd
+    monkeypatch.setattr(be, "visual_latent_bwd", lambda dy, x, wsh, dw=None, accumulate=False, want_dx=True:
+                        (calls.append(bool(accumulate)), real(dy, x, wsh, dw, accumulate, want_dx))[1])
+    xs = [torch.randn(3, 64) for _ in range(3)]
+    gs = [torch.randn(3, 16) for _ in range(3)]
+
+    def backward(i):
+        x = xs[i].clone().requires_grad_(True)
+        (Fn.visual_latent(x, w) * gs[i]).sum().backward()
+
+    want = [g.t() @ x for g, x in zip(gs, xs)]
+    w.grad.fill_(7.0)                       # stale content that a first write must not keep ...
+    opt.zero_grad()                         # ... and that the clear removes anyway
+    backward(0)
+    backward(1)
+    assert calls == [False, True]
+    torch.testing.assert_close(w.grad, want[0] + want[1], rtol=1e-5, atol=1e-5)
+    opt.zero_grad()
+    backward(2)
+    assert calls == [False, True, False]
+    torch.testing.assert_close(w.grad, want[2], rtol=1e-5, atol=1e-5)
+    opt.step(None, zero_grad=True)          # Adam clearing the gradients it has read marks them fresh too
+    backward(0)
+    assert calls[-1] is False
+    torch.testing.assert_close(w.grad, want[0], rtol=1e-5, atol=1e-5)
+    # a clear that does not go through the optimiser leaves the flag alone: the next backward accumulates into the zeros (slower, not wrong)
+    w.grad.zero_()
+    backward(1)
+    assert calls[-1] is True
+    torch.testing.assert_close(w.grad, want[1], rtol=1e-5, atol=1e-5)
