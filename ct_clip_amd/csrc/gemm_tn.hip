@@ -294,8 +294,10 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int nsplit, in
 // one 256 x 256 tile per CU (the 160-KiB ring allows one workgroup per CU: more than 256 workgroups would run in two rounds):
 // nsplit = floor(256 / tiles), at least 8 k-steps per split
 int pick_split(int64_t tiles, int64_t ksteps, int requested) {
-  int64_t s = requested > 0 ? requested : 256 / tiles;
-  if (s * tiles > 256) s = 256 / tiles;
+  static int64_t wgs = 0;                                  // CTCLIP_TN_WGS=<n>: workgroups (tiles x splits) per launch, A/B timing (default 256 = one per CU)
+  if (!wgs) { const char* e = getenv("CTCLIP_TN_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 8 || wgs > 256) wgs = 256; }
+  int64_t s = requested > 0 ? requested : wgs / tiles;
+  if (s * tiles > wgs) s = wgs / tiles;
   if (s > ksteps / 8) s = ksteps / 8;
   return s < 1 ? 1 : (int)s;
 }

@@ -276,6 +276,8 @@ _WG = {"on": False, "streams": {}, "used": set()}
 
 def wgrad_stream_begin():
     _WG["on"] = os.environ.get("CTCLIP_WGRAD_STREAM", "1") != "0"
+    _WG["bracket"] = True      # inside the trainer's backward: the weight-gradient GEMMs take _side_wgs() workgroups whether or not the stream is used
+                               # (CTCLIP_WGRAD_STREAM=0 then sums in the same order: test_zz_side_stream_backward_is_bit_identical)
 
 
 def _wgrad_side(t):
@@ -307,6 +309,7 @@ def wgrad_stream_end():
         torch.cuda.current_stream(torch.device("cuda", i)).wait_stream(_WG["streams"][i])
     _WG["used"].clear()
     _WG["on"] = False
+    _WG["bracket"] = False
 
 
 def weight_grad(dy, x, weight, segments, K):
@@ -318,12 +321,29 @@ def weight_grad(dy, x, weight, segments, K):
         dy.record_stream(side); x.record_stream(side)               # ... and may be freed there while the side stream still reads them
         _WG["used"].add(dy.device.index)
         with torch.cuda.stream(side):
-            _weight_grad(dy, x, weight, segments, K, sink)
+            _weight_grad(dy, x, weight, segments, K, sink, wgs=_side_wgs())
         return None
-    return _weight_grad(dy, x, weight, segments, K, sink)
+    return _weight_grad(dy, x, weight, segments, K, sink, wgs=_side_wgs() if (_WG.get("bracket") and sink is not None and dy.shape[0] >= 4096) else 0)
 
 
-def _weight_grad(dy, x, weight, segments, K, sink):
+def _side_wgs():
+    """Workgroups (tiles x k-splits) of a weight-gradient GEMM launched on the SIDE stream: 192 of the 256 CUs.  The split-K kernel and the
+    grad-input GEMM of the main stream are both persistent one-workgroup-per-CU kernels: with 256 workgroups each, the second to arrive waits
+    for whole CUs; 192 leave a quarter of the chip to the main stream and write a quarter less split-K slab traffic.  Measured (same box, twice
+    each, ms per 12+12 step): 256: 79.4 / 79.5; 224: 78.6; 208: 78.9; 192: 78.0 / 78.1; 176: 78.4; 160: 78.1 / 78.5; 128: 81.2.
+    Outside the trainer's backward bracket (fine-tuning heads, the attention-block benchmark) a launch keeps the whole chip."""
+    return int(os.environ.get("CTCLIP_WGRAD_WGS", "192"))
+
+
+def _split_for(wgs, rows, cols):
+    """k-split request of ctclip_gemm for a (rows x cols) weight gradient limited to `wgs` workgroups of 256 x 256 tiles (0 = the library's choice)"""
+    if not wgs:
+        return 0
+    tiles = ((rows + 255) // 256) * ((cols + 255) // 256)
+    return max(1, wgs // tiles)
+
+
+def _weight_grad(dy, x, weight, segments, K, sink, wgs=0):
     if sink is None:
         dst = torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
     else:
@@ -335,13 +355,14 @@ def _weight_grad(dy, x, weight, segments, K, sink):
         # added to their places -- two launches per segment read x (113 MB) once per segment
         c_lo, c_hi = min(c0 for _, _, c0 in segments), max(c0 + n for _, n, c0 in segments)
         tmp = torch.empty((c_hi - c_lo, K), dtype=torch.float32, device=dy.device)
-        B().gemm(dy[:, c_lo:c_hi], x[:, :K], a_kc=False, b_kc=False, out=tmp, accumulate=False, split_k=0, M=c_hi - c_lo, N=K, K=dy.shape[0])
+        B().gemm(dy[:, c_lo:c_hi], x[:, :K], a_kc=False, b_kc=False, out=tmp, accumulate=False, split_k=_split_for(wgs, c_hi - c_lo, K),
+                 M=c_hi - c_lo, N=K, K=dy.shape[0])
         for (r0, n, c0) in segments:
             B().accumulate(dst2[r0:r0 + n], tmp[c0 - c_lo:c0 - c_lo + n])
         return None if sink is not None else dst
     for (r0, n, c0) in segments:
         B().gemm(dy[:, c0:c0 + n], x[:, :K], a_kc=False, b_kc=False, out=dst2[r0:r0 + n, :K], accumulate=True,
-                 split_k=0, M=n, N=K, K=dy.shape[0])
+                 split_k=_split_for(wgs, n, K), M=n, N=K, K=dy.shape[0])
     return None if sink is not None else dst
 
 
