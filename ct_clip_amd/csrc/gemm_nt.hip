@@ -44,6 +44,9 @@
 #ifndef NT_STREAM_MB
 #define NT_STREAM_MB 128     // outputs larger than this use non-temporal stores
 #endif
+#ifndef NT_GELU_TAIL
+#define NT_GELU_TAIL 1         // GEGLU forward epilogue: 1 = gelu_tail_fast (one transcendental), 0 = gelu_erf_fast (A/B builds)
+#endif
 #ifndef NT_GEGLU_ABL
 #define NT_GEGLU_ABL 0       // ablations of the GEGLU forward epilogue: 1 = x * gate instead of x * gelu(gate), 2 = no stores
 #endif
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(NtParams p) {
 #if NT_GEGLU_ABL & 1
                   g[b] = x[b] * gt[b];
 #else
-                  g[b] = x[b] * gelu_erf_fast(gt[b]);
+                  g[b] = x[b] * (NT_GELU_TAIL ? gelu_tail_fast(gt[b]) : gelu_erf_fast(gt[b]));
 #endif
                 }
                 gg[q] = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};

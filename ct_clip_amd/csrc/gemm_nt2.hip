@@ -24,6 +24,9 @@
 // families (bit 0 plain / residual, bit 1 GEGLU forward, bit 2 GEGLU backward).  DEFAULT 0: MEASURED SLOWER than the first form on every family
 // (1.02 - 1.43 x per launch, profiles/r05_gemm_nt2.md) -- the kernel stays as the measurement, bit-identical to gemm_nt.hip.
 #include "common.h"
+#ifndef NT_GELU_TAIL
+#define NT_GELU_TAIL 1         // as in gemm_nt.hip
+#endif
 #include <stdlib.h>
 #include <type_traits>
 
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_nt2_kernel(Nt2Params p) {
 #pragma unroll
               for (int b = 0; b < 4; ++b) {
                 x[b] = acc[a][b][r] * p.alpha; gt[b] = acc[a][4 + b][r] * p.alpha;
-                g[b] = x[b] * gelu_erf_fast(gt[b]);
+                g[b] = x[b] * (NT_GELU_TAIL ? gelu_tail_fast(gt[b]) : gelu_erf_fast(gt[b]));
               }
               gg[q] = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
               if (WU) { ux[q] = u32x2{pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}; ug[q] = u32x2{pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3])}; }
