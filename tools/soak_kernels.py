@@ -151,3 +151,36 @@ soak("gemm_nt2 plain + residual (N=512, K=1408)", lambda: [be.gemm(g1408, w_ffou
 soak("gemm_nt2 in-projection + GEGLU (u, g)", lambda: as_list(be.gemm_geglu(x512, w_il, 1408)))
 soak("gemm_nt2 out-projection grad-input + GEGLU backward", lambda: [be.gemm_dgeglu(x512, wt_out, u)])
 be.gemm_nt2_select(prev_mask)
+# ---- round 6, late: the BERT attention on workgroup-shared LDS tiles (csrc/attn.hip attn64_*: double-buffered ring, one barrier per step), the
+# counting-sort placement, the latent projection's new forms, LayerNorm with 8 / 4 rows in flight
+nsq, Hb, Lb, Db = 8, 12, 512, 64
+qb, kb, vb, dob = (rnd(nsq * Lb, Hb * Db, scale=0.5) for _ in range(4))
+maskb = torch.zeros(nsq, Lb, device=dev)
+maskb[:, Lb - 37:] = torch.finfo(torch.float32).min
+vtb = be.head_transpose(vb, nsq, Hb, Lb, Db)
+dropb = (0.1, 1234567)
+soak("attn64 fwd (8 x 12 x 512 x 64, key mask, dropout)", lambda: as_list(be.attn_fwd(qb, kb, vtb, None, maskb, nsq, Hb, Lb, Db, 0.125, dropout=dropb)))
+ob, lseb = be.attn_fwd(qb, kb, vtb, None, maskb, nsq, Hb, Lb, Db, 0.125, dropout=dropb)
+qtb, ktb, dotb = (be.head_transpose(t, nsq, Hb, Lb, Db) for t in (qb, kb, dob))
+dqb, dkb, dvb = torch.empty_like(qb), torch.empty_like(qb), torch.empty_like(qb)
+
+
+def attn64_bwd():
+    be.attn_bwd(qb, kb, vb, qtb, ktb, ob, dob, dotb, lseb, None, maskb, dqb, dkb, dvb, None, nsq, Hb, Lb, Db, 0.125, dropout=dropb)
+    return [dqb, dkb, dvb]
+
+
+soak("attn64 bwd (dq, dk / dv)", attn64_bwd)
+keys = torch.randint(0, 8192, (M,), device=dev)
+sc = rnd(M, dtype=torch.float32)
+seg_out, seg_cnt = torch.zeros(8192, 512, device=dev), torch.zeros(8192, device=dev)
+soak("segment_sum (110592 rows -> 8192 codes: hist / scan / place / sum)", lambda: [be.segment_sum(keys, x512, seg_out.zero_(), 8192, rowscale=sc, counts=seg_cnt), seg_out, seg_cnt][1:])
+xl, wl, dyl = rnd(8, 294912, dtype=torch.float32), rnd(512, 294912, scale=0.01, dtype=torch.float32), rnd(8, 512, dtype=torch.float32)
+dwl = torch.zeros(512, 294912, device=dev)
+soak("visual_latent_fwd (8 x 294912 -> 512)", lambda: [be.visual_latent_fwd(xl, wl)])
+soak("visual_latent_bwd (overwrite)", lambda: [be.visual_latent_bwd(dyl, xl, wl, dwl, accumulate=False), dwl])
+xl18, dyl18 = rnd(18, 294912, dtype=torch.float32), rnd(18, 512, dtype=torch.float32)
+soak("visual_latent_bwd (18 rows, accumulate)", lambda: [be.visual_latent_bwd(dyl18, xl18, wl, dwl.zero_(), accumulate=True), dwl])
+yl, meanl, rstdl = be.layernorm_fwd(x512, gamma, beta, 1e-5)
+dgl, dbl = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+soak("layernorm_bwd + two addends", lambda: [be.layernorm_bwd(x512, x512, gamma, meanl, rstdl, dgl.zero_(), dbl.zero_(), x512, x512), dgl, dbl])
